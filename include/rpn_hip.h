@@ -1,0 +1,170 @@
+/*
+ * rpn_hip.h -- C ABI of librpn_hip.so: the MI355X (gfx950) Region Proposal Network
+ * forward / proposal path.
+ *
+ * The reference (FurkanOM/tf-rpn) is pure Python on TensorFlow 2.0 and has no FFI of
+ * its own; the boundary it offers is a handful of Python call signatures.  Every entry
+ * point below names the reference interface (file:line under /root/reference) it
+ * replaces; tf_rpn_amd/ binds them with ctypes under the reference's own function
+ * names (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - all `d_` pointers are DEVICE pointers (hipMalloc / torch.cuda storage), float32,
+ *     row-major, box order [y1, x1, y2, x2]; the caller allocates every output.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call
+ *     is asynchronous on that stream and never synchronises the device.
+ *   - return value: 0 on success, a negative rpn_status otherwise; rpn_last_error()
+ *     returns a thread-local human-readable message for the last failure.
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with
+ *     RPN_ERR_NO_DEVICE.
+ */
+#ifndef RPN_HIP_H
+#define RPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPN_ABI_VERSION 1
+
+typedef enum rpn_status {
+    RPN_OK = 0,
+    RPN_ERR_INVALID = -1,      /* bad argument (shape, null pointer, unsupported size) */
+    RPN_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime error */
+    RPN_ERR_WORKSPACE = -3,    /* workspace too small */
+    RPN_ERR_UNSUPPORTED = -4   /* configuration outside the implemented range */
+} rpn_status;
+
+typedef enum rpn_backbone { RPN_BACKBONE_VGG16 = 0, RPN_BACKBONE_MOBILENET_V2 = 1 } rpn_backbone;
+
+/* arithmetic of the conv stack.  F32: exact float32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit
+ * an ordered fmaf chain.  BF16X3: every f32 operand is split into hi+lo bfloat16 and each
+ * product is formed as hi*hi + hi*lo + lo*hi on the bf16 MFMA with float32 accumulation
+ * (~2^-16 relative error per product; measured against the 1e-4 parity bound in tests). */
+typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1 } rpn_precision;
+
+int rpn_abi_version(void);
+const char *rpn_last_error(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int rpn_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * generate_anchors(hyper_params) -> (A,4)            utils/bbox_utils.py:23-46 (+ :3-21)
+ *   A = feature_map_shape^2 * n_ratios * n_scales, flat index (y*F + x)*K + k,
+ *   k = scale_idx*n_ratios + ratio_idx.  ratios / scales are the python floats of
+ *   hyper_params["anchor_ratios"/"anchor_scales"] (HOST arrays of double).
+ * ---------------------------------------------------------------------------------- */
+int rpn_generate_anchors(double img_size, int feature_map_shape, const double *ratios, int n_ratios,
+                         const double *scales, int n_scales, float *d_anchors, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * get_bboxes_from_deltas(anchors, deltas) -> (B,A,4)          utils/bbox_utils.py:72-96
+ *   fused with the caller's `rpn_bbox_deltas *= variances`       predictor.py:55
+ *   d_anchors is (A,4) when anchors_batched == 0 (the predictor.py:56 call shape), else (B,A,4).
+ *   variances: HOST pointer to 4 floats, or NULL for no scaling.
+ * ---------------------------------------------------------------------------------- */
+int rpn_decode(const float *d_anchors, int anchors_batched, const float *d_deltas, const float *variances,
+               int B, int A, float *d_boxes, void *stream);
+
+/* get_deltas_from_bboxes(bboxes, gt_boxes) -> (B,A,4)        utils/bbox_utils.py:98-124 */
+int rpn_encode(const float *d_bboxes, int bboxes_batched, const float *d_gt_boxes, int B, int A,
+               float *d_deltas, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * generate_iou_map(bboxes, gt_boxes) -> (B,A,G)              utils/bbox_utils.py:126-150
+ *   d_bboxes is (A,4) when bboxes_batched == 0 (the utils/train_utils.py:106 call shape).
+ * ---------------------------------------------------------------------------------- */
+int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, const float *d_gt_boxes, int B, int G,
+                float *d_iou, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * non_max_suppression(pred_bboxes, pred_labels, **kwargs)      utils/bbox_utils.py:48-70
+ *   == tf.image.combined_non_max_suppression (TF 2.0.0 kernel semantics).
+ *   d_boxes (B,N,q,4) with q in {1,C}; d_scores (B,N,C).
+ *   Outputs (M = max_total; the pad_per_class rule is applied by the caller):
+ *   d_out_boxes (B,M,4), d_out_scores (B,M), d_out_classes (B,M) float32,
+ *   d_out_valid (B) int32, and -- not returned by TF, for parity checks -- d_out_idx (B,M)
+ *   int32 box indices (-1 padded; may be NULL).
+ *   d_workspace: rpn_nms_workspace_bytes(...) bytes of device scratch (may be NULL if 0).
+ * ---------------------------------------------------------------------------------- */
+size_t rpn_nms_workspace_bytes(int B, int N, int C, int max_per_class, int max_total);
+int rpn_combined_nms(const float *d_boxes, const float *d_scores, int B, int N, int q, int C,
+                     int max_per_class, int max_total, float iou_threshold, float score_threshold,
+                     int clip_boxes, float *d_out_boxes, float *d_out_scores, float *d_out_classes,
+                     int32_t *d_out_idx, int32_t *d_out_valid, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * predictor.py:52-56 + NMS in one launch sequence: (reg,cls) head outputs -> proposals.
+ *   d_deltas (B,A,4) raw head output, d_scores (B,A) objectness, d_anchors (A,4);
+ *   boxes are decoded lazily inside the NMS kernel (never materialised in HBM).
+ * ---------------------------------------------------------------------------------- */
+int rpn_decode_nms(const float *d_anchors, const float *d_deltas, const float *variances,
+                   const float *d_scores, int B, int A, int max_total, float iou_threshold,
+                   float score_threshold, int clip_boxes, float *d_out_boxes, float *d_out_scores,
+                   int32_t *d_out_idx, int32_t *d_out_valid, void *d_workspace, size_t workspace_bytes,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * get_model(hyper_params) -> rpn_model            models/rpn_vgg16.py:6-22,
+ *                                                 models/rpn_mobilenet_v2.py:6-22
+ * rpn_model.predict_on_batch(imgs) -> [reg, cls]  predictor.py:50
+ *   The handle owns the packed device weights and the activation workspace.
+ *   Weights are addressed by the Keras layer names the reference's
+ *   load_weights(by_name=True) uses (predictor.py:44): "block1_conv1" ... "rpn_conv",
+ *   "rpn_cls", "rpn_reg"; MobileNetV2: "Conv1", "bn_Conv1", "block_3_depthwise_BN", ...
+ * ---------------------------------------------------------------------------------- */
+typedef struct rpn_model rpn_model;
+
+int rpn_model_create(int backbone, int img_size, int anchor_count, int precision, int max_batch,
+                     rpn_model **out);
+void rpn_model_destroy(rpn_model *m);
+/* feature-map side F (31 for vgg16@500, 32 for mobilenet_v2@500) and head widths */
+int rpn_model_feature_map_shape(const rpn_model *m);
+/* number of weight-carrying layers, and the i-th layer's name / kernel shape (R,S,Cin,Cout) /
+ * kind: 0 conv+bias, 1 conv (no bias) followed by BatchNorm, 2 depthwise conv followed by BatchNorm */
+int rpn_model_num_layers(const rpn_model *m);
+int rpn_model_layer_info(const rpn_model *m, int i, char *name, int name_len, int shape[4], int *kind);
+/* Keras name of the BatchNormalization layer that follows layer i ("" when there is none) */
+int rpn_model_layer_bn_name(const rpn_model *m, int i, char *name, int name_len);
+/* device memory the handle needs (packed weights; activation arena for max_batch images) */
+int rpn_model_memory_bytes(const rpn_model *m, size_t *weights, size_t *arena);
+/* keep every intermediate activation alive (unique arena offsets) so that rpn_model_get_activation can
+ * read any layer after a forward pass; must be called before the first set_layer / forward */
+int rpn_model_keep_activations(rpn_model *m, int keep);
+/* HOST pointers: kernel HWIO float32 (depthwise: (R,S,C,1)); bias (Cout) or NULL;
+ * bn = {gamma, beta, moving_mean, moving_variance} each (Cout) or NULL (folded on the host, eps 1e-3) */
+int rpn_model_set_layer(rpn_model *m, const char *name, const float *kernel, const float *bias,
+                        const float *bn_gamma, const float *bn_beta, const float *bn_mean,
+                        const float *bn_var);
+/* d_imgs (B,img,img,3) NHWC float32 in [0,1] (utils/data_utils.py:25-26);
+ * d_reg (B,F,F,4K), d_cls (B,F,F,K) -- the reference's output order is [reg, cls]
+ * (models/rpn_vgg16.py:21). */
+int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float *d_reg, float *d_cls, void *stream);
+/* debug / test hook: copy the activation of layer `name` (NHWC float32) into d_out */
+int rpn_model_get_activation(rpn_model *m, const char *name, float *d_out, size_t out_bytes, int shape[4],
+                             void *stream);
+/* algorithmic FLOPs (2*MACs) of one image through the conv stack */
+double rpn_model_flops_per_image(const rpn_model *m);
+
+/* ------------------------------------------------------------------------------------
+ * single conv layer, for kernel-level parity tests and micro-benchmarks.
+ *   x (B,H,W,Cin) NHWC, w HWIO (device), bias (Cout, device, may be NULL).
+ *   pad_t / pad_l: zero rows/cols added before the first row/col; OH/OW given by the caller.
+ *   act: 0 linear, 1 relu, 2 sigmoid, 3 relu6.
+ * ---------------------------------------------------------------------------------- */
+int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const float *d_w, const float *d_bias,
+               int R, int S, int Cout, int stride, int pad_t, int pad_l, int OH, int OW, int act,
+               int precision, float *d_out, void *stream);
+int rpn_maxpool2x2(const float *d_x, int B, int H, int W, int C, float *d_out, void *stream);
+/* depthwise 3x3 (MobileNetV2): d_w (3,3,C), d_bias (C) or NULL, C % 4 == 0 */
+int rpn_dwconv3x3(const float *d_x, int B, int H, int W, int C, const float *d_w, const float *d_bias,
+                  int stride, int pad_t, int pad_l, int OH, int OW, int act, float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPN_HIP_H */

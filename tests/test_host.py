@@ -1,0 +1,148 @@
+"""CPU suite, part 2: host logic and the C-ABI boundary (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as entry
+from tf_rpn_amd import _lib as L
+from tf_rpn_amd.utils import train_utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        entry.build()
+    return L.lib()
+
+
+# ---- C ABI ------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "rpn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(rpn_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "librpn_hip.so does not export %s" % name
+    assert declared == L.exported_symbols(), "ctypes table and include/rpn_hip.h disagree"
+    assert lib.rpn_abi_version() == 1
+
+
+def test_no_torch_types_in_the_abi():
+    header = open(os.path.join(ROOT, "include", "rpn_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)              # comments may mention torch storage
+    assert "torch" not in code.lower() and "at::" not in code and "#include <hip" not in code
+
+
+def test_product_never_imports_the_oracle():
+    for base, _dirs, files in os.walk(os.path.join(ROOT, "tf_rpn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                assert "oracle" not in src, "%s mentions the oracle" % os.path.join(base, f)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_compute_calls_fail_loudly_without_a_device(lib):
+    assert lib.rpn_device_count() == 0
+    buf = (ctypes.c_float * 16)()
+    st = lib.rpn_decode(ctypes.cast(buf, L.vp), 0, ctypes.cast(buf, L.vp), None, 1, 1, ctypes.cast(buf, L.vp), None)
+    assert st == L.RPN_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.rpn_last_error()
+    from tf_rpn_amd.utils import bbox_utils
+    with pytest.raises(RuntimeError):
+        bbox_utils.generate_anchors(train_utils.get_hyper_params("vgg16"))
+
+
+def test_argument_validation_precedes_device_use(lib):
+    st = lib.rpn_combined_nms(None, None, 1, 10, 2, 3, 5, 5, 0.5, 0.0, 1, None, None, None, None, None, None, 0, None)
+    assert st == L.RPN_ERR_INVALID and b"q must be 1 or C" in lib.rpn_last_error()
+    h = L.vp(0)
+    assert lib.rpn_model_create(7, 500, 9, 0, 1, ctypes.byref(h)) == L.RPN_ERR_INVALID
+
+
+# ---- native graph builder (runs without a GPU: device buffers are allocated lazily) --------------
+@pytest.mark.parametrize("backbone,img,K,F,gflops,nlayers", [
+    ("vgg16", 500, 9, 31, 156.552, 16),
+    ("mobilenet_v2", 500, 9, 32, 7.737, 43),
+    ("vgg16", 1024, 15, 64, 661.07, 16),
+    ("mobilenet_v2", 1024, 15, 64, 31.282, 43),
+])
+def test_graph_builder_shapes_and_flops(lib, backbone, img, K, F, gflops, nlayers):
+    from tf_rpn_amd.models._rpn_model import RPNModel
+    m = RPNModel(backbone, {"img_size": img, "anchor_count": K}, max_batch=2)
+    assert m.feature_map_shape == F
+    assert abs(m.flops_per_image / 1e9 - gflops) < 0.01
+    assert len(m.layers) == nlayers
+    names = [l["name"] for l in m.layers]
+    assert names[-3:] == ["rpn_conv", "rpn_reg", "rpn_cls"]
+    assert m.layers[-2]["shape"] == (1, 1, 512, 4 * K) and m.layers[-1]["shape"] == (1, 1, 512, K)
+    if backbone == "vgg16":
+        assert names[0] == "block1_conv1" and m.layers[0]["shape"] == (3, 3, 3, 64)
+        assert m.activation_shape("block3_pool")[1:] == (img // 8, img // 8, 256)
+    else:
+        assert m.layers[0]["bn_name"] == "bn_Conv1" and m.layers[1]["kind"] == 2
+        assert m.activation_shape("block_13_expand")[1:] == (F, F, 576)
+        sides = [m.activation_shape(n)[1] for n in ("Conv1", "block_1_depthwise", "block_3_depthwise", "block_6_depthwise")]
+        assert sides == ([250, 125, 63, 32] if img == 500 else [512, 256, 128, 64])
+    w_bytes, arena_bytes = m.memory_bytes()
+    assert w_bytes > 0 and arena_bytes > 0
+
+
+# ---- config --------------------------------------------------------------------------------
+def test_get_hyper_params_contract():
+    import copy
+    saved = copy.deepcopy(train_utils.RPN)
+    try:
+        hp = train_utils.get_hyper_params("vgg16")
+        assert hp is train_utils.RPN["vgg16"]                       # mutates the module dict, as the reference
+        assert (hp["img_size"], hp["feature_map_shape"], hp["anchor_count"], hp["test_nms_topn"]) == (500, 31, 9, 300)
+        assert hp["variances"] == [0.1, 0.1, 0.2, 0.2] and hp["anchor_ratios"] == [1.0, 2.0, 0.5]
+        hp = train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                          anchor_ratios=[1., 2., .5, 3., 1 / 3.], unknown_key=5, test_nms_topn=0)
+        assert hp["anchor_count"] == 15 and hp["img_size"] == 1024 and "unknown_key" not in hp
+        assert hp["test_nms_topn"] == 300                          # falsy override ignored
+    finally:
+        train_utils.RPN.clear()
+        train_utils.RPN.update(saved)
+
+
+def test_hyper_params_agree_with_oracle():
+    import copy
+    from oracle import bbox_oracle as bo
+    saved = copy.deepcopy(train_utils.RPN)
+    try:
+        for bb in ("vgg16", "mobilenet_v2"):
+            assert train_utils.get_hyper_params(bb) == bo.get_hyper_params(bb)
+    finally:
+        train_utils.RPN.clear()
+        train_utils.RPN.update(saved)
+
+
+# ---- sharding / record packing ----------------------------------------------------------------
+def test_shard_bounds_cover_the_batch():
+    from tf_rpn_amd.predictor import shard_bounds
+    for total in (0, 1, 7, 8, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_record_pack_unpack_round_trip():
+    from tf_rpn_amd.predictor import Proposer
+    B, M = 3, 7
+    boxes, scores = torch.rand(B, M, 4), torch.rand(B, M)
+    valid = torch.tensor([7, 0, 3], dtype=torch.int32)
+    rec = Proposer.pack_records(None, boxes, scores, valid)
+    assert rec.shape == (B, M * 5 + 1)
+    b2, s2, v2 = Proposer.unpack_records(rec, M)
+    assert torch.equal(b2, boxes) and torch.equal(s2, scores) and torch.equal(v2, valid)

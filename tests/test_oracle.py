@@ -1,0 +1,174 @@
+"""CPU suite, part 1: the oracle itself.
+
+The reference has no tests or golden vectors, so the oracle is pinned three
+ways: (a) the committed restatement-generated fixtures, (b) agreement of two independent
+restatements (numpy vs plain C), (c) the self-consistency relations the reference's own
+functions offer (encode o decode = id, layout agreement, IoU invariants) and facts derived in
+SURVEY.md section 8a (base-anchor values, duplicate counts).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---- (a) golden fixtures -----------------------------------------------------------------
+def test_anchor_fixtures(golden_dir):
+    g = _load(golden_dir, "anchors.npz")
+    assert np.array_equal(bo.generate_anchors(bo.get_hyper_params("vgg16", feature_map_shape=4)), g["anchors_small_f4"])
+    for bb in ("vgg16", "mobilenet_v2"):
+        hp = bo.get_hyper_params(bb)
+        assert np.array_equal(bo.generate_anchors(hp), g["anchors_" + bb])
+        assert np.array_equal(co.generate_anchors(hp), g["anchors_" + bb])          # C restatement, bit-exact
+    assert np.array_equal(bo.generate_base_anchors(bo.get_hyper_params("vgg16")), g["base_anchors_default"])
+
+
+def test_boxmath_fixtures(golden_dir):
+    g = _load(golden_dir, "boxmath.npz")
+    scaled = bo.scale_deltas(g["deltas"], g["variances"])
+    assert np.array_equal(bo.get_bboxes_from_deltas(g["anchors"], scaled), g["boxes"])
+    # C uses glibc expf, numpy its own SIMD exp: a few ulp apart, far inside the 1e-4 bound
+    np.testing.assert_allclose(co.decode(g["anchors"], g["deltas"], g["variances"]), g["boxes"], rtol=0, atol=2e-6)
+    assert np.array_equal(bo.generate_iou_map(g["anchors"], g["gt"]), g["iou_map"])
+    assert np.array_equal(co.iou_map(g["anchors"], g["gt"]), g["iou_map"])
+    assert np.array_equal(bo.get_deltas_from_bboxes(g["anchors"], g["gt_per_anchor"]), g["encoded"])
+    np.testing.assert_allclose(co.encode(g["anchors"], g["gt_per_anchor"]), g["encoded"], rtol=0, atol=2e-6)
+
+
+_NMS_CASES = {
+    "edge_default": dict(max_output_size_per_class=20, max_total_size=20),
+    "edge_thr07_noclip": dict(max_output_size_per_class=64, max_total_size=64, iou_threshold=0.7, clip_boxes=False),
+    "edge_score_thr": dict(max_output_size_per_class=64, max_total_size=10, score_threshold=0.5),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_NMS_CASES))
+def test_nms_edge_fixtures(golden_dir, name):
+    g = _load(golden_dir, "nms.npz")
+    boxes, scores = g["edge_boxes"][None, :, None, :], g["edge_scores"][None, :, None]
+    for impl in (lambda: bo.combined_non_max_suppression(boxes, scores, return_indices=True, **_NMS_CASES[name]),
+                 lambda: co.combined_nms(boxes, scores, **_NMS_CASES[name])):
+        r = impl()
+        for key, arr in zip(("boxes", "scores", "classes", "valid", "idx"), r):
+            assert np.array_equal(arr, g["%s_%s" % (name, key)], equal_nan=True), (name, key)
+
+
+def test_nms_multiclass_fixtures(golden_dir):
+    g = _load(golden_dir, "nms.npz")
+    for name, bx, kw in (
+        ("mc_q1", g["mc_boxes"][:, :, None, :], dict(max_output_size_per_class=5, max_total_size=12)),
+        ("mc_qc", g["mc_boxes_q"], dict(max_output_size_per_class=6, max_total_size=40, pad_per_class=True,
+                                        iou_threshold=0.3)),
+    ):
+        for r in (bo.combined_non_max_suppression(bx, g["mc_scores"], return_indices=True, **kw),
+                  co.combined_nms(bx, g["mc_scores"], **kw)):
+            for key, arr in zip(("boxes", "scores", "classes", "valid", "idx"), r):
+                assert np.array_equal(arr, g["%s_%s" % (name, key)]), (name, key)
+
+
+# ---- (b) numpy vs C on fresh seeded inputs ----------------------------------------------------
+def test_numpy_and_c_nms_agree_on_random_images():
+    rng = np.random.RandomState(11)
+    boxes = cases.clustered_boxes(rng, 3, 400, n_clusters=20)
+    scores = cases.permutation_scores(rng, 3, 400)
+    for thr in (0.5, 0.7):
+        kw = dict(max_output_size_per_class=60, max_total_size=60, iou_threshold=thr)
+        a = bo.combined_non_max_suppression(boxes[:, :, None, :], scores[:, :, None], return_indices=True, **kw)
+        b = co.combined_nms(boxes[:, :, None, :], scores[:, :, None], **kw)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert (a[3] > 0).all()
+
+
+def test_c_conv_matches_torch_conv():
+    from oracle import conv_oracle as cv
+    rng = np.random.RandomState(3)
+    x = rng.uniform(0, 1, size=(2, 9, 11, 5)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 5, 7)).astype(np.float32)
+    b = rng.standard_normal((7,)).astype(np.float32)
+    ref = cv.conv2d_nhwc(x, w, b, pad=(1, 1, 1, 1), act="relu")
+    got = co.conv2d(x, w, b, pad_t=1, pad_l=1, out_hw=(9, 11), act="relu")
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    # stride 2 with the keras correct_pad rule for an odd size: pad (1,1)
+    ref = cv.conv2d_nhwc(x, w, None, stride=2, pad=(1, 1, 1, 1))
+    got = co.conv2d(x, w, None, stride=2, pad_t=1, pad_l=1, out_hw=(5, 6))
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(co.maxpool2x2(x[..., :4]),
+                                  x[:, :8, :10, :4].reshape(2, 4, 2, 5, 2, 4).max(axis=(2, 4)))
+
+
+# ---- (c) properties and derived facts ----------------------------------------------------------
+def test_base_anchor_values_match_survey():
+    base = bo.generate_base_anchors(bo.get_hyper_params("vgg16"))
+    assert base.shape == (9, 4)
+    np.testing.assert_array_equal(base[0], np.float32([-0.128, -0.128, 0.128, 0.128]))
+    np.testing.assert_allclose(base[1], [-0.18101934, -0.09050967, 0.18101934, 0.09050967], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(base[2], [-0.09050967, -0.18101934, 0.09050967, 0.18101934], rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(base[3:6], base[0:3] * 2)          # scale 256, 512: exact doubling
+    np.testing.assert_array_equal(base[6:9], base[0:3] * 4)
+
+
+@pytest.mark.parametrize("backbone,count,dups", [("vgg16", 8649, 744), ("mobilenet_v2", 9216, 832)])
+def test_anchor_counts_and_duplicates(backbone, count, dups):
+    a = bo.generate_anchors(bo.get_hyper_params(backbone))
+    assert a.shape == (count, 4) and a.min() >= 0 and a.max() <= 1
+    assert count - len(np.unique(a, axis=0)) == dups
+
+
+def test_anchor_layout_matches_head_layout():
+    """flat anchor index (y*F + x)*K + k == flat index of head output (B,F,F,K) -> (B,-1) (predictor.py:52-53)."""
+    hp = bo.get_hyper_params("vgg16", feature_map_shape=5)
+    F, K = 5, hp["anchor_count"]
+    a = bo.generate_anchors(hp).reshape(F, F, K, 4)
+    base = bo.generate_base_anchors(hp)
+    centres = ((np.arange(F) / F) + 0.5 / F).astype(np.float32)
+    y, x, k = 2, 3, 4                                                  # an interior cell: no clipping
+    np.testing.assert_array_equal(a[y, x, k], base[k] + np.float32([centres[y], centres[x], centres[y], centres[x]]))
+
+
+def test_encode_decode_round_trip():
+    rng = np.random.RandomState(5)
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16", feature_map_shape=6))
+    gt = cases.random_boxes(rng, (2, len(anchors)))
+    deltas = bo.get_deltas_from_bboxes(anchors, gt)
+    np.testing.assert_allclose(bo.get_bboxes_from_deltas(anchors, deltas), gt, rtol=0, atol=2e-6)
+
+
+def test_iou_map_invariants():
+    rng = np.random.RandomState(6)
+    b = cases.random_boxes(rng, (1, 40))
+    iou = bo.generate_iou_map(b[0], b)[0]
+    np.testing.assert_array_equal(np.diag(iou), np.ones(40, np.float32))
+    np.testing.assert_array_equal(iou, iou.T)
+    assert iou.min() >= 0 and iou.max() <= 1
+    padded = np.zeros((1, 3, 4), np.float32)
+    assert np.array_equal(bo.generate_iou_map(b[0], padded), np.zeros((1, 40, 3), np.float32))   # 0/area = 0
+
+
+def test_nms_iou_differs_from_map_iou_on_flipped_corners():
+    box, flipped = np.float32([0.1, 0.1, 0.5, 0.6]), np.float32([0.5, 0.6, 0.1, 0.1])
+    assert bo.nms_iou(box, flipped) == np.float32(1.0)                 # TF canonicalises corners
+    assert bo.generate_iou_map(box[None], flipped[None, None])[0, 0, 0] != np.float32(1.0)
+    assert bo.nms_iou(box, np.float32([0.3, 0.3, 0.3, 0.9])) == 0       # zero area -> 0
+    assert co.lib().orc_nms_iou(box.ctypes.data_as(co._f32p), flipped.ctypes.data_as(co._f32p)) == 1.0
+
+
+def test_nms_tie_order_and_padding():
+    boxes = np.float32([[0, 0, .1, .1], [.5, .5, .6, .6], [.2, .2, .3, .3], [.8, .8, .9, .9]])
+    scores = np.float32([0.5, 0.5, 0.5, 0.7])
+    b, s, c, v, idx = bo.combined_non_max_suppression(boxes[None, :, None], scores[None, :, None], 10, 6,
+                                                      return_indices=True)
+    assert v[0] == 4 and list(idx[0]) == [3, 0, 1, 2, -1, -1]           # ties -> lower index first
+    assert (b[0, 4:] == 0).all() and (s[0, 4:] == 0).all() and (c == 0).all()
+
+
+def test_top_k_ties_lower_index():
+    assert list(bo.top_k_indices(np.float32([[0.2, 0.9, 0.9, 0.1]]), 3)[0]) == [1, 2, 0]

@@ -1,0 +1,119 @@
+// bbox_core.h -- per-box arithmetic of the proposal path, written once for device code.
+//
+// Every function keeps the reference's operation order exactly (one float32 rounding
+// per multiply / add; this translation unit is compiled with -ffp-contract=off so no
+// FMA is formed) because NMS keep-masks and anchor values are required to be bit-exact.
+// Box order: [y1, x1, y2, x2].  Citations are /root/reference paths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rpn {
+
+struct Box {
+    float y1, x1, y2, x2;
+};
+
+__device__ __forceinline__ Box load_box(const float *p)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    return Box{v.x, v.y, v.z, v.w};
+}
+
+__device__ __forceinline__ void store_box(float *p, const Box &b)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(b.y1, b.x1, b.y2, b.x2);
+}
+
+__device__ __forceinline__ float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+// get_bboxes_from_deltas -- utils/bbox_utils.py:81-94; d = [dy, dx, dh, dw] (already x variances)
+__device__ __forceinline__ Box decode_box(const Box &an, float dy, float dx, float dh, float dw)
+{
+    const float w = an.x2 - an.x1;              // :81
+    const float h = an.y2 - an.y1;              // :82
+    const float cx = an.x1 + 0.5f * w;          // :83
+    const float cy = an.y1 + 0.5f * h;          // :84
+    const float bw = expf(dw) * w;              // :86
+    const float bh = expf(dh) * h;              // :87
+    const float bcx = (dx * w) + cx;            // :88
+    const float bcy = (dy * h) + cy;            // :89
+    Box o;
+    o.y1 = bcy - (0.5f * bh);                   // :91
+    o.x1 = bcx - (0.5f * bw);                   // :92
+    o.y2 = bh + o.y1;                           // :93
+    o.x2 = bw + o.x1;                           // :94
+    return o;
+}
+
+// get_deltas_from_bboxes -- utils/bbox_utils.py:107-124; returns [dy, dx, dh, dw]
+__device__ __forceinline__ float4 encode_box(const Box &bb, const Box &gt)
+{
+    float bw = bb.x2 - bb.x1, bh = bb.y2 - bb.y1;
+    const float bcx = bb.x1 + 0.5f * bw, bcy = bb.y1 + 0.5f * bh;
+    const float gw = gt.x2 - gt.x1, gh = gt.y2 - gt.y1;
+    const float gcx = gt.x1 + 0.5f * gw, gcy = gt.y1 + 0.5f * gh;
+    if (bw == 0.0f) bw = 1e-3f;                                  // :117
+    if (bh == 0.0f) bh = 1e-3f;                                  // :118
+    float4 d;
+    d.y = (gw == 0.0f) ? 0.0f : (gcx - bcx) / bw;                // :119 dx
+    d.x = (gh == 0.0f) ? 0.0f : (gcy - bcy) / bh;                // :120 dy
+    d.w = (gw == 0.0f) ? 0.0f : logf(gw / bw);                   // :121 dw
+    d.z = (gh == 0.0f) ? 0.0f : logf(gh / bh);                   // :122 dh
+    return d;
+}
+
+// generate_iou_map -- utils/bbox_utils.py:138-150 for one (bbox, gt) pair
+__device__ __forceinline__ float iou_map_pair(const Box &b, float b_area, const Box &g, float g_area)
+{
+    const float xt = b.x1 > g.x1 ? b.x1 : g.x1;                  // :141
+    const float yt = b.y1 > g.y1 ? b.y1 : g.y1;                  // :142
+    const float xb = b.x2 < g.x2 ? b.x2 : g.x2;                  // :143
+    const float yb = b.y2 < g.y2 ? b.y2 : g.y2;                  // :144
+    const float dx = xb - xt, dy = yb - yt;
+    const float inter = (dx > 0.0f ? dx : 0.0f) * (dy > 0.0f ? dy : 0.0f);   // :146
+    const float uni = b_area + g_area - inter;                   // :148
+    return inter / uni;                                          // :150 (no epsilon)
+}
+
+__device__ __forceinline__ float box_area_plain(const Box &b) { return (b.y2 - b.y1) * (b.x2 - b.x1); }
+
+// ---- TF CombinedNonMaxSuppression internals (utils/bbox_utils.py:66) ----
+__device__ __forceinline__ float tf_min(float a, float b) { return b < a ? b : a; }   // std::min
+__device__ __forceinline__ float tf_max(float a, float b) { return a < b ? b : a; }   // std::max
+
+// canonical corners + area of one box, computed once per candidate
+struct CBox {
+    float ymin, xmin, ymax, xmax, area;
+};
+
+__device__ __forceinline__ CBox canonical(const Box &b)
+{
+    CBox c;
+    c.ymin = tf_min(b.y1, b.y2);
+    c.xmin = tf_min(b.x1, b.x2);
+    c.ymax = tf_max(b.y1, b.y2);
+    c.xmax = tf_max(b.x1, b.x2);
+    c.area = (c.ymax - c.ymin) * (c.xmax - c.xmin);
+    return c;
+}
+
+// IoU(candidate i, selected j) exactly as TF's NMS kernel evaluates it
+__device__ __forceinline__ float nms_iou(const CBox &i, const CBox &j)
+{
+    if (i.area <= 0.0f || j.area <= 0.0f) return 0.0f;
+    const float iymin = tf_max(i.ymin, j.ymin), ixmin = tf_max(i.xmin, j.xmin);
+    const float iymax = tf_min(i.ymax, j.ymax), ixmax = tf_min(i.xmax, j.xmax);
+    const float inter = tf_max(iymax - iymin, 0.0f) * tf_max(ixmax - ixmin, 0.0f);
+    return inter / (i.area + j.area - inter);
+}
+
+// monotone map float -> uint32 (descending float order == descending uint order);
+// -0.0 is folded onto +0.0 so that equal scores tie exactly as a float compare would.
+__device__ __forceinline__ unsigned orderable(float s)
+{
+    if (s == 0.0f) s = 0.0f;
+    const unsigned u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+}  // namespace rpn

@@ -1,0 +1,56 @@
+// conv_kernels.h -- host-side interface of the conv / pool kernels (internal to librpn_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace rpn {
+
+enum Act { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_RELU6 = 3 };
+
+// Packed weight matrix of one dense conv layer, K-major: rows x cout_pad floats, zero padded.
+//   fast layout  (Cin % 4 == 0): row = tap * cin_pad + c,  cin_pad = round_up(Cin, 16)
+//   generic layout (any Cin)   : row = tap * Cin + c,      rows padded to a multiple of 16
+// cout_pad = round_up(Cout, 32).
+struct PackedShape {
+    int R, S, Cin, Cout;
+    int generic;      // 1 -> generic (flattened-K) layout
+    int cin_pad;      // fast layout only
+    int rows;         // total rows of the packed matrix
+    int cout_pad;
+    __host__ __device__ size_t floats() const { return (size_t)rows * cout_pad; }
+};
+
+PackedShape packed_shape(int R, int S, int Cin, int Cout);
+
+// pack HWIO (R,S,Cin,Cout) -> packed, on the host (scale[n] multiplies output channel n; may be null)
+void pack_weights_host(const PackedShape &ps, const float *hwio, const float *scale, float *dst);
+// same on the device (d_hwio, d_dst device pointers)
+void pack_weights_device(const PackedShape &ps, const float *d_hwio, float *d_dst, hipStream_t stream);
+
+struct ConvArgs {
+    const float *x;         // (B,H,W,Cin) NHWC
+    const float *w;         // packed weights (PackedShape)
+    const float *bias;      // (Cout) or null
+    const float *residual;  // (B,OH,OW,Cout) added before the activation, or null
+    float *out;             // (B,OH,OW,ld1): channels [0, split)
+    float *out2;            // (B,OH,OW,ld2): channels [split, Cout), or null
+    int B, H, W, Cin, OH, OW, Cout;
+    int R, S, stride, pad_t, pad_l;
+    int act, act2, split;   // split == Cout when there is a single output
+    int ld1, ld2;
+    PackedShape ps;
+};
+
+// dense convolution as an implicit GEMM on the f32 MFMA; returns hipGetLastError()
+hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream);
+
+// MaxPooling2D(2,2) 'valid' (floors odd sizes), NHWC, C % 4 == 0
+hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
+
+// depthwise 3x3 (+folded BN bias) + activation, NHWC; w is (3,3,C) with the BN scale folded in
+hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
+                            int stride, int pad_t, int pad_l, int OH, int OW, int act, float *out,
+                            hipStream_t stream);
+
+}  // namespace rpn

@@ -1,0 +1,402 @@
+// conv_kernels.hip -- the conv stack of the RPN forward path for gfx950 (MI355X).
+//
+// Keras Conv2D semantics (models/rpn_vgg16.py:16-20, models/rpn_mobilenet_v2.py:16-20):
+// NHWC x HWIO cross-correlation, bias add, then activation.  Dense convolutions run as an
+// implicit GEMM on the matrix cores:
+//     M = output pixels (an 8 x 16 spatial patch of one image per workgroup = 128 rows)
+//     N = output channels (32 / 64 / 128 per workgroup)
+//     K = taps x input channels, walked tap by tap in 16-channel slices
+// conv_igemm_f32 uses v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate, bit-for-bit an
+// ordered fmaf chain, so this path is the parity-clean one.  The im2col tile is never
+// materialised in HBM: each K-slice of the A operand is gathered from the NHWC input
+// (zero-filled at the borders) into LDS, k-major, so that MFMA fragment reads are
+// conflict-free ds_read_b32; global loads for slice s+1 are issued before the MFMAs of
+// slice s and written to the other LDS buffer afterwards (register-staged double buffer,
+// one barrier per slice).  Bias, residual add, activation and the reg/cls split of the
+// RPN head are fused into the epilogue.
+//
+// Roofline: MFMA-bound; 2*M*N*K flops per launch against 157.3 TFLOP/s (f32 MFMA peak).
+#include "conv_kernels.h"
+
+#include <cstring>
+
+namespace rpn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kConvThreads = 256;
+constexpr int BK = 16;                 // K-slice (input channels per step)
+constexpr int TH = 8, TW = 16;         // spatial patch of output pixels per workgroup
+constexpr int BM = TH * TW;            // 128 GEMM rows
+constexpr int LDA = BM + 2;            // +2 floats: conflict-free ds_write_b32 of the gathered tile
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+PackedShape packed_shape(int R, int S, int Cin, int Cout)
+{
+    PackedShape ps{};
+    ps.R = R; ps.S = S; ps.Cin = Cin; ps.Cout = Cout;
+    ps.generic = (Cin % 4 != 0) ? 1 : 0;
+    ps.cout_pad = round_up(Cout, 32);
+    if (ps.generic) {
+        ps.cin_pad = Cin;
+        ps.rows = round_up(R * S * Cin, BK);
+    } else {
+        ps.cin_pad = round_up(Cin, BK);
+        ps.rows = R * S * ps.cin_pad;
+    }
+    return ps;
+}
+
+void pack_weights_host(const PackedShape &ps, const float *hwio, const float *scale, float *dst)
+{
+    memset(dst, 0, ps.floats() * sizeof(float));
+    for (int t = 0; t < ps.R * ps.S; ++t)
+        for (int c = 0; c < ps.Cin; ++c) {
+            const int row = ps.generic ? (t * ps.Cin + c) : (t * ps.cin_pad + c);
+            const float *src = hwio + ((size_t)t * ps.Cin + c) * ps.Cout;
+            float *d = dst + (size_t)row * ps.cout_pad;
+            for (int n = 0; n < ps.Cout; ++n) d[n] = scale ? src[n] * scale[n] : src[n];
+        }
+}
+
+__global__ void pack_weights_kernel(PackedShape ps, const float *__restrict__ hwio, float *__restrict__ dst)
+{
+    const size_t total = ps.floats();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % ps.cout_pad);
+        const int row = (int)(i / ps.cout_pad);
+        int t, c;
+        if (ps.generic) {
+            t = row / ps.Cin;
+            c = row - t * ps.Cin;
+        } else {
+            t = row / ps.cin_pad;
+            c = row - t * ps.cin_pad;
+        }
+        float v = 0.0f;
+        if (n < ps.Cout && c < ps.Cin && t < ps.R * ps.S) v = hwio[((size_t)t * ps.Cin + c) * ps.Cout + n];
+        dst[i] = v;
+    }
+}
+
+void pack_weights_device(const PackedShape &ps, const float *d_hwio, float *d_dst, hipStream_t stream)
+{
+    const size_t total = ps.floats();
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, stream, ps, d_hwio, d_dst);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act)
+{
+    switch (act) {
+        case ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_RELU6: return v < 0.0f ? 0.0f : (v > 6.0f ? 6.0f : v);
+        default: return v;
+    }
+}
+
+// XCD-aware, bijective workgroup remap: hardware deals consecutive workgroup ids round-robin
+// over the 8 XCDs, so give each XCD a contiguous run of logical tiles (the N-tiles of one
+// M-tile, and neighbouring M-tiles, then share that XCD's L2).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int WM, int WN, int MI, int NI, bool GENERIC>
+__global__ void __launch_bounds__(kConvThreads)
+conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    static_assert(WM * WN == 4 && WM * MI * 32 == BM, "tile shape");
+    constexpr int BN = WN * NI * 32;
+    constexpr int B4 = BK * BN / 4;                                   // float4s in a B slice
+    constexpr int NB4 = (B4 + kConvThreads - 1) / kConvThreads;       // per thread
+
+    __shared__ float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = wg % n_tiles;
+    int mt = wg / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
+
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const int taps = a.R * a.S;
+
+    // ---- per-thread gather coordinates of the A tile -------------------------------------
+    // fast path: 2 pixels x one float4 (4 channels); generic path: 8 pixels x one scalar
+    constexpr int NA = GENERIC ? 8 : 2;
+    int a_iy0[NA], a_ix0[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int p = GENERIC ? ((tid >> 4) + 16 * j) : ((tid >> 2) + 64 * j);
+        a_iy0[j] = (oy0 + (p >> 4)) * a.stride - a.pad_t;
+        a_ix0[j] = (ox0 + (p & 15)) * a.stride - a.pad_l;
+    }
+    const int a_q = tid & 3;          // fast: channel quad
+    const int a_kk = tid & 15;        // generic: k within the slice
+
+    const int cpt = GENERIC ? 1 : (a.ps.cin_pad / BK);                 // slices per tap
+    const int nsteps = GENERIC ? (a.ps.rows / BK) : (taps * cpt);
+
+    float4 a_reg[GENERIC ? 1 : 2];
+    float a_sreg[GENERIC ? 8 : 1];
+    float4 b_reg[NB4];
+
+    auto load_global = [&](int step) {
+        if constexpr (GENERIC) {
+            const int k = step * BK + a_kk;
+            const bool kv = k < taps * a.Cin;
+            const int tap = k / a.Cin;
+            const int c = k - tap * a.Cin;
+            const int r = tap / a.S, s = tap - r * a.S;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
+                const bool v = kv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                a_sreg[j] = v ? xin[((size_t)iy * a.W + ix) * a.Cin + c] : 0.0f;
+            }
+        } else {
+            const int tap = step / cpt;
+            const int c0 = (step - tap * cpt) * BK + 4 * a_q;
+            const int r = tap / a.S, s = tap - r * a.S;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
+                const bool v = c0 < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                a_reg[j] = v ? *reinterpret_cast<const float4 *>(xin + ((size_t)iy * a.W + ix) * a.Cin + c0)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const int row0 = step * BK;      // both layouts: slice `step` covers packed rows [16*step, 16*step+16)
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int e = tid + i * kConvThreads;
+            const int kk = e / (BN / 4);
+            const int col = n0 + 4 * (e % (BN / 4));
+            const bool v = (B4 % kConvThreads == 0 || e < B4) && col < a.ps.cout_pad;
+            b_reg[i] = v ? *reinterpret_cast<const float4 *>(a.w + (size_t)(row0 + kk) * a.ps.cout_pad + col)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+        if constexpr (GENERIC) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) As[buf][a_kk][(tid >> 4) + 16 * j] = a_sreg[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = (tid >> 2) + 64 * j;
+                As[buf][4 * a_q + 0][p] = a_reg[j].x;
+                As[buf][4 * a_q + 1][p] = a_reg[j].y;
+                As[buf][4 * a_q + 2][p] = a_reg[j].z;
+                As[buf][4 * a_q + 3][p] = a_reg[j].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int e = tid + i * kConvThreads;
+            if (B4 % kConvThreads == 0 || e < B4) {
+                const int kk = e / (BN / 4);
+                const int nn = 4 * (e % (BN / 4));
+                *reinterpret_cast<float4 *>(&Bs[buf][kk][nn]) = b_reg[i];
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int am = wm * MI * 32 + (lane & 31);
+    const int bn = wn * NI * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        if (more) load_global(step + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[i] = As[cur][2 * kk + kh][am + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bv[j] = Bs[cur][2 * kk + kh][bn + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias + residual + activation, NHWC stores (32 lanes = 128 contiguous bytes) --
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * NI * 32 + j * 32 + (lane & 31);
+        if (n >= a.Cout) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+        const bool second = n >= a.split;
+        const int act = second ? a.act2 : a.act;
+        float *__restrict__ obase = second ? a.out2 : a.out;
+        const int ld = second ? a.ld2 : a.ld1;
+        const int ch = second ? n - a.split : n;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = wm * MI * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                if (oy < a.OH && ox < a.OW) {
+                    const size_t pix = ((size_t)img * a.OH + oy) * a.OW + ox;
+                    float v = acc[i][j][e] + bias;
+                    if (a.residual) v += a.residual[pix * a.Cout + n];
+                    obase[pix * ld + ch] = apply_act(v, act);
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MI, int NI>
+static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
+{
+    constexpr int BN = WN * NI * 32;
+    const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
+    const int n_tiles = (a.Cout + BN - 1) / BN;
+    const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
+    if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (a.ps.generic)
+        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+                           stream, a, tiles_x, tiles_y, n_tiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+                           stream, a, tiles_x, tiles_y, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream)
+{
+    if (a.Cout > 64) return launch_variant<2, 2, 2, 2>(a, stream);     // 128 x 128
+    if (a.Cout > 32) return launch_variant<4, 1, 1, 2>(a, stream);     // 128 x 64
+    return launch_variant<4, 1, 1, 1>(a, stream);                      // 128 x 32
+}
+
+// ---- MaxPooling2D(2,2) 'valid' -----------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool2x2_kernel(const float *__restrict__ x, int H, int W, int C4, int OH, int OW, long long total,
+                  float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const long long b = t / OH;
+        const float4 *p = reinterpret_cast<const float4 *>(x) + ((b * H + 2 * oy) * W + 2 * ox) * C4 + c;
+        const float4 v00 = p[0], v01 = p[C4], v10 = p[(size_t)W * C4], v11 = p[(size_t)W * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+        m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+        m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+        m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+        reinterpret_cast<float4 *>(out)[i] = m;
+    }
+}
+
+hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream)
+{
+    if (C % 4 != 0) return hipErrorInvalidValue;
+    const int OH = H / 2, OW = W / 2, C4 = C / 4;
+    const long long total = (long long)B * OH * OW * C4;
+    if (total == 0) return hipSuccess;
+    long long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, H, W, C4, OH, OW, total,
+                       out);
+    return hipGetLastError();
+}
+
+// ---- depthwise 3x3 + bias + activation (MobileNetV2) ---------------------------------------
+// HBM-bound: 4 B read + 4 B written per element (+ 9 taps served from L1/L2); one float4 of
+// channels per lane, lanes run along channels so every access is a contiguous 16-byte vector.
+__global__ void __launch_bounds__(256)
+dwconv3x3_kernel(const float *__restrict__ x, int H, int W, int C4, const float *__restrict__ w,
+                 const float *__restrict__ bias, int stride, int pad_t, int pad_l, int OH, int OW, int act,
+                 long long total, float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const long long b = t / OH;
+        float4 acc = bias ? reinterpret_cast<const float4 *>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * stride + r - pad_t;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox * stride + s - pad_l;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = reinterpret_cast<const float4 *>(x)[((b * H + iy) * W + ix) * C4 + c];
+                const float4 k = reinterpret_cast<const float4 *>(w)[(r * 3 + s) * C4 + c];
+                acc.x = fmaf(v.x, k.x, acc.x);
+                acc.y = fmaf(v.y, k.y, acc.y);
+                acc.z = fmaf(v.z, k.z, acc.z);
+                acc.w = fmaf(v.w, k.w, acc.w);
+            }
+        }
+        acc.x = apply_act(acc.x, act);
+        acc.y = apply_act(acc.y, act);
+        acc.z = apply_act(acc.z, act);
+        acc.w = apply_act(acc.w, act);
+        reinterpret_cast<float4 *>(out)[i] = acc;
+    }
+}
+
+hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const float *w, const float *bias,
+                            int stride, int pad_t, int pad_l, int OH, int OW, int act, float *out,
+                            hipStream_t stream)
+{
+    if (C % 4 != 0) return hipErrorInvalidValue;
+    const int C4 = C / 4;
+    const long long total = (long long)B * OH * OW * C4;
+    if (total == 0) return hipSuccess;
+    long long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, H, W, C4, w, bias, stride,
+                       pad_t, pad_l, OH, OW, act, total, out);
+    return hipGetLastError();
+}
+
+}  // namespace rpn

@@ -1,0 +1,574 @@
+// model.hip -- native graph builder + executor for the two RPN models of the reference:
+//   models/rpn_vgg16.py:15-21        VGG16 (to block5_conv3) + rpn_conv / rpn_cls / rpn_reg
+//   models/rpn_mobilenet_v2.py:15-21 MobileNetV2 alpha=1 (to block_13_expand_relu) + the same head
+// The Keras graphs themselves live in keras-applications 1.0.8 (not vendored by the reference);
+// layer names follow Keras so that weights can be addressed the way load_weights(by_name=True)
+// does (predictor.py:44).
+//
+// The handle owns (a) one device blob with every layer's packed weights (BatchNorm folded on
+// the host at load time) and (b) an activation arena planned by tensor liveness.  A forward
+// pass is a fixed sequence of kernel launches on the caller's stream: no allocation, no
+// synchronisation, so it can be captured into a hipGraph by the caller.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "conv_kernels.h"
+#include "rpn_common.h"
+
+namespace rpn {
+
+constexpr float kBnEps = 1e-3f;
+
+enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3 };
+
+struct Tensor {
+    std::string name;
+    int H = 0, W = 0, C = 0;
+    int def = -1, last_use = -1;       // op indices
+    size_t offset = 0;                 // floats per image inside the arena (x max_batch)
+    bool external = false;             // input images / head outputs
+    size_t floats() const { return (size_t)H * W * C; }
+};
+
+struct Param {
+    std::string name, bn_name;
+    int kind = 0;                      // 0 conv+bias, 1 conv+BN, 2 depthwise+BN
+    int R = 1, S = 1, Cin = 0, Cout = 0;
+    int op = -1;
+    int col_off = 0;                   // first output column inside the op's packed matrix
+    bool loaded = false;
+};
+
+struct Op {
+    int kind = OP_CONV;
+    std::string name;
+    int in = -1, out = -1, residual = -1;
+    int Cin = 0, Cout = 0, R = 1, S = 1, stride = 1, pad_t = 0, pad_l = 0;
+    int H = 0, W = 0, OH = 0, OW = 0;
+    int act = ACT_LINEAR;
+    PackedShape ps{};
+    size_t w_off = 0, b_off = 0;       // floats into the weight blob
+    std::vector<int> params;
+};
+
+}  // namespace rpn
+
+using namespace rpn;
+
+struct rpn_model {
+    int backbone = 0, img_size = 0, K = 0, precision = 0, max_batch = 0;
+    int F = 0, feat_tensor = -1;
+    bool keep_all = false;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<Param> params;
+    size_t weight_floats = 0, arena_floats = 0;   // arena: per-image floats
+    float *d_weights = nullptr, *d_arena = nullptr;
+    const float *last_input = nullptr;
+    double flops = 0.0;
+};
+
+namespace rpn {
+
+static int add_tensor(rpn_model *m, const std::string &name, int H, int W, int C, bool external = false)
+{
+    Tensor t;
+    t.name = name; t.H = H; t.W = W; t.C = C; t.external = external;
+    m->tensors.push_back(t);
+    return (int)m->tensors.size() - 1;
+}
+
+static int add_param(rpn_model *m, int op, const std::string &name, const std::string &bn, int kind, int R, int S,
+                     int Cin, int Cout, int col_off = 0)
+{
+    Param p;
+    p.name = name; p.bn_name = bn; p.kind = kind; p.R = R; p.S = S; p.Cin = Cin; p.Cout = Cout; p.op = op;
+    p.col_off = col_off;
+    m->params.push_back(p);
+    m->ops[op].params.push_back((int)m->params.size() - 1);
+    return (int)m->params.size() - 1;
+}
+
+// dense conv op; returns the output tensor id
+static int add_conv(rpn_model *m, const std::string &name, const std::string &bn, int in, int Cout, int R,
+                    int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1)
+{
+    const Tensor ti = m->tensors[in];
+    Op op;
+    op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
+    op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
+    op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
+    op.ps = packed_shape(R, R, ti.C, Cout);
+    op.out = add_tensor(m, name, OH, OW, Cout);
+    m->ops.push_back(op);
+    const int oi = (int)m->ops.size() - 1;
+    add_param(m, oi, name, bn, bn.empty() ? 0 : 1, R, R, ti.C, Cout);
+    m->flops += 2.0 * OH * OW * Cout * R * R * ti.C;
+    return op.out;
+}
+
+static int add_dwconv(rpn_model *m, const std::string &name, const std::string &bn, int in, int stride, int pad_t,
+                      int pad_l, int OH, int OW, int act)
+{
+    const Tensor ti = m->tensors[in];
+    Op op;
+    op.kind = OP_DWCONV; op.name = name; op.in = in;
+    op.Cin = ti.C; op.Cout = ti.C; op.R = 3; op.S = 3; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
+    op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
+    op.out = add_tensor(m, name, OH, OW, ti.C);
+    m->ops.push_back(op);
+    const int oi = (int)m->ops.size() - 1;
+    add_param(m, oi, name, bn, 2, 3, 3, ti.C, ti.C);
+    m->flops += 2.0 * OH * OW * ti.C * 9;
+    return op.out;
+}
+
+static int add_pool(rpn_model *m, const std::string &name, int in)
+{
+    const Tensor ti = m->tensors[in];
+    Op op;
+    op.kind = OP_POOL; op.name = name; op.in = in;
+    op.Cin = op.Cout = ti.C; op.H = ti.H; op.W = ti.W; op.OH = ti.H / 2; op.OW = ti.W / 2;   // 'valid' floors
+    op.out = add_tensor(m, name, op.OH, op.OW, ti.C);
+    m->ops.push_back(op);
+    return op.out;
+}
+
+// rpn_conv + fused (rpn_reg | rpn_cls) 1x1 head (models/rpn_vgg16.py:18-21)
+static void add_head(rpn_model *m, int feat)
+{
+    const Tensor tf = m->tensors[feat];
+    const int x = add_conv(m, "rpn_conv", "", feat, 512, 3, 1, 1, 1, tf.H, tf.W, ACT_RELU);
+    Op op;
+    op.kind = OP_HEAD; op.name = "rpn_head"; op.in = x;
+    op.Cin = 512; op.Cout = 5 * m->K; op.R = op.S = 1; op.stride = 1;
+    op.H = op.OH = tf.H; op.W = op.OW = tf.W;
+    op.ps = packed_shape(1, 1, 512, 5 * m->K);
+    op.out = -1;
+    m->ops.push_back(op);
+    const int oi = (int)m->ops.size() - 1;
+    add_param(m, oi, "rpn_reg", "", 0, 1, 1, 512, 4 * m->K, 0);          // columns [0,4K): linear
+    add_param(m, oi, "rpn_cls", "", 0, 1, 1, 512, m->K, 4 * m->K);       // columns [4K,5K): sigmoid
+    m->flops += 2.0 * tf.H * tf.W * 5 * m->K * 512;
+}
+
+static void build_vgg16(rpn_model *m)
+{
+    int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
+    const int cfg[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
+    for (int blk = 0; blk < 5; ++blk) {
+        for (int c = 0; c < cfg[blk][0]; ++c) {
+            char name[64];
+            snprintf(name, sizeof name, "block%d_conv%d", blk + 1, c + 1);
+            const Tensor ti = m->tensors[t];
+            t = add_conv(m, name, "", t, cfg[blk][1], 3, 1, 1, 1, ti.H, ti.W, ACT_RELU);
+        }
+        if (blk < 4) {                       // block5_pool is never executed (tap = block5_conv3)
+            char name[64];
+            snprintf(name, sizeof name, "block%d_pool", blk + 1);
+            t = add_pool(m, name, t);
+        }
+    }
+    m->feat_tensor = t;
+    add_head(m, t);
+}
+
+// keras_applications.correct_pad for a 3x3 kernel: (before, after) per spatial dim
+static void correct_pad(int n, int *before, int *after)
+{
+    const int adjust = 1 - n % 2;
+    *before = 1 - adjust;
+    *after = 1;
+}
+
+static void build_mobilenet_v2(rpn_model *m)
+{
+    int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
+    {   // Conv1_pad + Conv1 (3x3 s2 valid, no bias) + bn_Conv1 + ReLU6
+        const Tensor ti = m->tensors[t];
+        int pb, pa;
+        correct_pad(ti.H, &pb, &pa);
+        const int OH = (ti.H + pb + pa - 3) / 2 + 1;
+        t = add_conv(m, "Conv1", "bn_Conv1", t, 32, 3, 2, pb, pb, OH, OH, ACT_RELU6);
+    }
+    const int blocks[13][4] = {{32, 1, 16, 1}, {16, 6, 24, 2}, {24, 6, 24, 1}, {24, 6, 32, 2}, {32, 6, 32, 1},
+                               {32, 6, 32, 1}, {32, 6, 64, 2}, {64, 6, 64, 1}, {64, 6, 64, 1}, {64, 6, 64, 1},
+                               {64, 6, 96, 1}, {96, 6, 96, 1}, {96, 6, 96, 1}};
+    for (int bid = 0; bid < 13; ++bid) {
+        const int cin = blocks[bid][0], expand = blocks[bid][1], cout = blocks[bid][2], stride = blocks[bid][3];
+        char pre[32];
+        if (bid == 0) snprintf(pre, sizeof pre, "expanded_conv_");
+        else snprintf(pre, sizeof pre, "block_%d_", bid);
+        const std::string prefix = pre;
+        const int inp = t;
+        if (bid != 0) {
+            const Tensor ti = m->tensors[t];
+            t = add_conv(m, prefix + "expand", prefix + "expand_BN", t, cin * expand, 1, 1, 0, 0, ti.H, ti.W,
+                         ACT_RELU6);
+        }
+        {
+            const Tensor ti = m->tensors[t];
+            if (stride == 2) {
+                int pb, pa;
+                correct_pad(ti.H, &pb, &pa);
+                const int OH = (ti.H + pb + pa - 3) / 2 + 1;
+                t = add_dwconv(m, prefix + "depthwise", prefix + "depthwise_BN", t, 2, pb, pb, OH, OH, ACT_RELU6);
+            } else {
+                t = add_dwconv(m, prefix + "depthwise", prefix + "depthwise_BN", t, 1, 1, 1, ti.H, ti.W, ACT_RELU6);
+            }
+        }
+        {
+            const Tensor ti = m->tensors[t];
+            const int res = (cin == cout && stride == 1) ? inp : -1;
+            t = add_conv(m, prefix + "project", prefix + "project_BN", t, cout, 1, 1, 0, 0, ti.H, ti.W, ACT_LINEAR,
+                         res);
+        }
+    }
+    {
+        const Tensor ti = m->tensors[t];
+        t = add_conv(m, "block_13_expand", "block_13_expand_BN", t, 576, 1, 1, 0, 0, ti.H, ti.W, ACT_RELU6);
+    }
+    m->feat_tensor = t;
+    add_head(m, t);
+}
+
+// liveness-based arena plan (first fit); offsets in floats per image
+static void plan_arena(rpn_model *m)
+{
+    for (auto &t : m->tensors) t.def = t.last_use = -1;
+    for (int i = 0; i < (int)m->ops.size(); ++i) {
+        const Op &op = m->ops[i];
+        if (op.out >= 0) m->tensors[op.out].def = i;
+        if (op.in >= 0) m->tensors[op.in].last_use = i;
+        if (op.residual >= 0) m->tensors[op.residual].last_use = i;
+    }
+    size_t top = 0;
+    std::vector<int> placed;
+    for (int ti = 0; ti < (int)m->tensors.size(); ++ti) {
+        Tensor &t = m->tensors[ti];
+        if (t.external || t.def < 0) continue;
+        if (t.last_use < t.def) t.last_use = t.def;
+        const size_t sz = (t.floats() + 63) & ~(size_t)63;          // 256-byte granules
+        size_t off = 0;
+        if (m->keep_all) {
+            off = top;
+        } else {
+            bool moved = true;
+            while (moved) {
+                moved = false;
+                for (int pj : placed) {
+                    const Tensor &o = m->tensors[pj];
+                    const bool live_overlap = !(o.last_use < t.def || t.last_use < o.def);
+                    const size_t osz = (o.floats() + 63) & ~(size_t)63;
+                    if (live_overlap && off < o.offset + osz && o.offset < off + sz) {
+                        off = o.offset + osz;
+                        moved = true;
+                    }
+                }
+            }
+        }
+        t.offset = off;
+        placed.push_back(ti);
+        if (off + sz > top) top = off + sz;
+    }
+    m->arena_floats = top;
+}
+
+static void plan_weights(rpn_model *m)
+{
+    size_t off = 0;
+    for (auto &op : m->ops) {
+        if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+            op.w_off = off;
+            off += (op.ps.floats() + 63) & ~(size_t)63;
+            op.b_off = off;
+            off += (size_t)op.ps.cout_pad;
+        } else if (op.kind == OP_DWCONV) {
+            op.w_off = off;
+            off += ((size_t)9 * op.Cin + 63) & ~(size_t)63;
+            op.b_off = off;
+            off += ((size_t)op.Cin + 63) & ~(size_t)63;
+        }
+    }
+    m->weight_floats = off;
+}
+
+static int ensure_device(rpn_model *m)
+{
+    if (!have_device()) return RPN_ERR_NO_DEVICE;
+    if (!m->d_weights) {
+        RPN_HIP_CHECK(hipMalloc(&m->d_weights, m->weight_floats * sizeof(float)));
+        RPN_HIP_CHECK(hipMemset(m->d_weights, 0, m->weight_floats * sizeof(float)));
+    }
+    if (!m->d_arena) {
+        RPN_HIP_CHECK(hipMalloc(&m->d_arena, m->arena_floats * (size_t)m->max_batch * sizeof(float)));
+    }
+    return RPN_OK;
+}
+
+static float *tensor_ptr(rpn_model *m, int id, const float *d_input)
+{
+    if (id == 0) return const_cast<float *>(d_input);
+    return m->d_arena + m->tensors[id].offset * (size_t)m->max_batch;
+}
+
+}  // namespace rpn
+
+extern "C" int rpn_model_create(int backbone, int img_size, int anchor_count, int precision, int max_batch,
+                                rpn_model **out)
+{
+    RPN_REQUIRE(out, "rpn_model_create: null out");
+    RPN_REQUIRE(backbone == RPN_BACKBONE_VGG16 || backbone == RPN_BACKBONE_MOBILENET_V2,
+                "rpn_model_create: unknown backbone %d", backbone);
+    RPN_REQUIRE(img_size >= 32 && img_size <= 8192, "rpn_model_create: img_size %d out of range", img_size);
+    RPN_REQUIRE(anchor_count >= 1 && anchor_count <= 64, "rpn_model_create: anchor_count %d out of range",
+                anchor_count);
+    RPN_REQUIRE(max_batch >= 1, "rpn_model_create: max_batch must be >= 1");
+    if (precision != RPN_PRECISION_F32)
+        return fail(RPN_ERR_UNSUPPORTED, "rpn_model_create: precision %d not implemented", precision);
+    rpn_model *m = new rpn_model();
+    m->backbone = backbone; m->img_size = img_size; m->K = anchor_count; m->precision = precision;
+    m->max_batch = max_batch;
+    if (backbone == RPN_BACKBONE_VGG16) build_vgg16(m);
+    else build_mobilenet_v2(m);
+    m->F = m->tensors[m->feat_tensor].H;
+    plan_arena(m);
+    plan_weights(m);
+    *out = m;
+    return RPN_OK;
+}
+
+extern "C" void rpn_model_destroy(rpn_model *m)
+{
+    if (!m) return;
+    if (m->d_weights) (void)hipFree(m->d_weights);
+    if (m->d_arena) (void)hipFree(m->d_arena);
+    delete m;
+}
+
+extern "C" int rpn_model_feature_map_shape(const rpn_model *m) { return m ? m->F : 0; }
+
+extern "C" int rpn_model_num_layers(const rpn_model *m) { return m ? (int)m->params.size() : 0; }
+
+extern "C" int rpn_model_layer_info(const rpn_model *m, int i, char *name, int name_len, int shape[4], int *kind)
+{
+    RPN_REQUIRE(m && i >= 0 && i < (int)m->params.size(), "rpn_model_layer_info: bad index %d", i);
+    const Param &p = m->params[i];
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", p.name.c_str());
+    if (shape) {
+        shape[0] = p.R; shape[1] = p.S; shape[2] = p.Cin; shape[3] = (p.kind == 2) ? 1 : p.Cout;
+    }
+    if (kind) *kind = p.kind;
+    return RPN_OK;
+}
+
+// name of the BatchNormalization layer that follows layer i ("" when there is none)
+extern "C" int rpn_model_layer_bn_name(const rpn_model *m, int i, char *name, int name_len)
+{
+    RPN_REQUIRE(m && i >= 0 && i < (int)m->params.size(), "rpn_model_layer_bn_name: bad index %d", i);
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", m->params[i].bn_name.c_str());
+    return RPN_OK;
+}
+
+extern "C" double rpn_model_flops_per_image(const rpn_model *m) { return m ? m->flops : 0.0; }
+
+// bytes of device memory the handle needs (weights, activation arena)
+extern "C" int rpn_model_memory_bytes(const rpn_model *m, size_t *weights, size_t *arena)
+{
+    RPN_REQUIRE(m, "rpn_model_memory_bytes: null model");
+    if (weights) *weights = m->weight_floats * sizeof(float);
+    if (arena) *arena = m->arena_floats * (size_t)m->max_batch * sizeof(float);
+    return RPN_OK;
+}
+
+// keep every intermediate activation alive (unique arena offsets) so that
+// rpn_model_get_activation can read any layer after a forward pass; must precede the first forward
+extern "C" int rpn_model_keep_activations(rpn_model *m, int keep)
+{
+    RPN_REQUIRE(m, "rpn_model_keep_activations: null model");
+    RPN_REQUIRE(!m->d_arena, "rpn_model_keep_activations: arena already allocated");
+    m->keep_all = keep != 0;
+    plan_arena(m);
+    return RPN_OK;
+}
+
+extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *kernel, const float *bias,
+                                   const float *bn_gamma, const float *bn_beta, const float *bn_mean,
+                                   const float *bn_var)
+{
+    RPN_REQUIRE(m && name && kernel, "rpn_model_set_layer: null argument");
+    int pi = -1;
+    for (int i = 0; i < (int)m->params.size(); ++i)
+        if (m->params[i].name == name) pi = i;
+    RPN_REQUIRE(pi >= 0, "rpn_model_set_layer: no layer named '%s'", name);
+    Param &p = m->params[pi];
+    Op &op = m->ops[p.op];
+    const bool has_bn = p.kind != 0;
+    RPN_REQUIRE(!has_bn || (bn_gamma && bn_beta && bn_mean && bn_var),
+                "rpn_model_set_layer: layer '%s' is followed by BatchNorm '%s'; its parameters are required", name,
+                p.bn_name.c_str());
+    RPN_REQUIRE(has_bn || !bn_gamma, "rpn_model_set_layer: layer '%s' has no BatchNorm", name);
+    const int st = ensure_device(m);
+    if (st != RPN_OK) return st;
+
+    // fold BatchNorm (inference mode, eps = 1e-3): y = conv(x) * scale + shift
+    std::vector<float> scale, shift(p.Cout, 0.0f);
+    if (has_bn) {
+        scale.resize(p.Cout);
+        for (int n = 0; n < p.Cout; ++n) {
+            scale[n] = bn_gamma[n] / sqrtf(bn_var[n] + kBnEps);
+            shift[n] = bn_beta[n] - bn_mean[n] * scale[n];
+        }
+    }
+    if (bias)
+        for (int n = 0; n < p.Cout; ++n) shift[n] += has_bn ? bias[n] * scale[n] : bias[n];
+
+    if (p.kind == 2) {
+        std::vector<float> w((size_t)9 * p.Cin);
+        for (int t = 0; t < 9; ++t)
+            for (int c = 0; c < p.Cin; ++c) w[(size_t)t * p.Cin + c] = kernel[(size_t)t * p.Cin + c] * scale[c];
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
+    } else if (op.kind == OP_HEAD) {
+        // this parameter fills columns [col_off, col_off + Cout) of the fused head matrix
+        const PackedShape &ps = op.ps;
+        RPN_HIP_CHECK(hipMemcpy2D(m->d_weights + op.w_off + p.col_off, (size_t)ps.cout_pad * sizeof(float), kernel,
+                                  (size_t)p.Cout * sizeof(float), (size_t)p.Cout * sizeof(float), (size_t)p.Cin,
+                                  hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> packed(op.ps.floats());
+        pack_weights_host(op.ps, kernel, has_bn ? scale.data() : nullptr, packed.data());
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(float),
+                                hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
+    }
+    p.loaded = true;
+    return RPN_OK;
+}
+
+extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float *d_reg, float *d_cls, void *stream)
+{
+    RPN_REQUIRE(m && d_imgs && d_reg && d_cls, "rpn_model_forward: null argument");
+    RPN_REQUIRE(B >= 1 && B <= m->max_batch, "rpn_model_forward: batch %d outside [1, %d]", B, m->max_batch);
+    for (const Param &p : m->params)
+        RPN_REQUIRE(p.loaded, "rpn_model_forward: weights of layer '%s' were never set", p.name.c_str());
+    const int st = ensure_device(m);
+    if (st != RPN_OK) return st;
+    hipStream_t s = as_stream(stream);
+    m->last_input = d_imgs;
+    for (const Op &op : m->ops) {
+        const float *x = tensor_ptr(m, op.in, d_imgs);
+        hipError_t e = hipSuccess;
+        if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+            ConvArgs a{};
+            a.x = x;
+            a.w = m->d_weights + op.w_off;
+            a.bias = m->d_weights + op.b_off;
+            a.residual = op.residual >= 0 ? tensor_ptr(m, op.residual, d_imgs) : nullptr;
+            a.B = B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.OH = op.OH; a.OW = op.OW; a.Cout = op.Cout;
+            a.R = op.R; a.S = op.S; a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+            a.ps = op.ps;
+            if (op.kind == OP_HEAD) {
+                a.out = d_reg; a.ld1 = 4 * m->K; a.act = ACT_LINEAR; a.split = 4 * m->K;
+                a.out2 = d_cls; a.ld2 = m->K; a.act2 = ACT_SIGMOID;
+            } else {
+                a.out = tensor_ptr(m, op.out, d_imgs); a.ld1 = op.Cout; a.act = op.act; a.split = op.Cout;
+                a.out2 = nullptr; a.ld2 = 0; a.act2 = ACT_LINEAR;
+            }
+            e = launch_conv_f32(a, s);
+        } else if (op.kind == OP_DWCONV) {
+            e = launch_dwconv3x3(x, B, op.H, op.W, op.Cin, m->d_weights + op.w_off, m->d_weights + op.b_off,
+                                 op.stride, op.pad_t, op.pad_l, op.OH, op.OW, op.act, tensor_ptr(m, op.out, d_imgs), s);
+        } else {
+            e = launch_maxpool2x2(x, B, op.H, op.W, op.Cin, tensor_ptr(m, op.out, d_imgs), s);
+        }
+        if (e != hipSuccess)
+            return fail(RPN_ERR_NO_DEVICE, "rpn_model_forward: layer '%s' failed to launch: %s", op.name.c_str(),
+                        hipGetErrorString(e));
+    }
+    return RPN_OK;
+}
+
+extern "C" int rpn_model_get_activation(rpn_model *m, const char *name, float *d_out, size_t out_bytes,
+                                        int shape[4], void *stream)
+{
+    RPN_REQUIRE(m && name, "rpn_model_get_activation: null argument");
+    int ti = -1;
+    for (int i = 1; i < (int)m->tensors.size(); ++i)
+        if (m->tensors[i].name == name) ti = i;
+    RPN_REQUIRE(ti >= 0, "rpn_model_get_activation: no activation named '%s'", name);
+    const Tensor &t = m->tensors[ti];
+    if (shape) {
+        shape[0] = m->max_batch; shape[1] = t.H; shape[2] = t.W; shape[3] = t.C;
+    }
+    if (!d_out) return RPN_OK;                                      // shape query only
+    RPN_REQUIRE(m->keep_all || ti == m->feat_tensor,
+                "rpn_model_get_activation: call rpn_model_keep_activations(m, 1) before the first forward");
+    RPN_REQUIRE(m->d_arena, "rpn_model_get_activation: no forward pass has run");
+    const size_t bytes = t.floats() * (size_t)m->max_batch * sizeof(float);
+    RPN_REQUIRE(out_bytes >= bytes, "rpn_model_get_activation: %zu bytes needed, %zu given", bytes, out_bytes);
+    RPN_HIP_CHECK(hipMemcpyAsync(d_out, m->d_arena + t.offset * (size_t)m->max_batch, bytes,
+                                 hipMemcpyDeviceToDevice, as_stream(stream)));
+    return RPN_OK;
+}
+
+// ---- single-layer entry points (kernel-level parity tests, micro-benchmarks) -----------------
+extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const float *d_w, const float *d_bias,
+                          int R, int S, int Cout, int stride, int pad_t, int pad_l, int OH, int OW, int act,
+                          int precision, float *d_out, void *stream)
+{
+    RPN_REQUIRE(d_x && d_w && d_out, "rpn_conv2d: null pointer");
+    RPN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1 && R >= 1 && S >= 1 && stride >= 1 &&
+                    OH >= 1 && OW >= 1 && pad_t >= 0 && pad_l >= 0,
+                "rpn_conv2d: bad geometry");
+    RPN_REQUIRE(act >= 0 && act <= 3, "rpn_conv2d: bad activation %d", act);
+    if (precision != RPN_PRECISION_F32)
+        return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: precision %d not implemented", precision);
+    RPN_REQUIRE_DEVICE();
+    hipStream_t s = as_stream(stream);
+    ConvArgs a{};
+    a.ps = packed_shape(R, S, Cin, Cout);
+    float *d_packed = nullptr;
+    RPN_HIP_CHECK(hipMalloc(&d_packed, a.ps.floats() * sizeof(float)));   // test entry point: allocates + syncs
+    pack_weights_device(a.ps, d_w, d_packed, s);
+    a.x = d_x; a.w = d_packed; a.bias = d_bias; a.residual = nullptr;
+    a.out = d_out; a.out2 = nullptr;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = R; a.S = S; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.act = act; a.act2 = ACT_LINEAR; a.split = Cout; a.ld1 = Cout; a.ld2 = 0;
+    const hipError_t e = launch_conv_f32(a, s);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(d_packed);
+    if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d: launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d: kernel failed: %s", hipGetErrorString(e2));
+    return RPN_OK;
+}
+
+extern "C" int rpn_maxpool2x2(const float *d_x, int B, int H, int W, int C, float *d_out, void *stream)
+{
+    RPN_REQUIRE(d_x && d_out, "rpn_maxpool2x2: null pointer");
+    RPN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0, "rpn_maxpool2x2: bad shape (C %% 4 must be 0)");
+    RPN_REQUIRE_DEVICE();
+    const hipError_t e = launch_maxpool2x2(d_x, B, H, W, C, d_out, as_stream(stream));
+    if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_maxpool2x2: launch failed: %s", hipGetErrorString(e));
+    return RPN_OK;
+}
+
+// depthwise 3x3 single-layer entry (w: (3,3,C) device, bias (C) device or NULL)
+extern "C" int rpn_dwconv3x3(const float *d_x, int B, int H, int W, int C, const float *d_w, const float *d_bias,
+                             int stride, int pad_t, int pad_l, int OH, int OW, int act, float *d_out, void *stream)
+{
+    RPN_REQUIRE(d_x && d_w && d_out, "rpn_dwconv3x3: null pointer");
+    RPN_REQUIRE(B >= 1 && C >= 4 && C % 4 == 0 && (stride == 1 || stride == 2), "rpn_dwconv3x3: bad shape");
+    RPN_REQUIRE_DEVICE();
+    const hipError_t e = launch_dwconv3x3(d_x, B, H, W, C, d_w, d_bias, stride, pad_t, pad_l, OH, OW, act, d_out,
+                                          as_stream(stream));
+    if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_dwconv3x3: launch failed: %s", hipGetErrorString(e));
+    return RPN_OK;
+}

@@ -1,0 +1,131 @@
+"""The proposal loop of the reference's ``predictor.py:41-60`` on MI355X.
+
+Per batch (predictor.py:50-56): ``rpn_model.predict_on_batch(imgs)`` -> reshape the head
+outputs to (B,A,4) / (B,A) -> ``deltas *= variances`` -> ``get_bboxes_from_deltas`` -> pick
+proposals.  The reference picks ``tf.nn.top_k(rpn_labels, 10)`` for display
+(predictor.py:58-60); the proposal path named by the north star substitutes
+``non_max_suppression`` with ``test_nms_topn = 300`` (utils/train_utils.py:29,
+utils/bbox_utils.py:48-70).  Both selectors are provided.
+
+Data parallelism (not in the reference, which is single-process): images are independent, so
+each rank takes a contiguous slice of the batch, runs the whole path locally, and one RCCL
+all-gather of fixed-size proposal records collects the result.  There is no
+other collective on the data path.
+"""
+import torch
+
+from . import _lib as L
+from .utils import bbox_utils, train_utils
+
+
+class Proposer(object):
+    """anchors once (predictor.py:46), then ``propose(imgs)`` per batch."""
+
+    def __init__(self, backbone="vgg16", hyper_params=None, weights="synthetic", precision="f32",
+                 max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1):
+        if backbone == "mobilenet_v2":
+            from .models.rpn_mobilenet_v2 import get_model
+        else:
+            from .models.rpn_vgg16 import get_model
+        self.backbone = backbone
+        self.hyper_params = hyper_params if hyper_params is not None else train_utils.get_hyper_params(backbone)
+        hp = self.hyper_params
+        self.rpn_model, self.feature_extractor = get_model(hp, weights=weights, precision=precision,
+                                                           max_batch=max_batch, seed=seed)
+        if self.rpn_model.feature_map_shape != int(hp["feature_map_shape"]):
+            raise ValueError("hyper_params feature_map_shape=%s but the %s graph at img_size=%s yields %d"
+                             % (hp["feature_map_shape"], backbone, hp["img_size"], self.rpn_model.feature_map_shape))
+        self.anchors = bbox_utils.generate_anchors(hp)                       # predictor.py:46
+        self.variances = [float(v) for v in hp["variances"]]
+        self.topn = int(hp["test_nms_topn"])
+        self.iou_threshold = float(iou_threshold)
+        self.score_threshold = float(score_threshold)
+        self.max_batch = int(max_batch)
+        F, K = self.rpn_model.feature_map_shape, self.rpn_model.anchor_count
+        self.total_anchors = F * F * K
+        dev = "cuda"
+        # preallocated outputs: a step performs no allocation and no host synchronisation
+        self._reg = torch.empty((max_batch, F, F, 4 * K), dtype=torch.float32, device=dev)
+        self._cls = torch.empty((max_batch, F, F, K), dtype=torch.float32, device=dev)
+        M = self.topn
+        self._boxes = torch.zeros((max_batch, M, 4), dtype=torch.float32, device=dev)
+        self._scores = torch.zeros((max_batch, M), dtype=torch.float32, device=dev)
+        self._idx = torch.full((max_batch, M), -1, dtype=torch.int32, device=dev)
+        self._valid = torch.zeros((max_batch,), dtype=torch.int32, device=dev)
+        _keep, self._vptr = L.host_floats(self.variances)
+        self._vkeep = _keep
+
+    # -- the hot path ---------------------------------------------------------------------
+    def forward(self, imgs):
+        """imgs: CUDA float32 (B,img,img,3).  Returns views (deltas (B,A,4), objectness (B,A))."""
+        B = int(imgs.shape[0])
+        reg, cls = self._reg[:B], self._cls[:B]
+        self.rpn_model.forward_into(imgs, reg, cls)                           # predictor.py:50
+        return reg.view(B, -1, 4), cls.view(B, -1)                             # predictor.py:52-53
+
+    def propose(self, imgs):
+        """imgs -> (boxes (B,300,4), scores (B,300), valid (B,) int32, indices (B,300) int32)."""
+        B = int(imgs.shape[0])
+        deltas, scores = self.forward(imgs)
+        ob, osc, oi, ov = self._boxes[:B], self._scores[:B], self._idx[:B], self._valid[:B]
+        st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(deltas), self._vptr, L.ptr(scores), B,
+                                    self.total_anchors, self.topn, self.iou_threshold, self.score_threshold, 1,
+                                    L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr())
+        L.check(st, "rpn_decode_nms")
+        return ob, osc, ov, oi
+
+    def propose_unfused(self, imgs):
+        """Same result through the reference's separate calls (decode, then NMS)."""
+        B = int(imgs.shape[0])
+        deltas, scores = self.forward(imgs)
+        deltas = deltas * torch.tensor(self.variances, device=deltas.device)             # predictor.py:55
+        boxes = bbox_utils.get_bboxes_from_deltas(self.anchors, deltas)                  # predictor.py:56
+        nb, ns, _, nv, ni = bbox_utils.non_max_suppression(
+            boxes.view(B, -1, 1, 4), scores.reshape(B, -1, 1), max_output_size_per_class=self.topn,
+            max_total_size=self.topn, iou_threshold=self.iou_threshold, score_threshold=self.score_threshold,
+            return_indices=True)
+        return nb, ns, nv, ni
+
+    def top_k(self, imgs, k=10):
+        """The reference's own selector: tf.nn.top_k + gather (predictor.py:58-60)."""
+        B = int(imgs.shape[0])
+        deltas, scores = self.forward(imgs)
+        boxes = bbox_utils.get_bboxes_from_deltas(self.anchors, deltas, variances=self.variances)
+        order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]    # ties -> lower index
+        return torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, k, 4)), order
+
+    # -- multi-GPU collection ---------------------------------------------------------------
+    def pack_records(self, boxes, scores, valid):
+        """(B,M,4),(B,M),(B,) -> one float32 record per image: M*5 floats + valid count."""
+        B, M = int(scores.shape[0]), int(scores.shape[1])
+        rec = torch.empty((B, M * 5 + 1), dtype=torch.float32, device=boxes.device)
+        rec[:, :M * 4] = boxes.reshape(B, M * 4)
+        rec[:, M * 4:M * 5] = scores
+        rec[:, M * 5] = valid.to(torch.float32)
+        return rec
+
+    @staticmethod
+    def unpack_records(rec, M):
+        B = int(rec.shape[0])
+        return (rec[:, :M * 4].reshape(B, M, 4), rec[:, M * 4:M * 5], rec[:, M * 5].to(torch.int32))
+
+    def propose_distributed(self, local_imgs, gather_out=None):
+        """Each rank proposes for its slice; one all-gather (RCCL over xGMI when the backend is
+        "nccl") returns every rank's records on every rank: (world*B_local, M*5+1)."""
+        import torch.distributed as dist
+        boxes, scores, valid, _ = self.propose(local_imgs)
+        rec = self.pack_records(boxes, scores, valid)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return rec
+        world = dist.get_world_size()
+        if gather_out is None:
+            gather_out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(gather_out, rec)
+        return gather_out
+
+
+def shard_bounds(total, world, rank):
+    """Contiguous image slice of rank `rank`: [lo, hi)."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
