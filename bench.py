@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- proposal images/sec of the RPN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (predictor.py:50-56 + NMS(300)) over one batch of synthetic
+500x500x3 images per GPU: conv backbone -> RPN head -> fused delta-decode + NMS -> (N > 1) one RCCL
+all-gather of the proposal records.  Inputs are resident in HBM before the timed region.
+At N = 1 the workload is BASELINE.json configs[1] (batch 8, VGG16 backbone + RPN head).
+Images shard over ranks (weak scaling: the per-GPU batch is fixed), no other data-path collective.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128x128 f32-MFMA implicit-GEMM
+conv), timed live with HIP events recorded on the launch stream around every launch of the timed steps;
+`cpu_baseline` is the CPU oracle (torch-CPU conv stack + plain-C decode/NMS restatement: a "port", the
+TF2 reference cannot run here) timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0}    # MI355X_MICROARCH.md: f32 MFMA; dense bf16 MFMA / 3 products
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backbone", default="vgg16", choices=["vgg16", "mobilenet_v2"])
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--iou-threshold", type=float, default=0.7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(backbone, hyper_params, weights, iou_threshold, target_seconds):
+    """CPU oracle ("port") on this box's host cores: whole path for one image at a time."""
+    import numpy as np
+    import torch
+
+    from oracle import bbox_oracle as bo
+    from oracle import c_oracle as co
+    from oracle import conv_oracle as cv
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.RandomState(0)
+    anchors = bo.generate_anchors(hyper_params)
+    var = np.float32(hyper_params["variances"])
+    size = hyper_params["img_size"]
+
+    def one_image():
+        img = rng.uniform(0, 1, size=(1, size, size, 3)).astype(np.float32)
+        reg, cls = cv.rpn_forward(backbone, img, weights)
+        boxes = co.decode(anchors, reg.reshape(1, -1, 4), var)
+        co.combined_nms(boxes[:, :, None, :], cls.reshape(1, -1, 1), 300, 300, iou_threshold=iou_threshold)
+
+    one_image()                                    # warm-up (oneDNN primitive caches)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one_image()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or n >= 64:
+            break
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images of the same workload, one at a time (torch-CPU f32 conv stack with %d threads + "
+                      "plain-C decode/NMS(300), single thread), %.1f s" % (n, cores, dt),
+            "cpu": model_name}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from tf_rpn_amd import _lib
+    from tf_rpn_amd.models._rpn_model import synthetic_weights
+    from tf_rpn_amd.predictor import Proposer
+    from tf_rpn_amd.utils import train_utils
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+
+    hp = dict(train_utils.get_hyper_params(args.backbone))
+    weights = synthetic_weights(args.backbone, hp, seed=1)
+    prop = Proposer(args.backbone, hyper_params=hp, weights=weights, precision=args.precision,
+                    max_batch=args.batch, iou_threshold=args.iou_threshold)
+    B = args.batch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(rank)
+    imgs = torch.rand((B, hp["img_size"], hp["img_size"], 3), generator=gen, device="cuda", dtype=torch.float32)
+    M = prop.topn
+    gathered = torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def step():
+        return prop.propose_distributed(imgs, gather_out=gathered)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
+    model = prop.rpn_model
+    model.set_profiling(args.steps)               # HIP events on the launch stream around every launch of the K steps
+    ops = model.ops()
+    op_ms = [0.0] * len(ops)
+    nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        deltas, scores = prop.forward(imgs)
+        nms_ev[k][0].record()                     # same stream as the launches (torch's current stream)
+        prop_out = prop._boxes[:B], prop._scores[:B], prop._idx[:B], prop._valid[:B]
+        st = _lib.lib().rpn_decode_nms(_lib.ptr(prop.anchors), _lib.ptr(deltas), prop._vptr, _lib.ptr(scores), B,
+                                       prop.total_anchors, M, prop.iou_threshold, prop.score_threshold, 1,
+                                       _lib.ptr(prop_out[0]), _lib.ptr(prop_out[1]), _lib.ptr(prop_out[2]),
+                                       _lib.ptr(prop_out[3]), _lib.vp(0), 0, _lib.stream_ptr())
+        _lib.check(st, "rpn_decode_nms")
+        nms_ev[k][1].record()
+        if world > 1:
+            rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3])
+            dist.all_gather_into_tensor(gathered, rec)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # mean per-op durations over the K timed steps (events were recorded on the launch stream, read here)
+    last_ms, _kept = model.profile_ms()
+    model.set_profiling(0)
+    nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / args.steps
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    if rank == 0:
+        # dominant kernel: the conv instantiation with the largest total time
+        by_kernel = {}
+        for op, ms in zip(ops, last_ms):
+            d = by_kernel.setdefault(op["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
+            d["ms"] += ms
+            d["flops"] += op["flops_per_image"] * B
+            d["launches"] += 1
+        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+        d = by_kernel[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        traffic = None
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "flops_per_launch": d["flops"] / d["launches"],
+                    "conv_stack_ms": round(sum(last_ms), 3), "decode_nms_ms": round(nms_ms, 4)}
+        out = {
+            "metric": "proposal images/sec at 500x500x3 VOC batch; NMS boxes/sec",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[1]: 500x500x3 synthetic batch=%d per GPU, %s backbone + RPN head, "
+                                   "decode + NMS(300), %dxMI355X" % (B, args.backbone, world),
+                       "per_gpu_batch": B, "global_batch": world * B, "img_size": hp["img_size"],
+                       "anchors_per_image": prop.total_anchors, "nms_topn": M, "iou_threshold": args.iou_threshold,
+                       "weights": "random-init (seeded He-normal)",
+                       "parallelism": "image-sharded dp%d, one RCCL all-gather of proposals" % world},
+            "nms_boxes_per_sec": round(B * prop.total_anchors / (nms_ms * 1e-3), 1),
+            "roofline": roofline,
+        }
+        if args.layers:
+            for op, ms in zip(ops, last_ms):
+                tf = op["flops_per_image"] * B / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                gbs = op["bytes_per_image"] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                print("%-28s %-34s %8.3f ms %8.2f TF/s %9.1f GB/s" % (op["name"], op["kernel"], ms, tf, gbs),
+                      file=sys.stderr)
+            print("%-28s %-34s %8.3f ms" % ("decode+nms", "nms_kernel<decode>", nms_ms), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, args.iou_threshold, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,15 @@ int rpn_model_get_activation(rpn_model *m, const char *name, float *d_out, size_
                              void *stream);
 /* algorithmic FLOPs (2*MACs) of one image through the conv stack */
 double rpn_model_flops_per_image(const rpn_model *m);
+/* per-op timing with HIP events recorded on the caller's stream around every launch of a forward:
+ * keep the events of the last n_forwards forwards (0 = off), run forwards, then read the mean elapsed
+ * milliseconds of each op over the kept forwards.
+ * rpn_model_op_info names op i, the kernel that runs it and its algorithmic FLOPs / HBM bytes per image. */
+int rpn_model_set_profiling(rpn_model *m, int n_forwards);
+int rpn_model_num_ops(const rpn_model *m);
+int rpn_model_op_info(const rpn_model *m, int i, char *name, int name_len, char *kernel, int kernel_len,
+                      double *flops_per_image, double *bytes_per_image);
+int rpn_model_get_profile(rpn_model *m, float *ms, int n, int *n_forwards);
 
 /* ------------------------------------------------------------------------------------
  * single conv layer, for kernel-level parity tests and micro-benchmarks.

@@ -1,0 +1,260 @@
+"""GPU parity, box math: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact for anchors, IoU map and every NMS integer output (indices,
+valid counts); <= 1e-4 absolute on float32 boxes / scores (the north star's tolerance), with the
+much tighter bound actually observed asserted where the arithmetic is identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+from tf_rpn_amd.utils import bbox_utils
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4                       # north-star tolerance for float32 coordinates / scores
+VAR = np.float32([0.1, 0.1, 0.2, 0.2])
+
+
+def _np(t):
+    return t.cpu().numpy() if isinstance(t, torch.Tensor) else t
+
+
+# ---- anchors: bit-exact -------------------------------------------------------------------
+@pytest.mark.parametrize("backbone,kw", [
+    ("vgg16", {}), ("mobilenet_v2", {}),
+    ("vgg16", dict(feature_map_shape=4)),
+    ("mobilenet_v2", dict(img_size=1024, feature_map_shape=64, anchor_ratios=[1., 2., .5, 3., 1 / 3.])),   # C5
+    ("vgg16", dict(img_size=333, feature_map_shape=7, anchor_scales=[37, 290], anchor_ratios=[0.7, 1.9, 3.3])),
+])
+def test_anchors_bit_exact(backbone, kw):
+    hp = bo.get_hyper_params(backbone, **kw)
+    got = bbox_utils.generate_anchors(hp, as_numpy=True)
+    assert np.array_equal(got, bo.generate_anchors(hp))
+
+
+def test_anchor_golden_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "anchors.npz"))
+    assert np.array_equal(bbox_utils.generate_anchors(bo.get_hyper_params("vgg16"), as_numpy=True), g["anchors_vgg16"])
+    hp_c5 = bo.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                anchor_ratios=[1., 2., .5, 3., 1 / 3.])
+    a5 = bbox_utils.generate_anchors(hp_c5, as_numpy=True)
+    assert np.array_equal(a5[:600], g["anchors_c5_head"])
+    assert a5.astype(np.float64).sum() == g["anchors_c5_sum"][0] and len(a5) == g["anchors_c5_sum"][1]
+
+
+# ---- decode / encode ------------------------------------------------------------------------
+@pytest.mark.parametrize("B,backbone", [(1, "vgg16"), (8, "vgg16"), (64, "mobilenet_v2")])
+def test_decode_matches_oracle(B, backbone):
+    anchors = bo.generate_anchors(bo.get_hyper_params(backbone))
+    deltas = np.random.RandomState(2).standard_normal((B, len(anchors), 4)).astype(np.float32)
+    ref = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))
+    got = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)          # fused x variances
+    assert np.abs(got - ref).max() <= 2e-6 < TOL
+    got2 = bbox_utils.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))  # the reference's two steps
+    assert np.array_equal(got, got2)
+    batched = np.broadcast_to(anchors, (B,) + anchors.shape).copy()                 # (B,A,4) anchors
+    assert np.array_equal(bbox_utils.get_bboxes_from_deltas(batched, deltas, variances=VAR), got)
+
+
+def test_decode_golden_and_edge_shapes(golden_dir):
+    g = np.load(os.path.join(golden_dir, "boxmath.npz"))
+    got = bbox_utils.get_bboxes_from_deltas(g["anchors"], g["deltas"], variances=g["variances"])
+    assert np.abs(got - g["boxes"]).max() <= 2e-6
+    empty = bbox_utils.get_bboxes_from_deltas(g["anchors"], np.zeros((0, len(g["anchors"]), 4), np.float32))
+    assert empty.shape == (0, len(g["anchors"]), 4)
+    with pytest.raises(ValueError):
+        bbox_utils.get_bboxes_from_deltas(g["anchors"][:-1], g["deltas"])
+    # unbounded exp (no clamp in the reference, bbox_utils.py:86-87): inf/NaN must match the oracle's
+    big = np.float32([[[0, 0, 100, -100], [0, 0, np.inf, 1]]])
+    an = g["anchors"][:2]
+    with np.errstate(all="ignore"):
+        ref = bo.get_bboxes_from_deltas(an, big)
+    got = bbox_utils.get_bboxes_from_deltas(an, big)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref)) and np.array_equal(np.isnan(got), np.isnan(ref))
+
+
+def test_encode_matches_oracle_and_round_trips(golden_dir):
+    g = np.load(os.path.join(golden_dir, "boxmath.npz"))
+    got = bbox_utils.get_deltas_from_bboxes(g["anchors"], g["gt_per_anchor"])
+    assert np.abs(got - g["encoded"]).max() <= 2e-6
+    assert (got[0, 5] == 0).all()                                  # zero-size gt row -> zero deltas (:119-122)
+    back = bbox_utils.get_bboxes_from_deltas(g["anchors"], got)
+    keep = np.ones(got.shape[:2], bool)
+    keep[0, 5] = False
+    assert np.abs(back - g["gt_per_anchor"])[keep].max() <= 4e-6
+
+
+# ---- IoU map: bit-exact ---------------------------------------------------------------------
+@pytest.mark.parametrize("B,G,backbone", [(1, 1, "vgg16"), (3, 7, "vgg16"), (64, 42, "vgg16"), (8, 42, "mobilenet_v2")])
+def test_iou_map_bit_exact(B, G, backbone):
+    anchors = bo.generate_anchors(bo.get_hyper_params(backbone))
+    gt = cases.gt_boxes(np.random.RandomState(4), B, G=G, n_valid=min(10, G))
+    got = bbox_utils.generate_iou_map(anchors, gt)
+    assert got.shape == (B, len(anchors), G)
+    assert np.array_equal(got, co.iou_map(anchors, gt))
+
+
+def test_iou_map_golden_batched_and_invariants(golden_dir):
+    g = np.load(os.path.join(golden_dir, "boxmath.npz"))
+    assert np.array_equal(bbox_utils.generate_iou_map(g["anchors"], g["gt"]), g["iou_map"])
+    b = cases.random_boxes(np.random.RandomState(6), (2, 50))
+    iou = bbox_utils.generate_iou_map(b, b)                        # batched bboxes (B,A,4)
+    assert np.array_equal(iou, bo.generate_iou_map(b, b))
+    assert (np.diagonal(iou, axis1=1, axis2=2) == 1).all() and np.array_equal(iou, iou.transpose(0, 2, 1))
+    assert bbox_utils.generate_iou_map(b[0], np.zeros((2, 0, 4), np.float32)).shape == (2, 50, 0)
+
+
+# ---- NMS: integer outputs bit-exact -------------------------------------------------------------
+def _check_nms(boxes, scores, **kw):
+    ref = co.combined_nms(boxes, scores, **kw)
+    got = bbox_utils.non_max_suppression(boxes, scores, return_indices=True, **kw)
+    names = ("boxes", "scores", "classes", "valid", "idx")
+    for n, r, x in zip(names, ref, got):
+        assert r.shape == x.shape, n
+    assert np.array_equal(got[3], ref[3]), "valid_detections differ: %s vs %s" % (got[3], ref[3])
+    assert np.array_equal(got[4], ref[4]), "selected indices differ"
+    assert np.array_equal(got[2], ref[2])
+    assert np.array_equal(got[0], ref[0], equal_nan=True) and np.array_equal(got[1], ref[1], equal_nan=True)
+    return got
+
+
+def test_nms_golden_edge_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nms.npz"))
+    boxes, scores = g["edge_boxes"][None, :, None, :], g["edge_scores"][None, :, None]
+    for name, kw in {
+        "edge_default": dict(max_output_size_per_class=20, max_total_size=20),
+        "edge_thr07_noclip": dict(max_output_size_per_class=64, max_total_size=64, iou_threshold=0.7, clip_boxes=False),
+        "edge_score_thr": dict(max_output_size_per_class=64, max_total_size=10, score_threshold=0.5),
+    }.items():
+        got = _check_nms(boxes, scores, **kw)
+        for key, arr in zip(("boxes", "scores", "classes", "valid", "idx"), got):
+            assert np.array_equal(arr, g["%s_%s" % (name, key)], equal_nan=True), (name, key)
+
+
+def test_nms_golden_multiclass(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nms.npz"))
+    got = _check_nms(g["mc_boxes"][:, :, None, :], g["mc_scores"], max_output_size_per_class=5, max_total_size=12)
+    assert np.array_equal(got[4], g["mc_q1_idx"]) and np.array_equal(got[2], g["mc_q1_classes"])
+    got = _check_nms(g["mc_boxes_q"], g["mc_scores"], max_output_size_per_class=6, max_total_size=40,
+                     pad_per_class=True, iou_threshold=0.3)
+    assert got[0].shape == (2, 18, 4) and np.array_equal(got[4], g["mc_qc_idx"])
+
+
+@pytest.mark.parametrize("iou_thr", [0.5, 0.7])
+@pytest.mark.parametrize("backbone,B", [("vgg16", 8), ("mobilenet_v2", 4)])
+def test_nms_full_size_decoded_anchors(backbone, B, iou_thr):
+    """C3-shaped input: decoded anchors (N(0,1) deltas x variances), tie-free permutation scores, top 300."""
+    anchors = bo.generate_anchors(bo.get_hyper_params(backbone))
+    A = len(anchors)
+    deltas = np.random.RandomState(2).standard_normal((B, A, 4)).astype(np.float32)
+    boxes = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))
+    scores = cases.permutation_scores(np.random.RandomState(3), B, A)
+    got = _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                     iou_threshold=iou_thr)
+    assert (got[3] == 300).all()
+
+
+def test_nms_ties_and_duplicates_on_raw_anchors():
+    """Clipped anchors contain 744 exact duplicate rows; with constant / coarse scores every tie rule fires."""
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
+    A = len(anchors)
+    rng = np.random.RandomState(9)
+    scores = np.stack([np.full(A, 0.5, np.float32), (rng.randint(0, 8, size=A) / 8).astype(np.float32)])
+    boxes = np.stack([anchors, anchors])
+    for thr in (0.3, 0.7, 1.0):
+        _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                   iou_threshold=thr)
+
+
+def test_nms_heavy_suppression_walks_many_chunks():
+    """Tight clusters: far more than 256 candidates are visited to collect the outputs."""
+    rng = np.random.RandomState(12)
+    boxes = cases.clustered_boxes(rng, 3, 6000, n_clusters=40, jitter=0.004)
+    scores = cases.permutation_scores(rng, 3, 6000)
+    got = _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                     iou_threshold=0.5)
+    assert (got[3] < 300).all() and (got[3] >= 40).all()
+
+
+def test_nms_thresholds_sizes_and_limits():
+    rng = np.random.RandomState(13)
+    boxes = cases.clustered_boxes(rng, 2, 1000, n_clusters=30)
+    scores = rng.uniform(-1, 1, size=(2, 1000)).astype(np.float32)
+    b4, s3 = boxes[:, :, None, :], scores[:, :, None]
+    _check_nms(b4, s3, max_output_size_per_class=50, max_total_size=80, score_threshold=0.25)
+    _check_nms(b4, s3, max_output_size_per_class=100, max_total_size=30, iou_threshold=0.6)
+    _check_nms(b4, s3, max_output_size_per_class=1000, max_total_size=1000, iou_threshold=0.9)    # more slots than survivors
+    _check_nms(b4, s3, max_output_size_per_class=40, max_total_size=40, score_threshold=2.0)       # nothing qualifies
+    _check_nms(b4, s3, max_output_size_per_class=7, max_total_size=7, iou_threshold=0.0)
+    _check_nms(b4, s3, max_output_size_per_class=7, max_total_size=7, iou_threshold=-1.0)          # IoU 0 > thr: only the top box
+    _check_nms(b4, s3, max_output_size_per_class=0, max_total_size=5)
+    # N = 1, N = 2 and the largest N the single-workgroup sort takes
+    _check_nms(b4[:, :1], s3[:, :1], max_output_size_per_class=3, max_total_size=3)
+    _check_nms(b4[:, :2], s3[:, :2], max_output_size_per_class=3, max_total_size=3)
+    big = cases.clustered_boxes(rng, 1, 16384, n_clusters=200)
+    _check_nms(big[:, :, None, :], cases.permutation_scores(rng, 1, 16384)[:, :, None],
+               max_output_size_per_class=300, max_total_size=300)
+
+
+def test_nms_empty_inputs():
+    z = lambda *s: np.zeros(s, np.float32)
+    out = bbox_utils.non_max_suppression(z(0, 10, 1, 4), z(0, 10, 1), max_output_size_per_class=5, max_total_size=5)
+    assert out[0].shape == (0, 5, 4) and out[3].shape == (0,)
+    out = bbox_utils.non_max_suppression(z(2, 0, 1, 4), z(2, 0, 1), max_output_size_per_class=5, max_total_size=5)
+    assert out[0].shape == (2, 5, 4) and (out[3] == 0).all() and (out[0] == 0).all()
+    out = bbox_utils.non_max_suppression(z(2, 9, 1, 4), z(2, 9, 1), max_output_size_per_class=5, max_total_size=0)
+    assert out[0].shape == (2, 0, 4)
+    with pytest.raises(TypeError):
+        bbox_utils.non_max_suppression(z(1, 4, 1, 4), z(1, 4, 1), max_total_size=3)
+    with pytest.raises(ValueError):
+        bbox_utils.non_max_suppression(z(1, 4, 2, 4), z(1, 4, 3), max_output_size_per_class=1, max_total_size=1)
+
+
+def test_nms_multiclass_random():
+    rng = np.random.RandomState(14)
+    boxes = cases.clustered_boxes(rng, 3, 700, n_clusters=25)
+    scores = rng.uniform(0, 1, size=(3, 700, 21)).astype(np.float32)          # VOC: 21 labels
+    _check_nms(boxes[:, :, None, :], scores, max_output_size_per_class=30, max_total_size=100, score_threshold=0.3)
+    per_class = np.repeat(boxes[:, :, None, :], 21, axis=2) + rng.normal(0, 0.01, size=(3, 700, 21, 4)).astype(np.float32)
+    _check_nms(per_class.astype(np.float32), scores, max_output_size_per_class=10, max_total_size=500, pad_per_class=True)
+
+
+def test_nms_selection_properties_at_full_size():
+    """Size-independent properties at C3 scale (B=64): sorted scores, pairwise IoU <= thr among the kept
+    boxes, idempotence (NMS of its own output keeps everything)."""
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
+    B, A = 64, len(anchors)
+    deltas = torch.randn((B, A, 4), generator=torch.Generator().manual_seed(2)).numpy()
+    boxes = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)
+    scores = cases.permutation_scores(np.random.RandomState(3), B, A)
+    nb, ns, _nc, nv, ni = bbox_utils.non_max_suppression(boxes[:, :, None, :], scores[:, :, None], return_indices=True,
+                                                         max_output_size_per_class=300, max_total_size=300,
+                                                         iou_threshold=0.7, clip_boxes=False)
+    assert (nv == 300).all() and (np.diff(ns, axis=1) <= 0).all()
+    assert np.array_equal(np.take_along_axis(scores, ni.astype(np.int64), axis=1), ns)
+    for b in (0, 17, 63):
+        kept = nb[b]
+        iou = np.array([[bo.nms_iou(kept[i], kept[j]) for j in range(0, 300, 7)] for i in range(0, 300, 7)])
+        np.fill_diagonal(iou, 0)
+        assert iou.max() <= np.float32(0.7)
+    again = bbox_utils.non_max_suppression(nb[:, :, None, :], ns[:, :, None], max_output_size_per_class=300,
+                                           max_total_size=300, iou_threshold=0.7, clip_boxes=False)
+    assert np.array_equal(again[0], nb) and (again[3] == 300).all()
+
+
+# ---- fused decode + NMS ---------------------------------------------------------------------------
+@pytest.mark.parametrize("backbone,B", [("vgg16", 8), ("mobilenet_v2", 3)])
+def test_decode_nms_fused_equals_two_step(backbone, B):
+    anchors = bo.generate_anchors(bo.get_hyper_params(backbone))
+    A = len(anchors)
+    deltas = np.random.RandomState(21).standard_normal((B, A, 4)).astype(np.float32)
+    scores = cases.permutation_scores(np.random.RandomState(22), B, A)
+    fb, fs, fi, fv = bbox_utils.decode_and_nms(anchors, deltas, scores, VAR, 300, iou_threshold=0.7)
+    gpu_boxes = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)
+    # bit-exact against the oracle fed the SAME decoded boxes (decode itself is checked above to 2e-6)
+    rb, rs, _rc, rv, ri = co.combined_nms(gpu_boxes[:, :, None, :], scores[:, :, None], 300, 300, iou_threshold=0.7)
+    assert np.array_equal(fv, rv) and np.array_equal(fi, ri)
+    assert np.array_equal(fb, rb) and np.array_equal(fs, rs)

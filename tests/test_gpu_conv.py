@@ -1,0 +1,174 @@
+"""GPU parity, conv stack: HIP kernels (through the C ABI) against torch-CPU conv (oracle/conv_oracle.py)
+on seeded inputs.  Floating point: tolerance 1e-4 absolute on head outputs (north star); single layers are
+held to a relative bound derived from the f32 MFMA's ordered-fmaf numerics."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+from oracle import conv_oracle as cv
+from tf_rpn_amd import _lib as L
+from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_gpu(x, w, b, stride, pad_t, pad_l, OH, OW, act, precision="f32"):
+    xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    bd = torch.from_numpy(b).cuda() if b is not None else None
+    B, H, W, Cin = x.shape
+    R, S, _, Cout = w.shape
+    out = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    st = L.lib().rpn_conv2d(L.ptr(xd), B, H, W, Cin, L.ptr(wd), L.ptr(bd), R, S, Cout, stride, pad_t, pad_l, OH, OW,
+                            L.ACTS[act], L.PRECISIONS[precision], L.ptr(out), L.stream_ptr())
+    L.check(st, "rpn_conv2d")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, R, stride, (pt, pb, pl, pr), act
+    (1, 16, 16, 16, 32, 3, 1, (1, 1, 1, 1), "relu"),          # one exact tile
+    (2, 20, 37, 64, 128, 3, 1, (1, 1, 1, 1), "relu"),         # ragged tiles, 128-wide N tile
+    (1, 31, 31, 512, 512, 3, 1, (1, 1, 1, 1), "relu"),        # block5 / rpn_conv shape
+    (2, 19, 23, 3, 64, 3, 1, (1, 1, 1, 1), "relu"),           # block1_conv1: Cin = 3 (generic gather)
+    (1, 40, 40, 3, 32, 3, 2, (0, 1, 0, 1), "relu6"),          # MobileNetV2 stem, even size: pad (0,1)
+    (1, 41, 41, 3, 32, 3, 2, (1, 1, 1, 1), "relu6"),          # odd size: pad (1,1)
+    (2, 31, 31, 512, 45, 1, 1, (0, 0, 0, 0), "sigmoid"),      # head-sized 1x1, Cout = 45
+    (1, 33, 17, 24, 144, 1, 1, (0, 0, 0, 0), "relu6"),        # MNv2 expand: Cin = 24 (partial K slice)
+    (1, 33, 17, 144, 24, 1, 1, (0, 0, 0, 0), "linear"),       # MNv2 project: Cout = 24
+    (3, 9, 9, 96, 576, 1, 1, (0, 0, 0, 0), "relu6"),
+    (1, 8, 16, 20, 36, 3, 1, (1, 1, 1, 1), "linear"),         # Cin % 16 != 0 with 9 taps
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_conv2d_single_layer(case):
+    B, H, W, Cin, Cout, R, stride, pad, act = case
+    rng = np.random.RandomState(hash(case[:7]) % (2 ** 31))
+    x = rng.uniform(-1, 1, size=(B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((R, R, Cin, Cout)) * np.sqrt(2.0 / (R * R * Cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(Cout,)).astype(np.float32)
+    ref = cv.conv2d_nhwc(x, w, b, stride=stride, pad=pad, act=act, dtype=torch.float64)
+    OH, OW = ref.shape[1:3]
+    got = _conv_gpu(x, w, b, stride, pad[0], pad[2], OH, OW, act)
+    assert not np.isnan(got).any(), "some outputs were never written"
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).max()
+    assert err <= 2e-5 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
+    if R * R * Cin <= 600:                     # cross-check the independent plain-C direct conv on small cases
+        cref = co.conv2d(x, w, b, stride=stride, pad_t=pad[0], pad_l=pad[2], out_hw=(OH, OW), act=act)
+        assert np.abs(got - cref).max() <= 2e-5 * scale
+
+
+def test_conv2d_no_bias_matches():
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-1, 1, size=(1, 12, 12, 32)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 32, 16)).astype(np.float32) * 0.1
+    ref = cv.conv2d_nhwc(x, w, None, pad=(1, 1, 1, 1), dtype=torch.float64)
+    assert np.abs(_conv_gpu(x, w, None, 1, 1, 1, 12, 12, "linear") - ref).max() <= 2e-5
+
+
+def test_maxpool_and_depthwise():
+    rng = np.random.RandomState(6)
+    x = rng.uniform(-1, 1, size=(2, 125, 37, 64)).astype(np.float32)            # odd sizes: 'valid' floors
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((2, 62, 18, 64), device="cuda")
+    L.check(L.lib().rpn_maxpool2x2(L.ptr(xd), 2, 125, 37, 64, L.ptr(out), L.stream_ptr()), "rpn_maxpool2x2")
+    assert np.array_equal(out.cpu().numpy(), co.maxpool2x2(x))
+    for (H, stride, pad) in ((21, 1, (1, 1, 1, 1)), (20, 2, (0, 1, 0, 1)), (21, 2, (1, 1, 1, 1))):
+        x = rng.uniform(-1, 1, size=(2, H, H, 96)).astype(np.float32)
+        w = rng.standard_normal((3, 3, 96, 1)).astype(np.float32)
+        b = rng.uniform(-1, 1, size=(96,)).astype(np.float32)
+        ref = cv.conv2d_nhwc(x, w, b, stride=stride, pad=pad, act="relu6", depthwise=True, dtype=torch.float64)
+        OH = ref.shape[1]
+        xd, wd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(w.reshape(3, 3, 96)).cuda(), torch.from_numpy(b).cuda()
+        out = torch.empty((2, OH, OH, 96), device="cuda")
+        L.check(L.lib().rpn_dwconv3x3(L.ptr(xd), 2, H, H, 96, L.ptr(wd), L.ptr(bd), stride, pad[0], pad[2], OH, OH,
+                                      L.ACTS["relu6"], L.ptr(out), L.stream_ptr()), "rpn_dwconv3x3")
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
+
+
+# ---- whole models ---------------------------------------------------------------------------------
+def _model_case(backbone, img, B, seed=1, fm=None):
+    hp = bo.get_hyper_params(backbone, img_size=img, feature_map_shape=fm)
+    weights = synthetic_weights(backbone, hp, seed=seed)
+    model = RPNModel(backbone, hp, max_batch=B, keep_activations=True)
+    model.set_weights(weights)
+    imgs = np.random.RandomState(0).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+    return hp, weights, model, imgs
+
+
+@pytest.mark.parametrize("backbone,img,B", [("vgg16", 64, 2), ("vgg16", 150, 1), ("mobilenet_v2", 64, 2),
+                                             ("mobilenet_v2", 150, 3), ("mobilenet_v2", 125, 1)])
+def test_model_forward_small(backbone, img, B):
+    hp, weights, model, imgs = _model_case(backbone, img, B)
+    reg, cls = model.predict_on_batch(imgs)
+    ref64 = cv.rpn_forward(backbone, imgs, weights, dtype=torch.float64, return_features=True)
+    ref32 = cv.rpn_forward(backbone, imgs, weights, dtype=torch.float32)
+    F = model.feature_map_shape
+    assert reg.shape == (B, F, F, 36) and cls.shape == (B, F, F, 9) and ref64[0].shape == reg.shape
+    feat = model.get_activation(model.tap_layer, batch=B).cpu().numpy()
+    fscale = max(1.0, float(np.abs(ref64[2]).max()))
+    assert np.abs(feat - ref64[2]).max() <= 5e-5 * fscale
+    assert np.abs(reg - ref64[0]).max() <= 1e-4 and np.abs(cls - ref64[1]).max() <= 1e-4
+    # no further from the float64 reference than torch's own float32 path is (x4 slack)
+    assert np.abs(reg - ref64[0]).max() <= 4 * np.abs(ref32[0] - ref64[0]).max() + 1e-6
+
+
+def test_model_layerwise_vgg16():
+    """Every intermediate activation against the float64 oracle (catches an O(1)-wrong layer that a
+    whole-model tolerance could hide)."""
+    hp, weights, model, imgs = _model_case("vgg16", 96, 1)
+    model.predict_on_batch(imgs)
+    x = torch.from_numpy(imgs).to(torch.float64).permute(0, 3, 1, 2)
+    import torch.nn.functional as Fnn
+    for layer in cv.VGG16_LAYERS:
+        if layer == "pool":
+            x = Fnn.max_pool2d(x, 2, 2)
+            continue
+        name = layer[0]
+        x = torch.relu(cv._conv(x, weights[name]["kernel"], weights[name]["bias"], padding=1, dtype=torch.float64))
+        got = model.get_activation(name, batch=1).cpu().numpy()
+        ref = x.permute(0, 2, 3, 1).numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= 3e-5 * scale, name
+
+
+@pytest.mark.parametrize("backbone", ["vgg16", "mobilenet_v2"])
+def test_model_forward_full_size_one_image(backbone):
+    """The reference's own input size (500x500), one image, against torch-CPU float32."""
+    hp, weights, model, imgs = _model_case(backbone, 500, 1)
+    reg, cls = model.predict_on_batch(imgs)
+    ref = cv.rpn_forward(backbone, imgs, weights, dtype=torch.float32)
+    assert reg.shape == ref[0].shape == (1, hp["feature_map_shape"], hp["feature_map_shape"], 36)
+    assert np.abs(reg - ref[0]).max() <= 1e-4, np.abs(reg - ref[0]).max()
+    assert np.abs(cls - ref[1]).max() <= 1e-4, np.abs(cls - ref[1]).max()
+    assert 0.0 < cls.min() and cls.max() < 1.0
+
+
+def test_model_batch_invariance_full_size():
+    """BASELINE config C2 (B=8, VGG16, 500x500): image i alone gives bit-identical outputs to image i in
+    the batch (no cross-image term anywhere on the path)."""
+    hp = bo.get_hyper_params("vgg16")
+    model = RPNModel("vgg16", hp, max_batch=8)
+    model.set_weights(synthetic_weights("vgg16", hp, seed=1))
+    imgs = torch.rand((8, 500, 500, 3), generator=torch.Generator().manual_seed(0)).cuda()
+    reg, cls = model.predict_on_batch(imgs)
+    reg, cls = reg.clone(), cls.clone()
+    for i in (0, 5):
+        r1, c1 = model.predict_on_batch(imgs[i:i + 1].contiguous())
+        assert torch.equal(r1[0], reg[i]) and torch.equal(c1[0], cls[i])
+    assert torch.isfinite(reg).all() and torch.isfinite(cls).all()
+
+
+def test_forward_requires_all_weights():
+    hp = bo.get_hyper_params("vgg16", img_size=64, feature_map_shape=4)
+    model = RPNModel("vgg16", hp, max_batch=1)
+    with pytest.raises(ValueError, match="never set"):
+        model.predict_on_batch(np.zeros((1, 64, 64, 3), np.float32))
+    with pytest.raises(ValueError):
+        model.predict_on_batch(np.zeros((1, 32, 64, 3), np.float32))

@@ -1,0 +1,60 @@
+"""GPU parity, the whole hot path (predictor.py:46-60 with NMS(300)): images -> proposals."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+from oracle import conv_oracle as cv
+from tf_rpn_amd.models._rpn_model import synthetic_weights
+from tf_rpn_amd.predictor import Proposer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("backbone,img,fm", [("vgg16", 160, 10), ("mobilenet_v2", 160, 10)])
+def test_propose_against_oracle_pipeline(backbone, img, fm):
+    hp = bo.get_hyper_params(backbone, img_size=img, feature_map_shape=fm)
+    weights = synthetic_weights(backbone, hp, seed=3)
+    prop = Proposer(backbone, hyper_params=dict(hp), weights=weights, max_batch=2, iou_threshold=0.7)
+    imgs = np.random.RandomState(1).uniform(0, 1, size=(2, img, img, 3)).astype(np.float32)
+    x = torch.from_numpy(imgs).cuda()
+    boxes, scores, valid, idx = [t.cpu().numpy() for t in prop.propose(x)]
+    deltas, obj = [t.cpu().numpy() for t in prop.forward(x)]
+    # conv stack vs oracle: 1e-4 on deltas and objectness
+    reg_ref, cls_ref = cv.rpn_forward(backbone, imgs, weights)
+    assert np.abs(deltas.reshape(reg_ref.shape) - reg_ref).max() <= 1e-4
+    assert np.abs(obj.reshape(cls_ref.shape) - cls_ref).max() <= 1e-4
+    # box stage vs oracle fed the GPU head outputs: integer outputs bit-exact, floats <= 1e-4
+    anchors = bo.generate_anchors(hp)
+    assert np.array_equal(prop.anchors.cpu().numpy(), anchors)
+    dec = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, hp["variances"]))
+    rb, rs, _rc, rv, ri = co.combined_nms(dec[:, :, None, :], obj[:, :, None], 300, 300, iou_threshold=0.7)
+    assert np.array_equal(valid, rv) and np.array_equal(idx, ri)
+    assert np.abs(boxes - rb).max() <= 1e-4 and np.array_equal(scores, rs)
+    # the unfused route (reference's separate calls) agrees with the fused kernel
+    ub, us, uv, ui = [t.cpu().numpy() for t in prop.propose_unfused(x)]
+    assert np.array_equal(uv, valid) and np.array_equal(ui, idx) and np.array_equal(ub, boxes)
+    # the reference's own selector: top-10 by objectness (predictor.py:58-60)
+    tb, order = prop.top_k(x, 10)
+    assert np.array_equal(order.cpu().numpy(), bo.top_k_indices(obj, 10))
+
+
+def test_propose_full_size_properties():
+    """C2 (B=8, VGG16, 500x500): output contract and size-independent properties."""
+    prop = Proposer("vgg16", max_batch=8, iou_threshold=0.7)
+    imgs = torch.rand((8, 500, 500, 3), generator=torch.Generator().manual_seed(0)).cuda()
+    boxes, scores, valid, idx = [t.clone() for t in prop.propose(imgs)]
+    assert boxes.shape == (8, 300, 4) and scores.shape == (8, 300) and valid.dtype == torch.int32
+    assert (valid > 0).all() and (valid <= 300).all()
+    assert boxes.min() >= 0 and boxes.max() <= 1                      # clip_boxes
+    for b in range(8):
+        v = int(valid[b])
+        s = scores[b, :v]
+        assert (s[:-1] >= s[1:]).all() and (scores[b, v:] == 0).all() and (idx[b, v:] == -1).all()
+        assert len(set(idx[b, :v].tolist())) == v
+    again = [t.clone() for t in prop.propose(imgs)]                    # deterministic
+    assert torch.equal(again[0], boxes) and torch.equal(again[3], idx)
+    rec = prop.pack_records(boxes, scores, valid)
+    b2, s2, v2 = prop.unpack_records(rec, 300)
+    assert torch.equal(b2, boxes) and torch.equal(v2, valid)

@@ -52,6 +52,11 @@ _SIGNATURES = {
     "rpn_model_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
     "rpn_model_get_activation": (ctypes.c_int, [vp, ctypes.c_char_p, vp, ctypes.c_size_t, c_int_p, vp]),
     "rpn_model_flops_per_image": (ctypes.c_double, [vp]),
+    "rpn_model_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
+    "rpn_model_num_ops": (ctypes.c_int, [vp]),
+    "rpn_model_op_info": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "rpn_model_get_profile": (ctypes.c_int, [vp, c_float_p, ctypes.c_int, c_int_p]),
     "rpn_conv2d": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "rpn_maxpool2x2": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "rpn_dwconv3x3": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp] + [ctypes.c_int] * 6 + [vp, vp]),

@@ -68,6 +68,10 @@ struct rpn_model {
     float *d_weights = nullptr, *d_arena = nullptr;
     const float *last_input = nullptr;
     double flops = 0.0;
+    // optional per-op timing: one hipEvent before the first op and one after every op
+    int profiling = 0;                 // number of forwards whose events are kept (ring)
+    std::vector<hipEvent_t> events;    // profiling x (ops + 1)
+    long long profiled_forwards = 0;
 };
 
 namespace rpn {
@@ -345,6 +349,7 @@ extern "C" void rpn_model_destroy(rpn_model *m)
     if (!m) return;
     if (m->d_weights) (void)hipFree(m->d_weights);
     if (m->d_arena) (void)hipFree(m->d_arena);
+    for (auto &ev : m->events) (void)hipEventDestroy(ev);
     delete m;
 }
 
@@ -462,6 +467,20 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     if (st != RPN_OK) return st;
     hipStream_t s = as_stream(stream);
     m->last_input = d_imgs;
+    hipEvent_t *evs = nullptr;
+    if (m->profiling > 0) {
+        const size_t per = m->ops.size() + 1;
+        if (m->events.size() != per * (size_t)m->profiling) {
+            for (auto &ev : m->events) (void)hipEventDestroy(ev);
+            m->events.assign(per * (size_t)m->profiling, nullptr);
+            for (auto &ev : m->events) RPN_HIP_CHECK(hipEventCreate(&ev));
+            m->profiled_forwards = 0;
+        }
+        evs = m->events.data() + per * (size_t)(m->profiled_forwards % m->profiling);
+        RPN_HIP_CHECK(hipEventRecord(evs[0], s));
+        ++m->profiled_forwards;
+    }
+    int op_index = 0;
     for (const Op &op : m->ops) {
         const float *x = tensor_ptr(m, op.in, d_imgs);
         hipError_t e = hipSuccess;
@@ -491,7 +510,73 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
         if (e != hipSuccess)
             return fail(RPN_ERR_NO_DEVICE, "rpn_model_forward: layer '%s' failed to launch: %s", op.name.c_str(),
                         hipGetErrorString(e));
+        ++op_index;
+        if (evs) RPN_HIP_CHECK(hipEventRecord(evs[op_index], s));
     }
+    return RPN_OK;
+}
+
+// ---- per-op timing with HIP events on the caller's stream ------------------------------------
+extern "C" int rpn_model_set_profiling(rpn_model *m, int n_forwards)
+{
+    RPN_REQUIRE(m && n_forwards >= 0 && n_forwards <= 4096, "rpn_model_set_profiling: bad argument");
+    m->profiling = n_forwards;
+    m->profiled_forwards = 0;
+    return RPN_OK;
+}
+
+extern "C" int rpn_model_num_ops(const rpn_model *m) { return m ? (int)m->ops.size() : 0; }
+
+// name, kernel family ("conv128x128", "conv128x64", "conv128x32", "conv_generic*", "dwconv", "maxpool") and
+// algorithmic FLOPs (2*MACs, whole batch of the last profiled forward... per image here) of op i
+extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name_len, char *kernel, int kernel_len,
+                                 double *flops_per_image, double *bytes_per_image)
+{
+    RPN_REQUIRE(m && i >= 0 && i < (int)m->ops.size(), "rpn_model_op_info: bad index %d", i);
+    const Op &op = m->ops[i];
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", op.name.c_str());
+    double fl = 0.0, by = 0.0;
+    const char *k = "maxpool2x2";
+    const double in_b = 4.0 * op.H * op.W * op.Cin, out_b = 4.0 * op.OH * op.OW * op.Cout;
+    if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+        fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
+        by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
+        if (op.ps.generic) k = op.Cout > 64 ? "conv_igemm_f32<128x128,generic>" : (op.Cout > 32 ? "conv_igemm_f32<128x64,generic>" : "conv_igemm_f32<128x32,generic>");
+        else k = op.Cout > 64 ? "conv_igemm_f32<128x128>" : (op.Cout > 32 ? "conv_igemm_f32<128x64>" : "conv_igemm_f32<128x32>");
+    } else if (op.kind == OP_DWCONV) {
+        fl = 2.0 * op.OH * op.OW * op.Cin * 9;
+        by = in_b + out_b;
+        k = "dwconv3x3";
+    } else {
+        by = in_b + out_b;
+    }
+    if (kernel && kernel_len > 0) snprintf(kernel, (size_t)kernel_len, "%s", k);
+    if (flops_per_image) *flops_per_image = fl;
+    if (bytes_per_image) *bytes_per_image = by;
+    return RPN_OK;
+}
+
+// mean elapsed milliseconds of every op over the kept forwards (synchronises on their last events);
+// returns the number of forwards averaged in *n_forwards (may be NULL)
+extern "C" int rpn_model_get_profile(rpn_model *m, float *ms, int n, int *n_forwards)
+{
+    RPN_REQUIRE(m && ms, "rpn_model_get_profile: null argument");
+    RPN_REQUIRE(m->profiling > 0 && m->profiled_forwards > 0 && !m->events.empty(),
+                "rpn_model_get_profile: profiling is off or no forward has run");
+    RPN_REQUIRE(n >= (int)m->ops.size(), "rpn_model_get_profile: need room for %d ops", (int)m->ops.size());
+    const size_t per = m->ops.size() + 1;
+    const int kept = (int)(m->profiled_forwards < m->profiling ? m->profiled_forwards : m->profiling);
+    for (size_t i = 0; i < m->ops.size(); ++i) ms[i] = 0.0f;
+    for (int f = 0; f < kept; ++f) {
+        hipEvent_t *evs = m->events.data() + per * (size_t)f;
+        RPN_HIP_CHECK(hipEventSynchronize(evs[per - 1]));
+        for (size_t i = 0; i < m->ops.size(); ++i) {
+            float t = 0.0f;
+            RPN_HIP_CHECK(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            ms[i] += t / (float)kept;
+        }
+    }
+    if (n_forwards) *n_forwards = kept;
     return RPN_OK;
 }
 

@@ -133,6 +133,32 @@ class RPNModel(object):
         st = L.lib().rpn_model_forward(self._h, L.ptr(x), int(x.shape[0]), L.ptr(reg), L.ptr(cls), L.stream_ptr())
         L.check(st, "rpn_model_forward")
 
+    # ---- per-op timing (HIP events on the launch stream) ---------------------------------------
+    def set_profiling(self, n_forwards=1):
+        """Keep HIP-event timings of the last ``n_forwards`` forwards (0 switches profiling off)."""
+        L.check(L.lib().rpn_model_set_profiling(self._h, int(n_forwards)), "rpn_model_set_profiling")
+
+    def ops(self):
+        """[{name, kernel, flops_per_image, bytes_per_image}] in launch order."""
+        lib = L.lib()
+        out = []
+        nb, kb = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+        fl, by = ctypes.c_double(0), ctypes.c_double(0)
+        for i in range(lib.rpn_model_num_ops(self._h)):
+            L.check(lib.rpn_model_op_info(self._h, i, nb, 128, kb, 128, ctypes.byref(fl), ctypes.byref(by)),
+                    "rpn_model_op_info")
+            out.append({"name": nb.value.decode(), "kernel": kb.value.decode(), "flops_per_image": fl.value,
+                        "bytes_per_image": by.value})
+        return out
+
+    def profile_ms(self):
+        """Mean milliseconds per op over the kept forwards -> (list, n_forwards)."""
+        n = L.lib().rpn_model_num_ops(self._h)
+        buf = (ctypes.c_float * n)()
+        kept = ctypes.c_int(0)
+        L.check(L.lib().rpn_model_get_profile(self._h, buf, n, ctypes.byref(kept)), "rpn_model_get_profile")
+        return [float(v) for v in buf], int(kept.value)
+
     def activation_shape(self, name):
         shape = (ctypes.c_int * 4)()
         L.check(L.lib().rpn_model_get_activation(self._h, name.encode(), None, 0, shape, None),
