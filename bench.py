@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0}    # MI355X_MICROARCH.md: f32 MFMA; dense bf16 MFMA / 3 products
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "f16x3": 2500.0 / 3.0}   # MI355X_MICROARCH.md: f32 MFMA; dense 16-bit MFMA / 3 products
 
 
 def parse_args():
@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--backbone", default="vgg16", choices=["vgg16", "mobilenet_v2"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "f16x3"])
     ap.add_argument("--iou-threshold", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")

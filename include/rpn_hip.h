@@ -41,10 +41,12 @@ typedef enum rpn_status {
 typedef enum rpn_backbone { RPN_BACKBONE_VGG16 = 0, RPN_BACKBONE_MOBILENET_V2 = 1 } rpn_backbone;
 
 /* arithmetic of the conv stack.  F32: exact float32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit
- * an ordered fmaf chain.  BF16X3: every f32 operand is split into hi+lo bfloat16 and each
- * product is formed as hi*hi + hi*lo + lo*hi on the bf16 MFMA with float32 accumulation
- * (~2^-16 relative error per product; measured against the 1e-4 parity bound in tests). */
-typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1 } rpn_precision;
+ * an ordered fmaf chain.  BF16X3 / F16X3: in the 3x3 stride-1 layers every float32 operand is carried
+ * as hi + lo 16-bit halves (bfloat16 / float16) and each product is formed as
+ * hi*hi + hi*lo + lo*hi on the 16-bit MFMA with float32 accumulation (product error ~2^-16 / ~2^-21
+ * relative; measured against the 1e-4 parity bound in tests/, never assumed).  F16X3 requires
+ * |activation| < 65504.  All other layers stay on the float32 kernels. */
+typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1, RPN_PRECISION_F16X3 = 2 } rpn_precision;
 
 int rpn_abi_version(void);
 const char *rpn_last_error(void);

@@ -172,3 +172,89 @@ def test_forward_requires_all_weights():
         model.predict_on_batch(np.zeros((1, 64, 64, 3), np.float32))
     with pytest.raises(ValueError):
         model.predict_on_batch(np.zeros((1, 32, 64, 3), np.float32))
+
+
+# ---- x3-split 16-bit MFMA path (bf16x3 / f16x3) -------------------------------------------------------
+SPLIT_CASES = [
+    # B, H, W, Cin, Cout, act
+    (1, 8, 32, 16, 64, "relu"),            # one exact 8x32 tile, one K slice, 64-wide N tile
+    (2, 21, 45, 64, 64, "relu"),           # ragged tiles (block1_conv2 shape class)
+    (1, 37, 70, 64, 128, "relu"),          # 128-wide N tile
+    (2, 31, 31, 512, 512, "relu"),         # block5 / rpn_conv: short tiles (TH = 4)
+    (8, 62, 62, 256, 512, "relu"),         # block4_conv1: tall tiles, 512 blocks
+    (1, 13, 9, 32, 48, "linear"),          # Cout = 48 (cout_pad 64), signed outputs
+    (1, 40, 33, 128, 256, "relu6"),
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv3x3_split_single_layer(case, precision):
+    B, H, W, Cin, Cout, act = case
+    rng = np.random.RandomState(abs(hash(case[:5])) % (2 ** 31))
+    x = rng.uniform(-1, 1, size=(B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(Cout,)).astype(np.float32)
+    ref = cv.conv2d_nhwc(x, w, b, pad=(1, 1, 1, 1), act=act, dtype=torch.float64)
+    got = _conv_gpu(x, w, b, 1, 1, 1, H, W, act, precision=precision)
+    assert not np.isnan(got).any(), "some outputs were never written"
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).max()
+    bound = 1e-4 if precision == "bf16x3" else 1e-5          # observed: ~1e-5 / ~1e-6 (product error 2^-16 / 2^-21)
+    assert err <= bound * scale, "%s max abs err %.3e (scale %.2f)" % (precision, err, scale)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("backbone,img,B", [("vgg16", 96, 2), ("vgg16", 150, 1), ("mobilenet_v2", 96, 2)])
+def test_model_forward_split_small(backbone, img, B, precision):
+    hp = bo.get_hyper_params(backbone, img_size=img, feature_map_shape=None)
+    weights = synthetic_weights(backbone, hp, seed=1)
+    model = RPNModel(backbone, hp, precision=precision, max_batch=B, keep_activations=True)
+    model.set_weights(weights)
+    imgs = np.random.RandomState(0).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+    reg, cls = model.predict_on_batch(imgs)
+    ref = cv.rpn_forward(backbone, imgs, weights, dtype=torch.float64, return_features=True)
+    feat = model.get_activation(model.tap_layer, batch=B).cpu().numpy()
+    fscale = max(1.0, float(np.abs(ref[2]).max()))
+    assert np.abs(feat - ref[2]).max() <= 2e-4 * fscale
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4      # the north star's bound
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_model_forward_split_full_size(precision):
+    """VGG16 at the reference's 500x500: head outputs within 1e-4 of torch-CPU float32 AND of the exact-f32
+    HIP path; the measured errors are printed (-s) and recorded in DESIGN.md."""
+    hp = bo.get_hyper_params("vgg16")
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    imgs = np.random.RandomState(0).uniform(0, 1, size=(1, 500, 500, 3)).astype(np.float32)
+    outs = {}
+    for prec in ("f32", precision):
+        model = RPNModel("vgg16", hp, precision=prec, max_batch=1)
+        model.set_weights(weights)
+        outs[prec] = model.predict_on_batch(imgs)
+        del model
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    for name, i in (("reg", 0), ("cls", 1)):
+        e_split = np.abs(outs[precision][i] - ref[i]).max()
+        e_f32 = np.abs(outs["f32"][i] - ref[i]).max()
+        print("%s %s: max|err| vs float64 oracle: split %.3e, exact-f32 kernel %.3e" % (precision, name, e_split, e_f32))
+        assert e_split <= 1e-4
+        assert np.abs(outs[precision][i] - outs["f32"][i]).max() <= 1e-4
+
+
+def test_split_round_trip_and_pool():
+    """SPLIT16 carries hi + lo: float32 -> split -> float32 is within 2^-16 (bf16) / 2^-21 (f16) relative,
+    and pooling in split form equals pooling the joined values."""
+    hp = bo.get_hyper_params("vgg16", img_size=64)
+    weights = synthetic_weights("vgg16", hp, seed=2)
+    imgs = np.random.RandomState(3).uniform(0, 1, size=(1, 64, 64, 3)).astype(np.float32)
+    for precision, rel in (("bf16x3", 2.0 ** -15), ("f16x3", 2.0 ** -20)):
+        model = RPNModel("vgg16", hp, precision=precision, max_batch=1, keep_activations=True)
+        model.set_weights(weights)
+        model.predict_on_batch(imgs)
+        a = model.get_activation("block1_conv1", batch=1).cpu().numpy()              # float32 producer
+        s = model.get_activation("block1_conv1/split", batch=1).cpu().numpy()        # its SPLIT16 copy, joined
+        assert np.abs(s - a).max() <= rel * max(1.0, np.abs(a).max())
+        c2 = model.get_activation("block1_conv2", batch=1).cpu().numpy()
+        p = model.get_activation("block1_pool", batch=1).cpu().numpy()
+        assert np.array_equal(p, co.maxpool2x2(c2))

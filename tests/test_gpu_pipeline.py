@@ -58,3 +58,24 @@ def test_propose_full_size_properties():
     rec = prop.pack_records(boxes, scores, valid)
     b2, s2, v2 = prop.unpack_records(rec, 300)
     assert torch.equal(b2, boxes) and torch.equal(v2, valid)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_propose_split_precision_full_size(precision):
+    """C2 with the split-precision conv stack: proposals stay within the parity bound of the exact-f32 path.
+    Integer outputs are compared through the oracle fed the SAME head outputs (bit-exact), floats <= 1e-4."""
+    hp = dict(bo.get_hyper_params("vgg16"))
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    imgs = torch.rand((2, 500, 500, 3), generator=torch.Generator().manual_seed(0)).cuda()
+    p32 = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f32", max_batch=2)
+    d32, s32 = [t.clone() for t in p32.forward(imgs)]
+    del p32
+    prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision=precision, max_batch=2)
+    boxes, scores, valid, idx = [t.cpu().numpy() for t in prop.propose(imgs)]
+    deltas, obj = prop.forward(imgs)
+    assert (deltas - d32).abs().max().item() <= 1e-4 and (obj - s32).abs().max().item() <= 1e-4
+    anchors = bo.generate_anchors(hp)
+    dec = co.decode(anchors, deltas.cpu().numpy(), np.float32(hp["variances"]))
+    rb, rs, _rc, rv, ri = co.combined_nms(dec[:, :, None, :], obj.cpu().numpy()[:, :, None], 300, 300, iou_threshold=0.7)
+    assert np.array_equal(valid, rv) and np.array_equal(idx, ri)
+    assert np.abs(boxes - rb).max() <= 1e-4 and np.array_equal(scores, rs)

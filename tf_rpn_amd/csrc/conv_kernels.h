@@ -53,4 +53,20 @@ hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const fl
                             int stride, int pad_t, int pad_l, int OH, int OW, int act, float *out,
                             hipStream_t stream);
 
+// ---- x3-split 16-bit MFMA path (conv_split_kernels.hip) ----------------------------------------
+// SPLIT16 activation layout: [B][H][W][C/16][64 B] = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} (bf16 or f16).
+// Split weights: [9][Cin/16][cout_pad][64 B], cout_pad = round_up(Cout, 64).
+inline int split_cout_pad(int Cout) { return (Cout + 63) / 64 * 64; }
+inline size_t split_weight_bytes(int Cin, int Cout) { return (size_t)9 * (Cin / 16) * split_cout_pad(Cout) * 64; }
+// power-of-two pre-scale of the weights (f16 only; 0 for bf16) so that their lo halves stay normal
+int split_weight_shift(const float *hwio, size_t count, bool f16);
+void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
+                             int shift, unsigned short *dst);
+hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, void *out, hipStream_t s);
+hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, float *out, hipStream_t s);
+hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);
+hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
+                                hipStream_t s);
+
 }  // namespace rpn

@@ -1,0 +1,533 @@
+// conv_split_kernels.hip -- 3x3 / stride-1 / 'same' convolution on the 16-bit matrix cores with
+// float32-grade accuracy ("x3 split"), for gfx950 (MI355X).
+//
+// Why: the exact-f32 MFMA tops out at 157 TFLOP/s, i.e. ~1000 images/s for VGG16+RPN at 500x500
+// (SURVEY.md H1); the 16-bit MFMA is 16x faster.  Every float32 operand x is carried as two
+// 16-bit halves hi = rn16(x), lo = rn16(x - hi), and each product is formed as
+//        a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (3 MFMAs, float32 accumulation)
+// dropping only a_lo*b_lo.  With bfloat16 halves the product error is ~2^-16 relative, with
+// float16 halves ~2^-21 (weights are pre-scaled by a power of two so their low halves stay
+// normal); the error is measured against a CPU float64 reference in tests/, never assumed.
+//
+// Layouts ("SPLIT16"): activations [B][H][W][C/16][64 B], one 64-byte record per pixel and
+// 16-channel slice = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} as four 16-byte pieces; weights
+// [tap][C/16][cout_pad][64 B] with the same record per output channel.  A 16-byte piece is
+// exactly one lane's A (or B) fragment of v_mfma_f32_32x32x16_{bf16,f16}.
+//
+// Kernel: implicit GEMM, M = TH x 32 output pixels of one image, N = 64 or 128 output
+// channels, K walked as (16-channel slice) x (9 taps).  Per slice the (TH+2) x 34 input halo is
+// staged in LDS ONCE and re-read by all 9 taps at shifted addresses (the im2col matrix never
+// exists); per tap only the BN x 64 B weight tile is streamed.  Both are double-buffered through
+// registers (global loads for step s+1 are issued before the MFMAs of step s), one barrier per
+// tap.  LDS records are XOR-swizzled by (row >> 2) & 3 so that every ds_read_b128 fragment
+// read is bank-conflict free.  Epilogue: bias + activation, then the tile is transposed
+// through LDS so each lane stores whole 16-byte pieces (256 contiguous bytes per pixel).
+//
+// Roofline: MFMA-bound; 3 MFMAs per algorithmic product, so the algorithmic peak is
+// (dense 16-bit MFMA peak, 2.5 PFLOP/s) / 3.
+#include "conv_kernels.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace rpn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kSplitThreads = 256;
+constexpr int TWS = 32;                 // tile width in pixels = one MFMA M-block
+constexpr int HW = TWS + 2;             // halo width
+constexpr int kStagePad = 4;            // floats of padding per staged row (keeps 16-byte alignment)
+
+template <bool F16> struct Half;
+template <> struct Half<false> {
+    using vec = bf16x8;
+    using elem = __bf16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                       0, 0, 0);
+    }
+};
+template <> struct Half<true> {
+    using vec = f16x8;
+    using elem = _Float16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    }
+};
+
+// 8 floats -> one 16-byte piece: the hi halves, or the lo halves (x - hi)
+template <bool F16>
+__device__ __forceinline__ uint4 split_piece(const float (&x)[8], bool lo)
+{
+    using E = typename Half<F16>::elem;
+    typename Half<F16>::vec v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const E h = (E)x[k];
+        v[k] = lo ? (E)(x[k] - (float)h) : h;
+    }
+    return __builtin_bit_cast(uint4, v);
+}
+
+template <bool F16>
+__device__ __forceinline__ float join(unsigned short hi, unsigned short lo)
+{
+    using E = typename Half<F16>::elem;
+    return (float)__builtin_bit_cast(E, hi) + (float)__builtin_bit_cast(E, lo);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    switch (act) {
+        case ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_RELU6: return v < 0.0f ? 0.0f : (v > 6.0f ? 6.0f : v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int xcd_remap_s(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+struct SplitConvArgs {
+    const uint4 *x;       // SPLIT16 input  [B][H][W][Cin/16][4]
+    const uint4 *w;       // split weights  [9][Cin/16][cout_pad][4]
+    const float *bias;    // (Cout) float32, may be null
+    void *out;            // SPLIT16 [B][H][W][Cout/16][4]  or float32 NHWC [B][H][W][Cout]
+    int B, H, W, Cin, Cout, cout_pad;
+    float out_scale;      // 2^-s when the weights were pre-scaled by 2^s
+    int act, out_f32;
+};
+
+// TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64)
+template <int TH, int WN, bool F16>
+__global__ void __launch_bounds__(kSplitThreads, 2)
+conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int WM = 4 / WN;               // waves along M
+    constexpr int MI = TH / WM;              // 32-pixel rows per wave
+    constexpr int NI = 2;                    // 32-channel blocks per wave
+    constexpr int BN = WN * NI * 32;
+    constexpr int HP = (TH + 2) * HW;        // halo pixels
+    constexpr int A_PIECES = HP * 4;
+    constexpr int A_ROUNDS = (A_PIECES + kSplitThreads - 1) / kSplitThreads;
+    constexpr int B_PIECES = BN * 4;
+    constexpr int B_ROUNDS = B_PIECES / kSplitThreads;
+    static_assert(MI * WM == TH && B_PIECES % kSplitThreads == 0 && A_ROUNDS <= 9, "tile shape");
+    constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
+    constexpr int LDS_PIPE = 2 * HP * 4 + 2 * BN * 4;                // uint4 units
+    constexpr int LDS_STAGE = (4 * 32 * STAGE_LD * 4 + 15) / 16;     // uint4 units (4 waves x 32 rows)
+    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
+
+    __shared__ uint4 lds[LDS_UINT4];
+    uint4 *As = lds;                          // [2][HP][4]
+    uint4 *Bs = lds + 2 * HP * 4;             // [2][BN][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lm = lane & 31, kh = lane >> 5;
+
+    const int wg = xcd_remap_s(blockIdx.x, gridDim.x);
+    const int nt = wg % n_tiles;
+    int mt = wg / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
+
+    const int chunks = a.Cin >> 4;
+    const int steps = chunks * 9;
+    const size_t in_pix_stride = (size_t)chunks * 4;                     // uint4 per input pixel
+    const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
+
+    // ---- global -> register staging ---------------------------------------------------------
+    uint4 b_reg[B_ROUNDS];
+    uint4 a_reg;
+    auto load_b = [&](int step) {          // weight tile of (tap, chunk): rows n0 .. n0+BN, 64 B each
+        const int chunk = step / 9, tap = step - chunk * 9;
+        const uint4 *src = a.w + ((size_t)(tap * chunks + chunk) * a.cout_pad + n0) * 4;
+#pragma unroll
+        for (int i = 0; i < B_ROUNDS; ++i) {
+            const int e = tid + i * kSplitThreads;
+            const bool v = n0 + (e >> 2) < a.cout_pad;
+            b_reg[i] = v ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_ROUNDS; ++i) {
+            const int e = tid + i * kSplitThreads;
+            const int n = e >> 2, pc = e & 3;
+            Bs[(buf * BN + n) * 4 + (pc ^ ((n >> 2) & 3))] = b_reg[i];
+        }
+    };
+    auto load_a = [&](int chunk, int round) {       // one 16-byte piece of the (TH+2) x 34 halo of `chunk`
+        const int e = round * kSplitThreads + tid;
+        const int pix = e >> 2, pc = e & 3;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool v = e < A_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        a_reg = v ? xin[((size_t)iy * a.W + ix) * in_pix_stride + (size_t)chunk * 4 + pc] : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_a = [&](int buf, int round) {
+        const int e = round * kSplitThreads + tid;
+        if (e < A_PIECES) {
+            const int pix = e >> 2, pc = e & 3;
+            As[(buf * HP + pix) * 4 + (pc ^ ((pix >> 2) & 3))] = a_reg;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // B fragment addresses are tap-invariant
+    int b_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = wn * (NI * 32) + j * 32 + lm;
+        b_off[j] = n * 4 + ((2 * kh) ^ ((n >> 2) & 3));
+    }
+
+    // ---- prologue: halo of chunk 0, weights of step 0 -------------------------------------------
+#pragma unroll 1
+    for (int r = 0; r < A_ROUNDS; ++r) {
+        load_a(0, r);
+        store_a(0, r);
+    }
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+
+    int abuf = 0, bbuf = 0, tap = 0, chunk = 0;
+#pragma unroll 1
+    for (int step = 0; step < steps; ++step) {
+        const bool more_b = step + 1 < steps;
+        const bool more_a = tap < A_ROUNDS && chunk + 1 < chunks;
+        if (more_b) load_b(step + 1);
+        if (more_a) load_a(chunk + 1, tap);
+
+        const int r = tap / 3, s = tap - 3 * r;
+        uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int pix = (wm * MI + i + r) * HW + lm + s;
+            const int idx = (abuf * HP + pix) * 4 + ((2 * kh) ^ ((pix >> 2) & 3));
+            ahi[i] = As[idx];
+            alo[i] = As[idx ^ 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bhi[j] = Bs[bbuf * BN * 4 + b_off[j]];
+            blo[j] = Bs[bbuf * BN * 4 + (b_off[j] ^ 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                acc[i][j] = Half<F16>::mfma(alo[i], bhi[j], acc[i][j]);
+                acc[i][j] = Half<F16>::mfma(ahi[i], blo[j], acc[i][j]);
+                acc[i][j] = Half<F16>::mfma(ahi[i], bhi[j], acc[i][j]);
+            }
+
+        if (more_b) store_b(bbuf ^ 1);
+        if (more_a) store_a(abuf ^ 1, tap);
+        __syncthreads();
+        bbuf ^= 1;
+        if (++tap == 9) {
+            tap = 0;
+            ++chunk;
+            abuf ^= 1;
+        }
+    }
+
+    // ---- epilogue: scale + bias + activation, transpose through LDS, 16-byte stores --------------
+    float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
+    float bias_v[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (NI * 32) + j * 32 + lm;
+        bias_v[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+    }
+    const int cout_chunks = a.Cout >> 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {             // fully unrolled: acc[] must be indexed statically
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                stage[m * STAGE_LD + j * 32 + lm] = act_apply(acc[i][j][e] * a.out_scale + bias_v[j], a.act);
+            }
+        __syncthreads();
+        const int oy = oy0 + wm * MI + i;
+        const int nbase = n0 + wn * (NI * 32);                         // first channel of this wave's 64
+        if (oy < a.H) {
+            if (a.out_f32) {
+                float *out = reinterpret_cast<float *>(a.out);
+#pragma unroll
+                for (int rd = 0; rd < 8; ++rd) {                       // 32 px x 16 float4 = 512 pieces
+                    const int e = rd * 64 + lane;
+                    const int px = e >> 4, q = e & 15;
+                    const int ox = ox0 + px, n = nbase + 4 * q;
+                    if (ox < a.W && n < a.Cout) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
+                        *reinterpret_cast<float4 *>(out + (((size_t)img * a.H + oy) * a.W + ox) * a.Cout + n) = v;
+                    }
+                }
+            } else {
+                uint4 *out = reinterpret_cast<uint4 *>(a.out);
+#pragma unroll
+                for (int rd = 0; rd < 8; ++rd) {                       // 32 px x 16 pieces
+                    const int e = rd * 64 + lane;
+                    const int px = e >> 4, q = e & 15;                 // q: chunk-local (q >> 2), piece (q & 3)
+                    const int ox = ox0 + px;
+                    const int cl = q >> 2, pc = q & 3;
+                    const int n = nbase + cl * 16;                     // first channel of the 16-slice
+                    if (ox < a.W && n < a.Cout) {
+                        float xs[8];
+                        const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
+                        const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                        const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                        xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                        out[((((size_t)img * a.H + oy) * a.W + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
+                            split_piece<F16>(xs, (pc & 1) != 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- float32 NHWC <-> SPLIT16 ---------------------------------------------------------------
+template <bool F16>
+__global__ void __launch_bounds__(256)
+f32_to_split_kernel(const float *__restrict__ x, long long npieces, uint4 *__restrict__ out)
+{
+    // piece p: pixel-major; 4 pieces per 16 channels; piece (g*2 + lo) covers channels 8g..8g+7
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npieces; p += (long long)gridDim.x * 256) {
+        const long long rec = p >> 2;                 // (pixel, chunk) record
+        const int pc = (int)(p & 3);
+        const float *src = x + rec * 16 + (pc >> 1) * 8;
+        const float4 v0 = *reinterpret_cast<const float4 *>(src);
+        const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+        const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        out[p] = split_piece<F16>(xs, (pc & 1) != 0);
+    }
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256)
+split_to_f32_kernel(const uint4 *__restrict__ x, long long nhalf, float *__restrict__ out)
+{
+    // one thread per 8 channels: pieces (2g, 2g+1) -> 8 floats
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < nhalf; p += (long long)gridDim.x * 256) {
+        const uint4 hi = x[2 * p], lo = x[2 * p + 1];
+        const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = join<F16>((unsigned short)(h[k] & 0xffffu), (unsigned short)(l[k] & 0xffffu));
+            o[2 * k + 1] = join<F16>((unsigned short)(h[k] >> 16), (unsigned short)(l[k] >> 16));
+        }
+        float4 *dst = reinterpret_cast<float4 *>(out + p * 8);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// MaxPooling2D(2,2) 'valid' on SPLIT16: compare hi+lo, keep the winner's (hi, lo) pair
+template <bool F16>
+__global__ void __launch_bounds__(256)
+maxpool_split_kernel(const uint4 *__restrict__ x, int H, int W, int G, int OH, int OW, long long total,
+                     uint4 *__restrict__ out)
+{
+    // G = C/8 groups of 8 channels per pixel; thread = one (pixel, group): reads pieces (2g, 2g+1)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long t = i / G;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const long long b = t / OH;
+        unsigned bh[4] = {0, 0, 0, 0}, bl[4] = {0, 0, 0, 0};
+        float best[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const size_t pix = ((size_t)b * H + 2 * oy + dy) * W + 2 * ox + dx;
+                const uint4 hi = x[(pix * G + g) * 2], lo = x[(pix * G + g) * 2 + 1];
+                const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned short hs = (unsigned short)((k & 1) ? (h[k >> 1] >> 16) : (h[k >> 1] & 0xffffu));
+                    const unsigned short ls = (unsigned short)((k & 1) ? (l[k >> 1] >> 16) : (l[k >> 1] & 0xffffu));
+                    const float v = join<F16>(hs, ls);
+                    if ((dy == 0 && dx == 0) || v > best[k]) {
+                        best[k] = v;
+                        const unsigned sh = (k & 1) ? 16u : 0u;
+                        const unsigned m = 0xffffu << sh;
+                        bh[k >> 1] = (bh[k >> 1] & ~m) | ((unsigned)hs << sh);
+                        bl[k >> 1] = (bl[k >> 1] & ~m) | ((unsigned)ls << sh);
+                    }
+                }
+            }
+        const size_t opix = ((size_t)b * OH + oy) * OW + ox;
+        out[(opix * G + g) * 2] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
+        out[(opix * G + g) * 2 + 1] = make_uint4(bl[0], bl[1], bl[2], bl[3]);
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+static inline unsigned short f32_to_bf16_rne(float f)
+{
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_to_f32(unsigned short h)
+{
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int split_weight_shift(const float *hwio, size_t count, bool f16)
+{
+    if (!f16) return 0;
+    float mx = 0.0f;
+    for (size_t i = 0; i < count; ++i) {
+        const float v = hwio[i] < 0 ? -hwio[i] : hwio[i];
+        if (v > mx) mx = v;
+    }
+    if (!(mx > 0.0f)) return 0;
+    int e = 0;
+    (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
+    int s = 12 - e;                             // largest weight lands in [2^11, 2^12): far from fp16 overflow
+    if (s < 0) s = 0;
+    if (s > 24) s = 24;
+    return s;
+}
+
+// HWIO (3,3,Cin,Cout) float32 (already multiplied by `scale[n]` if given) -> split records
+void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
+                             int shift, unsigned short *dst /* [9][Cin/16][cout_pad][32] */)
+{
+    const int chunks = Cin / 16;
+    const float mul = ldexpf(1.0f, shift);
+    memset(dst, 0, (size_t)9 * chunks * cout_pad * 32 * sizeof(unsigned short));
+    for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < Cin; ++c)
+            for (int n = 0; n < Cout; ++n) {
+                float v = hwio[((size_t)t * Cin + c) * Cout + n];
+                if (scale) v *= scale[n];
+                v *= mul;
+                unsigned short hi, lo;
+                if (f16) {
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    memcpy(&hi, &h, 2);
+                    memcpy(&lo, &l, 2);
+                } else {
+                    hi = f32_to_bf16_rne(v);
+                    lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+                }
+                const int chunk = c >> 4, g = (c >> 3) & 1, k = c & 7;
+                unsigned short *rec = dst + (((size_t)t * chunks + chunk) * cout_pad + n) * 32;
+                rec[(g * 2 + 0) * 8 + k] = hi;
+                rec[(g * 2 + 1) * 8 + k] = lo;
+            }
+}
+
+static int grid_cap(long long items)
+{
+    long long g = (items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, void *out, hipStream_t s)
+{
+    if (C % 16 != 0) return hipErrorInvalidValue;
+    const long long pieces = npix * (C / 16) * 4;
+    if (pieces == 0) return hipSuccess;
+    if (f16) hipLaunchKernelGGL(f32_to_split_kernel<true>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out);
+    else hipLaunchKernelGGL(f32_to_split_kernel<false>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, float *out, hipStream_t s)
+{
+    if (C % 16 != 0) return hipErrorInvalidValue;
+    const long long halves = npix * (C / 8);
+    if (halves == 0) return hipSuccess;
+    if (f16) hipLaunchKernelGGL(split_to_f32_kernel<true>, dim3(grid_cap(halves)), dim3(256), 0, s, (const uint4 *)x, halves, out);
+    else hipLaunchKernelGGL(split_to_f32_kernel<false>, dim3(grid_cap(halves)), dim3(256), 0, s, (const uint4 *)x, halves, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s)
+{
+    if (C % 16 != 0) return hipErrorInvalidValue;
+    const int OH = H / 2, OW = W / 2, G = C / 8;
+    const long long total = (long long)B * OH * OW * G;
+    if (total == 0) return hipSuccess;
+    if (f16) hipLaunchKernelGGL(maxpool_split_kernel<true>, dim3(grid_cap(total)), dim3(256), 0, s, (const uint4 *)x, H, W, G, OH, OW, total, (uint4 *)out);
+    else hipLaunchKernelGGL(maxpool_split_kernel<false>, dim3(grid_cap(total)), dim3(256), 0, s, (const uint4 *)x, H, W, G, OH, OW, total, (uint4 *)out);
+    return hipGetLastError();
+}
+
+template <int TH, int WN, bool F16>
+static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
+{
+    constexpr int BN = WN * 64;
+    const int tiles_x = (a.W + TWS - 1) / TWS, tiles_y = (a.H + TH - 1) / TH;
+    const int n_tiles = (a.Cout + BN - 1) / BN;
+    const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
+    if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, F16>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0, s, a,
+                       tiles_x, tiles_y, n_tiles);
+    return hipGetLastError();
+}
+
+// 3x3 stride-1 'same' conv on SPLIT16 input.  x: SPLIT16 (B,H,W,Cin), w: split records, out: SPLIT16 or f32 NHWC.
+hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
+                                hipStream_t s)
+{
+    if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0) return hipErrorInvalidValue;
+    SplitConvArgs a{};
+    a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
+    a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
+    // tile choice: 64-wide N tiles for Cout <= 64; short tiles when the grid would not fill the chip
+    const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
+    if (Cout <= 64) return f16 ? launch_split_variant<8, 1, true>(a, s) : launch_split_variant<8, 1, false>(a, s);
+    if (big_blocks < 512) return f16 ? launch_split_variant<4, 2, true>(a, s) : launch_split_variant<4, 2, false>(a, s);
+    return f16 ? launch_split_variant<8, 2, true>(a, s) : launch_split_variant<8, 2, false>(a, s);
+}
+
+}  // namespace rpn

@@ -21,7 +21,7 @@ namespace rpn {
 
 constexpr float kBnEps = 1e-3f;
 
-enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3 };
+enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3, OP_TOSPLIT = 4 };
 
 struct Tensor {
     std::string name;
@@ -29,6 +29,7 @@ struct Tensor {
     int def = -1, last_use = -1;       // op indices
     size_t offset = 0;                 // floats per image inside the arena (x max_batch)
     bool external = false;             // input images / head outputs
+    bool split_fmt = false;            // SPLIT16 (hi/lo 16-bit records) instead of float32 NHWC; same byte size
     size_t floats() const { return (size_t)H * W * C; }
 };
 
@@ -51,6 +52,9 @@ struct Op {
     PackedShape ps{};
     size_t w_off = 0, b_off = 0;       // floats into the weight blob
     std::vector<int> params;
+    bool split = false;                // runs on the x3-split 16-bit MFMA kernel (SPLIT16 input)
+    bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
+    float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
 };
 
 }  // namespace rpn
@@ -59,6 +63,7 @@ using namespace rpn;
 
 struct rpn_model {
     int backbone = 0, img_size = 0, K = 0, precision = 0, max_batch = 0;
+    bool use_split = false, f16 = false;   // precision != F32: eligible 3x3 convs use the split kernel
     int F = 0, feat_tensor = -1;
     bool keep_all = false;
     std::vector<Tensor> tensors;
@@ -97,15 +102,31 @@ static int add_param(rpn_model *m, int op, const std::string &name, const std::s
 
 // dense conv op; returns the output tensor id
 static int add_conv(rpn_model *m, const std::string &name, const std::string &bn, int in, int Cout, int R,
-                    int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1)
+                    int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1,
+                    bool force_f32_out = false)
 {
+    const bool split = m->use_split && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && residual < 0 &&
+                       m->tensors[in].C % 16 == 0 && Cout % 16 == 0 && !m->tensors[in].external;
+    if (split && !m->tensors[in].split_fmt) {          // float32 producer -> SPLIT16 copy for the split kernel
+        const Tensor tsrc = m->tensors[in];
+        Op cv;
+        cv.kind = OP_TOSPLIT; cv.name = tsrc.name + "/split"; cv.in = in;
+        cv.Cin = cv.Cout = tsrc.C; cv.H = cv.OH = tsrc.H; cv.W = cv.OW = tsrc.W;
+        cv.out = add_tensor(m, cv.name, tsrc.H, tsrc.W, tsrc.C);
+        m->tensors[cv.out].split_fmt = true;
+        m->ops.push_back(cv);
+        in = cv.out;
+    }
     const Tensor ti = m->tensors[in];
     Op op;
+    op.split = split;
+    op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
     op.ps = packed_shape(R, R, ti.C, Cout);
     op.out = add_tensor(m, name, OH, OW, Cout);
+    m->tensors[op.out].split_fmt = split && !force_f32_out;
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
     add_param(m, oi, name, bn, bn.empty() ? 0 : 1, R, R, ti.C, Cout);
@@ -136,6 +157,8 @@ static int add_pool(rpn_model *m, const std::string &name, int in)
     op.kind = OP_POOL; op.name = name; op.in = in;
     op.Cin = op.Cout = ti.C; op.H = ti.H; op.W = ti.W; op.OH = ti.H / 2; op.OW = ti.W / 2;   // 'valid' floors
     op.out = add_tensor(m, name, op.OH, op.OW, ti.C);
+    op.split = ti.split_fmt;
+    m->tensors[op.out].split_fmt = ti.split_fmt;
     m->ops.push_back(op);
     return op.out;
 }
@@ -144,7 +167,7 @@ static int add_pool(rpn_model *m, const std::string &name, int in)
 static void add_head(rpn_model *m, int feat)
 {
     const Tensor tf = m->tensors[feat];
-    const int x = add_conv(m, "rpn_conv", "", feat, 512, 3, 1, 1, 1, tf.H, tf.W, ACT_RELU);
+    const int x = add_conv(m, "rpn_conv", "", feat, 512, 3, 1, 1, 1, tf.H, tf.W, ACT_RELU, -1, true);
     Op op;
     op.kind = OP_HEAD; op.name = "rpn_head"; op.in = x;
     op.Cin = 512; op.Cout = 5 * m->K; op.R = op.S = 1; op.stride = 1;
@@ -284,7 +307,12 @@ static void plan_weights(rpn_model *m)
 {
     size_t off = 0;
     for (auto &op : m->ops) {
-        if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+        if (op.kind == OP_CONV && op.split) {
+            op.w_off = off;
+            off += (split_weight_bytes(op.Cin, op.Cout) / sizeof(float) + 63) & ~(size_t)63;
+            op.b_off = off;
+            off += (size_t)split_cout_pad(op.Cout);
+        } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             op.w_off = off;
             off += (op.ps.floats() + 63) & ~(size_t)63;
             op.b_off = off;
@@ -330,11 +358,13 @@ extern "C" int rpn_model_create(int backbone, int img_size, int anchor_count, in
     RPN_REQUIRE(anchor_count >= 1 && anchor_count <= 64, "rpn_model_create: anchor_count %d out of range",
                 anchor_count);
     RPN_REQUIRE(max_batch >= 1, "rpn_model_create: max_batch must be >= 1");
-    if (precision != RPN_PRECISION_F32)
-        return fail(RPN_ERR_UNSUPPORTED, "rpn_model_create: precision %d not implemented", precision);
+    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3,
+                "rpn_model_create: unknown precision %d", precision);
     rpn_model *m = new rpn_model();
     m->backbone = backbone; m->img_size = img_size; m->K = anchor_count; m->precision = precision;
     m->max_batch = max_batch;
+    m->use_split = precision != RPN_PRECISION_F32;
+    m->f16 = precision == RPN_PRECISION_F16X3;
     if (backbone == RPN_BACKBONE_VGG16) build_vgg16(m);
     else build_mobilenet_v2(m);
     m->F = m->tensors[m->feat_tensor].H;
@@ -445,6 +475,17 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                   hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+    } else if (op.split) {
+        const int cpad = split_cout_pad(op.Cout);
+        const int wshift = split_weight_shift(kernel, (size_t)9 * p.Cin * p.Cout, m->f16);
+        std::vector<unsigned short> packed(split_weight_bytes(op.Cin, op.Cout) / sizeof(unsigned short));
+        pack_weights_split_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
+                                packed.data());
+        op.out_scale = ldexpf(1.0f, -wshift);
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(unsigned short),
+                                hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
     } else {
         std::vector<float> packed(op.ps.floats());
         pack_weights_host(op.ps, kernel, has_bn ? scale.data() : nullptr, packed.data());
@@ -484,7 +525,15 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     for (const Op &op : m->ops) {
         const float *x = tensor_ptr(m, op.in, d_imgs);
         hipError_t e = hipSuccess;
-        if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+        if (op.kind == OP_TOSPLIT) {
+            e = launch_f32_to_split(x, (long long)B * op.H * op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
+        } else if (op.kind == OP_CONV && op.split) {
+            e = launch_conv3x3_split(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
+                                     tensor_ptr(m, op.out, d_imgs), B, op.H, op.W, op.Cin, op.Cout,
+                                     split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, s);
+        } else if (op.kind == OP_POOL && op.split) {
+            e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
+        } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
             a.x = x;
             a.w = m->d_weights + op.w_off;
@@ -538,7 +587,17 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     double fl = 0.0, by = 0.0;
     const char *k = "maxpool2x2";
     const double in_b = 4.0 * op.H * op.W * op.Cin, out_b = 4.0 * op.OH * op.OW * op.Cout;
-    if (op.kind == OP_CONV || op.kind == OP_HEAD) {
+    if (op.kind == OP_TOSPLIT) {
+        by = in_b + out_b;
+        k = "f32_to_split";
+    } else if (op.kind == OP_POOL && op.split) {
+        by = in_b + out_b;
+        k = "maxpool_split";
+    } else if (op.kind == OP_CONV && op.split) {
+        fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
+        by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
+        k = m->f16 ? "conv3x3_split<f16x3>" : "conv3x3_split<bf16x3>";
+    } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
         fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
         by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
         if (op.ps.generic) k = op.Cout > 64 ? "conv_igemm_f32<128x128,generic>" : (op.Cout > 32 ? "conv_igemm_f32<128x64,generic>" : "conv_igemm_f32<128x32,generic>");
@@ -598,6 +657,13 @@ extern "C" int rpn_model_get_activation(rpn_model *m, const char *name, float *d
     RPN_REQUIRE(m->d_arena, "rpn_model_get_activation: no forward pass has run");
     const size_t bytes = t.floats() * (size_t)m->max_batch * sizeof(float);
     RPN_REQUIRE(out_bytes >= bytes, "rpn_model_get_activation: %zu bytes needed, %zu given", bytes, out_bytes);
+    if (t.split_fmt) {
+        const hipError_t e = launch_split_to_f32(m->d_arena + t.offset * (size_t)m->max_batch,
+                                                 (long long)m->max_batch * t.H * t.W, t.C, m->f16, d_out,
+                                                 as_stream(stream));
+        if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_model_get_activation: %s", hipGetErrorString(e));
+        return RPN_OK;
+    }
     RPN_HIP_CHECK(hipMemcpyAsync(d_out, m->d_arena + t.offset * (size_t)m->max_batch, bytes,
                                  hipMemcpyDeviceToDevice, as_stream(stream)));
     return RPN_OK;
@@ -613,10 +679,38 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
                     OH >= 1 && OW >= 1 && pad_t >= 0 && pad_l >= 0,
                 "rpn_conv2d: bad geometry");
     RPN_REQUIRE(act >= 0 && act <= 3, "rpn_conv2d: bad activation %d", act);
-    if (precision != RPN_PRECISION_F32)
-        return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: precision %d not implemented", precision);
+    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3,
+                "rpn_conv2d: unknown precision %d", precision);
     RPN_REQUIRE_DEVICE();
     hipStream_t s = as_stream(stream);
+    if (precision != RPN_PRECISION_F32) {
+        // x3-split path: 3x3 / stride 1 / pad 1 only; converts x to SPLIT16 and packs the weights on the host
+        if (!(R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && Cin % 16 == 0 &&
+              Cout % 16 == 0))
+            return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the split path needs 3x3 s1 'same', Cin,Cout %% 16 == 0");
+        const bool f16 = precision == RPN_PRECISION_F16X3;
+        const size_t wcount = (size_t)9 * Cin * Cout;
+        std::vector<float> hw(wcount);
+        RPN_HIP_CHECK(hipMemcpy(hw.data(), d_w, wcount * sizeof(float), hipMemcpyDeviceToHost));
+        const int cpad = split_cout_pad(Cout);
+        const int wshift = split_weight_shift(hw.data(), wcount, f16);
+        std::vector<unsigned short> packed(split_weight_bytes(Cin, Cout) / 2);
+        pack_weights_split_host(hw.data(), nullptr, Cin, Cout, cpad, f16, wshift, packed.data());
+        void *d_ws = nullptr, *d_xs = nullptr;
+        RPN_HIP_CHECK(hipMalloc(&d_ws, packed.size() * 2));
+        RPN_HIP_CHECK(hipMalloc(&d_xs, (size_t)B * H * W * Cin * sizeof(float)));
+        RPN_HIP_CHECK(hipMemcpy(d_ws, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        hipError_t e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
+        if (e == hipSuccess)
+            e = launch_conv3x3_split(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad, ldexpf(1.0f, -wshift), act,
+                                     true, f16, s);
+        const hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(d_ws);
+        (void)hipFree(d_xs);
+        if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): launch failed: %s", hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): kernel failed: %s", hipGetErrorString(e2));
+        return RPN_OK;
+    }
     ConvArgs a{};
     a.ps = packed_shape(R, S, Cin, Cout);
     float *d_packed = nullptr;
