@@ -16,5 +16,5 @@ for P in f32 bf16x3 f16x3; do
   timeout 600 python bench.py --steps 10 --warmup 2 --layers --precision $P --no-cpu-baseline > $OUT/bench_$P.json 2> $OUT/bench_layers_$P.txt
   echo "bench exit $?" >> $OUT/bench_layers_$P.txt
 done
-timeout 300 python scripts/cpu_threads.py > $OUT/cpu_threads.txt 2>&1
-grep -E "passed|failed|error" $OUT/pytest.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench_*.json; cat $OUT/cpu_threads.txt
+timeout 300 python scripts/nms_probe.py > $OUT/nms_probe.txt 2>&1
+grep -E "passed|failed|error" $OUT/pytest.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench_*.json; cat $OUT/nms_probe.txt

@@ -221,6 +221,22 @@ def test_model_forward_split_small(backbone, img, B, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("img", [150, 200])
+def test_model_forward_split_fused_pool(img, precision):
+    """Without keep_activations the 2x2 max-pools run inside the conv epilogue; odd sizes (150 -> 75 -> 37 ->
+    18 -> 9) exercise the 'valid' floor at every level."""
+    hp = bo.get_hyper_params("vgg16", img_size=img)
+    weights = synthetic_weights("vgg16", hp, seed=4)
+    model = RPNModel("vgg16", hp, precision=precision, max_batch=2)
+    model.set_weights(weights)
+    imgs = np.random.RandomState(5).uniform(0, 1, size=(2, img, img, 3)).astype(np.float32)
+    reg, cls = model.predict_on_batch(imgs)
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    assert reg.shape == ref[0].shape
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 def test_model_forward_split_full_size(precision):
     """VGG16 at the reference's 500x500: head outputs within 1e-4 of torch-CPU float32 AND of the exact-f32
     HIP path; the measured errors are printed (-s) and recorded in DESIGN.md."""
@@ -252,8 +268,11 @@ def test_split_round_trip_and_pool():
         model = RPNModel("vgg16", hp, precision=precision, max_batch=1, keep_activations=True)
         model.set_weights(weights)
         model.predict_on_batch(imgs)
-        a = model.get_activation("block1_conv1", batch=1).cpu().numpy()              # float32 producer
-        s = model.get_activation("block1_conv1/split", batch=1).cpu().numpy()        # its SPLIT16 copy, joined
+        exact = RPNModel("vgg16", hp, precision="f32", max_batch=1, keep_activations=True)
+        exact.set_weights(weights)
+        exact.predict_on_batch(imgs)
+        a = exact.get_activation("block1_conv1", batch=1).cpu().numpy()              # float32 NHWC
+        s = model.get_activation("block1_conv1", batch=1).cpu().numpy()              # SPLIT16 written directly, joined
         assert np.abs(s - a).max() <= rel * max(1.0, np.abs(a).max())
         c2 = model.get_activation("block1_conv2", batch=1).cpu().numpy()
         p = model.get_activation("block1_pool", batch=1).cpu().numpy()

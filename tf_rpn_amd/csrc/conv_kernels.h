@@ -67,6 +67,12 @@ hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, f
 hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);
 hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                hipStream_t s);
+                                bool pool, hipStream_t s);
+
+// first layer (Cin = 3, 3x3): direct conv on the vector ALU; w (27,Cout) float32; out_fmt 0 = float32 NHWC,
+// 1 = SPLIT16.  Cout % 16 == 0.
+hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, void *out, int B, int H, int W,
+                            int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
+                            hipStream_t s);
 
 }  // namespace rpn

@@ -109,7 +109,7 @@ struct SplitConvArgs {
 };
 
 // TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64)
-template <int TH, int WN, bool F16>
+template <int TH, int WN, bool F16, bool POOL>
 __global__ void __launch_bounds__(kSplitThreads, 2)
 conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -257,7 +257,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         }
     }
 
-    // ---- epilogue: scale + bias + activation, transpose through LDS, 16-byte stores --------------
+    // ---- epilogue: scale + bias + activation (+ fused 2x2 max-pool), transpose through LDS, 16-byte stores --
     float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
     float bias_v[NI];
 #pragma unroll
@@ -266,54 +266,79 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         bias_v[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     }
     const int cout_chunks = a.Cout >> 4;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {             // fully unrolled: acc[] must be indexed statically
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
-                stage[m * STAGE_LD + j * 32 + lm] = act_apply(acc[i][j][e] * a.out_scale + bias_v[j], a.act);
-            }
-        __syncthreads();
-        const int oy = oy0 + wm * MI + i;
-        const int nbase = n0 + wn * (NI * 32);                         // first channel of this wave's 64
-        if (oy < a.H) {
-            if (a.out_f32) {
-                float *out = reinterpret_cast<float *>(a.out);
-#pragma unroll
-                for (int rd = 0; rd < 8; ++rd) {                       // 32 px x 16 float4 = 512 pieces
-                    const int e = rd * 64 + lane;
-                    const int px = e >> 4, q = e & 15;
-                    const int ox = ox0 + px, n = nbase + 4 * q;
-                    if (ox < a.W && n < a.Cout) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
-                        *reinterpret_cast<float4 *>(out + (((size_t)img * a.H + oy) * a.W + ox) * a.Cout + n) = v;
-                    }
+    const int nbase = n0 + wn * (NI * 32);                             // first channel of this wave's 64
+    // write NPX staged pixels x 64 channels of output row `oy` (output image OHo x OWo, first column oxb)
+    auto store_stage = [&](int npx_log2, int oy, int oxb, int OHo, int OWo) {
+        if (oy >= OHo) return;
+        const int rounds = (16 << npx_log2) >> 6;                      // (npx * 16 pieces) / 64 lanes
+        if (a.out_f32) {
+            float *out = reinterpret_cast<float *>(a.out);
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int e = rd * 64 + lane;
+                const int px = e >> 4, q = e & 15;
+                const int ox = oxb + px, n = nbase + 4 * q;
+                if (ox < OWo && n < a.Cout) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
+                    *reinterpret_cast<float4 *>(out + (((size_t)img * OHo + oy) * OWo + ox) * a.Cout + n) = v;
                 }
-            } else {
-                uint4 *out = reinterpret_cast<uint4 *>(a.out);
-#pragma unroll
-                for (int rd = 0; rd < 8; ++rd) {                       // 32 px x 16 pieces
-                    const int e = rd * 64 + lane;
-                    const int px = e >> 4, q = e & 15;                 // q: chunk-local (q >> 2), piece (q & 3)
-                    const int ox = ox0 + px;
-                    const int cl = q >> 2, pc = q & 3;
-                    const int n = nbase + cl * 16;                     // first channel of the 16-slice
-                    if (ox < a.W && n < a.Cout) {
-                        float xs[8];
-                        const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
-                        const float4 v0 = *reinterpret_cast<const float4 *>(src);
-                        const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-                        xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
-                        xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-                        out[((((size_t)img * a.H + oy) * a.W + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
-                            split_piece<F16>(xs, (pc & 1) != 0);
-                    }
+            }
+        } else {
+            uint4 *out = reinterpret_cast<uint4 *>(a.out);
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int e = rd * 64 + lane;
+                const int px = e >> 4, q = e & 15;                     // q: 16-slice (q >> 2), piece (q & 3)
+                const int ox = oxb + px;
+                const int cl = q >> 2, pc = q & 3;
+                const int n = nbase + cl * 16;
+                if (ox < OWo && n < a.Cout) {
+                    float xs[8];
+                    const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
+                    const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                    xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                    out[((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
+                        split_piece<F16>(xs, (pc & 1) != 0);
                 }
             }
         }
-        __syncthreads();
+    };
+
+    if constexpr (POOL) {
+        // MaxPooling2D(2,2) 'valid' fused: the 2x2 window of output pixel (y,x) is rows (2y, 2y+1) -- two
+        // M-blocks of this wave -- and accumulator registers (2e', 2e'+1) of one lane, so the max is lane-local.
+        // max commutes with the monotone bias + activation, which are applied once afterwards.
+        static_assert(!POOL || (MI % 2 == 0), "pooling needs an even number of rows per wave");
+        const int OHo = a.H >> 1, OWo = a.W >> 1;
+#pragma unroll
+        for (int ip = 0; ip < MI / 2; ++ip) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e2 = 0; e2 < 8; ++e2) {
+                    const float v0 = fmaxf(acc[2 * ip][j][2 * e2], acc[2 * ip][j][2 * e2 + 1]);
+                    const float v1 = fmaxf(acc[2 * ip + 1][j][2 * e2], acc[2 * ip + 1][j][2 * e2 + 1]);
+                    const int m2 = (e2 & 1) + 4 * (e2 >> 1) + 2 * kh;             // pooled column 0..15
+                    stage[m2 * STAGE_LD + j * 32 + lm] = act_apply(fmaxf(v0, v1) * a.out_scale + bias_v[j], a.act);
+                }
+            __syncthreads();
+            store_stage(4, (oy0 + wm * MI + 2 * ip) >> 1, ox0 >> 1, OHo, OWo);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {             // fully unrolled: acc[] must be indexed statically
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    stage[m * STAGE_LD + j * 32 + lm] = act_apply(acc[i][j][e] * a.out_scale + bias_v[j], a.act);
+                }
+            __syncthreads();
+            store_stage(5, oy0 + wm * MI + i, ox0, a.H, a.W);
+            __syncthreads();
+        }
     }
 }
 
@@ -395,6 +420,113 @@ maxpool_split_kernel(const uint4 *__restrict__ x, int H, int W, int G, int OH, i
         out[(opix * G + g) * 2] = make_uint4(bh[0], bh[1], bh[2], bh[3]);
         out[(opix * G + g) * 2 + 1] = make_uint4(bl[0], bl[1], bl[2], bl[3]);
     }
+}
+
+// ---- first layer: Cin = 3, 3x3, stride 1 or 2 (VGG16 block1_conv1, MobileNetV2 Conv1) -------------
+// K = 27 is too short for the matrix cores to pay off (the gather dominates), so this is a direct
+// convolution on the vector ALU: one thread = 2 horizontally adjacent output pixels x 16 output
+// channels, weights broadcast from LDS (27 x Cout floats), 864 FMAs per thread.  The output is written
+// either as float32 NHWC or directly as SPLIT16 records (one 64-byte record per thread and pixel), which
+// removes the separate float32 -> SPLIT16 pass in front of the split-precision layers.
+// HBM-bound in principle (12 B read + 4*Cout B written per pixel); VALU-bound in practice.
+template <bool F16, bool OUT_SPLIT>
+__global__ void __launch_bounds__(256)
+conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27, Cout) */,
+                 const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
+                 int Cout, int stride, int pad_t, int pad_l, int act, long long npairs)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [27][Cout] + bias[Cout]
+    const int CG = Cout >> 4;
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.0f;
+    __syncthreads();
+    const int PW = (OW + 1) >> 1;                                     // pixel pairs per output row
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(t % CG);
+    const long long pair = t / CG;
+    if (pair >= npairs) return;
+    const int px2 = (int)(pair % PW);
+    long long rest = pair / PW;
+    const int oy = (int)(rest % OH);
+    const int img = (int)(rest / OH);
+    const int ox = 2 * px2;
+
+    float acc[2][16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) acc[0][n] = acc[1][n] = wl[27 * Cout + cg * 16 + n];
+    const float *ximg = x + (size_t)img * H * W * 3;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {           // rolled: keeps the weight fragment at 16 registers
+        const int r = tap / 3, s = tap - 3 * r;
+        const int iy = oy * stride + r - pad_t;
+        float in[2][3];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ix = (ox + p) * stride + s - pad_l;
+            const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float *src = ximg + ((size_t)(v ? iy : 0) * W + (v ? ix : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in[p][c] = v ? src[c] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 *wk = reinterpret_cast<const float4 *>(&wl[(tap * 3 + c) * Cout + cg * 16]);
+            const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
+            const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                  w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                acc[0][n] = fmaf(in[0][c], ws[n], acc[0][n]);
+                acc[1][n] = fmaf(in[1][c], ws[n], acc[1][n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (ox + p >= OW) break;
+        const size_t pix = ((size_t)img * OH + oy) * OW + ox + p;
+        float v[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v[n] = act_apply(acc[p][n], act);
+        if constexpr (OUT_SPLIT) {
+            uint4 *dst = reinterpret_cast<uint4 *>(out) + (pix * CG + cg) * 4;
+            const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const float hi8[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+            dst[0] = split_piece<F16>(lo8, false);
+            dst[1] = split_piece<F16>(lo8, true);
+            dst[2] = split_piece<F16>(hi8, false);
+            dst[3] = split_piece<F16>(hi8, true);
+        } else {
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + pix * Cout + cg * 16);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+            dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+        }
+    }
+}
+
+// w: (27, Cout) float32 = HWIO flattened (BatchNorm scale already folded); out_fmt: 0 float32 NHWC, 1 SPLIT16
+hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, void *out, int B, int H, int W,
+                            int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
+                            hipStream_t s)
+{
+    if (Cout % 16 != 0 || Cout > 256) return hipErrorInvalidValue;
+    const long long npairs = (long long)B * OH * ((OW + 1) / 2);
+    const long long threads = npairs * (Cout / 16);
+    if (threads <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    const size_t lds = (size_t)28 * Cout * sizeof(float);
+    if (out_fmt == 0)
+        hipLaunchKernelGGL((conv_cin3_kernel<false, false>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
+                           OW, Cout, stride, pad_t, pad_l, act, npairs);
+    else if (f16)
+        hipLaunchKernelGGL((conv_cin3_kernel<true, true>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
+                           OW, Cout, stride, pad_t, pad_l, act, npairs);
+    else
+        hipLaunchKernelGGL((conv_cin3_kernel<false, true>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
+                           OW, Cout, stride, pad_t, pad_l, act, npairs);
+    return hipGetLastError();
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -500,7 +632,7 @@ hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool 
     return hipGetLastError();
 }
 
-template <int TH, int WN, bool F16>
+template <int TH, int WN, bool F16, bool POOL>
 static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
 {
     constexpr int BN = WN * 64;
@@ -508,26 +640,39 @@ static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
     const int n_tiles = (a.Cout + BN - 1) / BN;
     const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, F16>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0, s, a,
-                       tiles_x, tiles_y, n_tiles);
+    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, F16, POOL>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0, s,
+                       a, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
 
-// 3x3 stride-1 'same' conv on SPLIT16 input.  x: SPLIT16 (B,H,W,Cin), w: split records, out: SPLIT16 or f32 NHWC.
+template <bool F16, bool POOL>
+static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
+{
+    // tile choice: 64-wide N tiles for Cout <= 64; shorter / narrower tiles when the grid would not put
+    // two workgroups on each of the 256 CUs
+    const long long mt8 = (long long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
+    const long long mt4 = (long long)((a.W + 31) / 32) * ((a.H + 3) / 4) * a.B;
+    const int nt128 = (a.Cout + 127) / 128;
+    if (a.Cout <= 64) return launch_split_variant<8, 1, F16, POOL>(a, s);
+    if (mt8 * nt128 >= 512) return launch_split_variant<8, 2, F16, POOL>(a, s);
+    if (mt4 * nt128 >= 512 || POOL) return launch_split_variant<4, 2, F16, POOL>(a, s);
+    if constexpr (!POOL) return launch_split_variant<4, 1, F16, false>(a, s);
+    return hipErrorInvalidValue;
+}
+
+// 3x3 stride-1 'same' conv on SPLIT16 input (optionally followed by a fused 2x2 'valid' max-pool).
+// x: SPLIT16 (B,H,W,Cin), w: split records, out: SPLIT16 or f32 NHWC of (B,H,W,Cout) or, pooled, (B,H/2,W/2,Cout).
 hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                hipStream_t s)
+                                bool pool, hipStream_t s)
 {
     if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
-    // tile choice: 64-wide N tiles for Cout <= 64; short tiles when the grid would not fill the chip
-    const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
-    if (Cout <= 64) return f16 ? launch_split_variant<8, 1, true>(a, s) : launch_split_variant<8, 1, false>(a, s);
-    if (big_blocks < 512) return f16 ? launch_split_variant<4, 2, true>(a, s) : launch_split_variant<4, 2, false>(a, s);
-    return f16 ? launch_split_variant<8, 2, true>(a, s) : launch_split_variant<8, 2, false>(a, s);
+    if (pool) return f16 ? launch_split_tiles<true, true>(a, s) : launch_split_tiles<false, true>(a, s);
+    return f16 ? launch_split_tiles<true, false>(a, s) : launch_split_tiles<false, false>(a, s);
 }
 
 }  // namespace rpn

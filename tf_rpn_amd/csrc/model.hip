@@ -52,6 +52,7 @@ struct Op {
     PackedShape ps{};
     size_t w_off = 0, b_off = 0;       // floats into the weight blob
     std::vector<int> params;
+    bool cin3 = false;                 // first layer (Cin = 3, 3x3): direct vector-ALU kernel
     bool split = false;                // runs on the x3-split 16-bit MFMA kernel (SPLIT16 input)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
@@ -103,7 +104,7 @@ static int add_param(rpn_model *m, int op, const std::string &name, const std::s
 // dense conv op; returns the output tensor id
 static int add_conv(rpn_model *m, const std::string &name, const std::string &bn, int in, int Cout, int R,
                     int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1,
-                    bool force_f32_out = false)
+                    bool force_f32_out = false, bool cin3_out_split = false)
 {
     const bool split = m->use_split && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && residual < 0 &&
                        m->tensors[in].C % 16 == 0 && Cout % 16 == 0 && !m->tensors[in].external;
@@ -120,13 +121,14 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     const Tensor ti = m->tensors[in];
     Op op;
     op.split = split;
+    op.cin3 = ti.C == 3 && R == 3 && Cout % 16 == 0 && Cout <= 256 && residual < 0;
     op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
     op.ps = packed_shape(R, R, ti.C, Cout);
     op.out = add_tensor(m, name, OH, OW, Cout);
-    m->tensors[op.out].split_fmt = split && !force_f32_out;
+    m->tensors[op.out].split_fmt = (split && !force_f32_out) || (op.cin3 && cin3_out_split);
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
     add_param(m, oi, name, bn, bn.empty() ? 0 : 1, R, R, ti.C, Cout);
@@ -190,7 +192,9 @@ static void build_vgg16(rpn_model *m)
             char name[64];
             snprintf(name, sizeof name, "block%d_conv%d", blk + 1, c + 1);
             const Tensor ti = m->tensors[t];
-            t = add_conv(m, name, "", t, cfg[blk][1], 3, 1, 1, 1, ti.H, ti.W, ACT_RELU);
+            // block1_conv1 (Cin = 3) writes SPLIT16 directly when the next layer runs on the split kernel
+            t = add_conv(m, name, "", t, cfg[blk][1], 3, 1, 1, 1, ti.H, ti.W, ACT_RELU, -1, false,
+                         m->use_split && ti.C == 3);
         }
         if (blk < 4) {                       // block5_pool is never executed (tap = block5_conv3)
             char name[64];
@@ -307,7 +311,12 @@ static void plan_weights(rpn_model *m)
 {
     size_t off = 0;
     for (auto &op : m->ops) {
-        if (op.kind == OP_CONV && op.split) {
+        if (op.kind == OP_CONV && op.cin3) {
+            op.w_off = off;
+            off += ((size_t)27 * op.Cout + 63) & ~(size_t)63;
+            op.b_off = off;
+            off += ((size_t)op.Cout + 63) & ~(size_t)63;
+        } else if (op.kind == OP_CONV && op.split) {
             op.w_off = off;
             off += (split_weight_bytes(op.Cin, op.Cout) / sizeof(float) + 63) & ~(size_t)63;
             op.b_off = off;
@@ -475,6 +484,14 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                   hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+    } else if (op.cin3) {
+        std::vector<float> w((size_t)27 * p.Cout);
+        for (int k = 0; k < 27; ++k)
+            for (int n = 0; n < p.Cout; ++n)
+                w[(size_t)k * p.Cout + n] = kernel[(size_t)k * p.Cout + n] * (has_bn ? scale[n] : 1.0f);
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
     } else if (op.split) {
         const int cpad = split_cout_pad(op.Cout);
         const int wshift = split_weight_shift(kernel, (size_t)9 * p.Cin * p.Cout, m->f16);
@@ -522,15 +539,30 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
         ++m->profiled_forwards;
     }
     int op_index = 0;
-    for (const Op &op : m->ops) {
+    bool skip_next = false;
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const Op &op = m->ops[oi];
         const float *x = tensor_ptr(m, op.in, d_imgs);
         hipError_t e = hipSuccess;
-        if (op.kind == OP_TOSPLIT) {
+        // a split conv directly followed by its 2x2 max-pool runs as ONE kernel (pool fused into the
+        // epilogue; the un-pooled activation never reaches HBM) unless every activation must be kept
+        const bool fuse_pool = op.kind == OP_CONV && op.split && !op.out_f32 && !m->keep_all &&
+                               oi + 1 < m->ops.size() && m->ops[oi + 1].kind == OP_POOL &&
+                               m->ops[oi + 1].split && m->ops[oi + 1].in == op.out;
+        if (skip_next) {
+            skip_next = false;                      // the pool already ran inside the previous conv
+        } else if (op.kind == OP_TOSPLIT) {
             e = launch_f32_to_split(x, (long long)B * op.H * op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
+        } else if (op.kind == OP_CONV && op.cin3) {
+            e = launch_conv_cin3(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs), B,
+                                 op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
+                                 m->tensors[op.out].split_fmt ? 1 : 0, m->f16, s);
         } else if (op.kind == OP_CONV && op.split) {
+            const int dst = fuse_pool ? m->ops[oi + 1].out : op.out;
             e = launch_conv3x3_split(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
-                                     tensor_ptr(m, op.out, d_imgs), B, op.H, op.W, op.Cin, op.Cout,
-                                     split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, s);
+                                     tensor_ptr(m, dst, d_imgs), B, op.H, op.W, op.Cin, op.Cout,
+                                     split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, fuse_pool, s);
+            skip_next = fuse_pool;
         } else if (op.kind == OP_POOL && op.split) {
             e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
@@ -593,6 +625,10 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_POOL && op.split) {
         by = in_b + out_b;
         k = "maxpool_split";
+    } else if (op.kind == OP_CONV && op.cin3) {
+        fl = 2.0 * op.OH * op.OW * op.Cout * 27.0;
+        by = in_b + out_b;
+        k = "conv_cin3_direct";
     } else if (op.kind == OP_CONV && op.split) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
         by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
@@ -703,12 +739,19 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         hipError_t e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
         if (e == hipSuccess)
             e = launch_conv3x3_split(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad, ldexpf(1.0f, -wshift), act,
-                                     true, f16, s);
+                                     true, f16, false, s);
         const hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(d_ws);
         (void)hipFree(d_xs);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): launch failed: %s", hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): kernel failed: %s", hipGetErrorString(e2));
+        return RPN_OK;
+    }
+    if (Cin == 3 && R == 3 && S == 3 && Cout % 16 == 0 && Cout <= 256) {      // first-layer direct kernel
+        const hipError_t e = launch_conv_cin3(d_x, d_w, d_bias, d_out, B, H, W, OH, OW, Cout, stride, pad_t, pad_l, act,
+                                              0, false, s);
+        if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(cin3): launch failed: %s", hipGetErrorString(e));
+        RPN_HIP_CHECK(hipStreamSynchronize(s));
         return RPN_OK;
     }
     ConvArgs a{};
