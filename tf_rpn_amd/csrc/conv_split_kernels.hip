@@ -11,7 +11,7 @@
 //
 // Layouts ("SPLIT16"): activations [B][H][W][C/16][64 B], one 64-byte record per pixel and
 // 16-channel slice = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} as four 16-byte pieces; weights
-// [tap][C/16][cout_pad][64 B] with the same record per output channel.  A 16-byte piece is
+// [C/16][tap][cout_pad][64 B] with the same record per output channel.  A 16-byte piece is
 // exactly one lane's A (or B) fragment of v_mfma_f32_32x32x16_{bf16,f16}.
 //
 // Kernel: implicit GEMM, M = TH x 32 output pixels of one image, N = 64 or 128 output
@@ -100,7 +100,7 @@ __device__ __forceinline__ int xcd_remap_s(int bid, int nwg)
 
 struct SplitConvArgs {
     const uint4 *x;       // SPLIT16 input  [B][H][W][Cin/16][4]
-    const uint4 *w;       // split weights  [9][Cin/16][cout_pad][4]
+    const uint4 *w;       // split weights  [Cin/16][9][cout_pad][4]
     const float *bias;    // (Cout) float32, may be null
     void *out;            // SPLIT16 [B][H][W][Cout/16][4]  or float32 NHWC [B][H][W][Cout]
     int B, H, W, Cin, Cout, cout_pad;
@@ -108,7 +108,11 @@ struct SplitConvArgs {
     int act, out_f32;
 };
 
-// TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64)
+// TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64).
+// One barrier interval ("step") = one 16-channel slice x one FILTER ROW (3 taps): 3 x MI x NI x 3 MFMAs per
+// wave between barriers, and the LDS fragment reads of tap s+1 overlap the MFMAs of tap s.
+// BBUF: weight-tile buffers in LDS (2 = double buffered, one barrier per step; 1 = single buffered with a
+// second barrier, used where two buffers would not leave room for two workgroups per CU).
 template <int TH, int WN, bool F16, bool POOL>
 __global__ void __launch_bounds__(kSplitThreads, 2)
 conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
@@ -120,17 +124,19 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     constexpr int HP = (TH + 2) * HW;        // halo pixels
     constexpr int A_PIECES = HP * 4;
     constexpr int A_ROUNDS = (A_PIECES + kSplitThreads - 1) / kSplitThreads;
-    constexpr int B_PIECES = BN * 4;
+    constexpr int A_RPS = (A_ROUNDS + 2) / 3;                         // halo rounds issued per step
+    constexpr int B_PIECES = 3 * BN * 4;                              // one filter row of weight records
     constexpr int B_ROUNDS = B_PIECES / kSplitThreads;
-    static_assert(MI * WM == TH && B_PIECES % kSplitThreads == 0 && A_ROUNDS <= 9, "tile shape");
+    constexpr int BBUF = (2 * HP * 4 + 2 * B_PIECES) * 16 <= 80 * 1024 ? 2 : 1;
+    static_assert(MI * WM == TH && B_PIECES % kSplitThreads == 0, "tile shape");
     constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
-    constexpr int LDS_PIPE = 2 * HP * 4 + 2 * BN * 4;                // uint4 units
+    constexpr int LDS_PIPE = 2 * HP * 4 + BBUF * B_PIECES;           // uint4 units
     constexpr int LDS_STAGE = (4 * 32 * STAGE_LD * 4 + 15) / 16;     // uint4 units (4 waves x 32 rows)
     constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
 
     __shared__ uint4 lds[LDS_UINT4];
     uint4 *As = lds;                          // [2][HP][4]
-    uint4 *Bs = lds + 2 * HP * 4;             // [2][BN][4]
+    uint4 *Bs = lds + 2 * HP * 4;             // [BBUF][3][BN][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,44 +154,45 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
 
     const int chunks = a.Cin >> 4;
-    const int steps = chunks * 9;
+    const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)chunks * 4;                     // uint4 per input pixel
     const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
 
     // ---- global -> register staging ---------------------------------------------------------
     uint4 b_reg[B_ROUNDS];
-    uint4 a_reg;
-    auto load_b = [&](int step) {          // weight tile of (tap, chunk): rows n0 .. n0+BN, 64 B each
-        const int chunk = step / 9, tap = step - chunk * 9;
-        const uint4 *src = a.w + ((size_t)(tap * chunks + chunk) * a.cout_pad + n0) * 4;
+    uint4 a_reg[A_RPS];
+    auto load_b = [&](int step) {          // weight records of (chunk, filter row): 3 taps x rows n0 .. n0+BN
+        const uint4 *src = a.w + ((size_t)step * 3 * a.cout_pad + n0) * 4;    // step = chunk*3 + row
 #pragma unroll
         for (int i = 0; i < B_ROUNDS; ++i) {
             const int e = tid + i * kSplitThreads;
-            const bool v = n0 + (e >> 2) < a.cout_pad;
-            b_reg[i] = v ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+            const int t = e / (BN * 4), rem = e - t * (BN * 4);
+            const bool v = n0 + (rem >> 2) < a.cout_pad;
+            b_reg[i] = v ? src[(size_t)t * a.cout_pad * 4 + rem] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     auto store_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < B_ROUNDS; ++i) {
             const int e = tid + i * kSplitThreads;
-            const int n = e >> 2, pc = e & 3;
-            Bs[(buf * BN + n) * 4 + (pc ^ ((n >> 2) & 3))] = b_reg[i];
+            const int t = e / (BN * 4), rem = e - t * (BN * 4);
+            const int n = rem >> 2, pc = rem & 3;
+            Bs[((buf * 3 + t) * BN + n) * 4 + (pc ^ ((n >> 2) & 3))] = b_reg[i];
         }
     };
-    auto load_a = [&](int chunk, int round) {       // one 16-byte piece of the (TH+2) x 34 halo of `chunk`
+    auto load_a = [&](int chunk, int round, uint4 &dst) {   // one 16-byte piece of the (TH+2) x 34 halo of `chunk`
         const int e = round * kSplitThreads + tid;
         const int pix = e >> 2, pc = e & 3;
         const int hy = pix / HW, hx = pix - hy * HW;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool v = e < A_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        a_reg = v ? xin[((size_t)iy * a.W + ix) * in_pix_stride + (size_t)chunk * 4 + pc] : make_uint4(0u, 0u, 0u, 0u);
+        const bool v = round < A_ROUNDS && e < A_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        dst = v ? xin[((size_t)iy * a.W + ix) * in_pix_stride + (size_t)chunk * 4 + pc] : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto store_a = [&](int buf, int round) {
+    auto store_a = [&](int buf, int round, const uint4 &src) {
         const int e = round * kSplitThreads + tid;
-        if (e < A_PIECES) {
+        if (round < A_ROUNDS && e < A_PIECES) {
             const int pix = e >> 2, pc = e & 3;
-            As[(buf * HP + pix) * 4 + (pc ^ ((pix >> 2) & 3))] = a_reg;
+            As[(buf * HP + pix) * 4 + (pc ^ ((pix >> 2) & 3))] = src;
         }
     };
 
@@ -197,7 +204,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // B fragment addresses are tap-invariant
+    // B fragment addresses are step-invariant (relative to the tap's tile)
     int b_off[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -208,50 +215,59 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     // ---- prologue: halo of chunk 0, weights of step 0 -------------------------------------------
 #pragma unroll 1
     for (int r = 0; r < A_ROUNDS; ++r) {
-        load_a(0, r);
-        store_a(0, r);
+        load_a(0, r, a_reg[0]);
+        store_a(0, r, a_reg[0]);
     }
     load_b(0);
     store_b(0);
     __syncthreads();
 
-    int abuf = 0, bbuf = 0, tap = 0, chunk = 0;
+    int abuf = 0, bbuf = 0, row = 0, chunk = 0;
 #pragma unroll 1
     for (int step = 0; step < steps; ++step) {
         const bool more_b = step + 1 < steps;
-        const bool more_a = tap < A_ROUNDS && chunk + 1 < chunks;
+        const bool more_a = chunk + 1 < chunks;
         if (more_b) load_b(step + 1);
-        if (more_a) load_a(chunk + 1, tap);
+        if (more_a) {
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) load_a(chunk + 1, row * A_RPS + q, a_reg[q]);
+        }
 
-        const int r = tap / 3, s = tap - 3 * r;
-        uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int pix = (wm * MI + i + r) * HW + lm + s;
-            const int idx = (abuf * HP + pix) * 4 + ((2 * kh) ^ ((pix >> 2) & 3));
-            ahi[i] = As[idx];
-            alo[i] = As[idx ^ 1];
-        }
+        for (int s = 0; s < 3; ++s) {                    // the 3 taps of filter row `row`
+            uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bhi[j] = Bs[bbuf * BN * 4 + b_off[j]];
-            blo[j] = Bs[bbuf * BN * 4 + (b_off[j] ^ 1)];
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                const int pix = (wm * MI + i + row) * HW + lm + s;
+                const int idx = (abuf * HP + pix) * 4 + ((2 * kh) ^ ((pix >> 2) & 3));
+                ahi[i] = As[idx];
+                alo[i] = As[idx ^ 1];
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                acc[i][j] = Half<F16>::mfma(alo[i], bhi[j], acc[i][j]);
-                acc[i][j] = Half<F16>::mfma(ahi[i], blo[j], acc[i][j]);
-                acc[i][j] = Half<F16>::mfma(ahi[i], bhi[j], acc[i][j]);
+                bhi[j] = Bs[(bbuf * 3 + s) * BN * 4 + b_off[j]];
+                blo[j] = Bs[(bbuf * 3 + s) * BN * 4 + (b_off[j] ^ 1)];
             }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = Half<F16>::mfma(alo[i], bhi[j], acc[i][j]);
+                    acc[i][j] = Half<F16>::mfma(ahi[i], blo[j], acc[i][j]);
+                    acc[i][j] = Half<F16>::mfma(ahi[i], bhi[j], acc[i][j]);
+                }
+        }
 
-        if (more_b) store_b(bbuf ^ 1);
-        if (more_a) store_a(abuf ^ 1, tap);
+        if (BBUF == 1) __syncthreads();                  // every wave is done reading the single weight buffer
+        if (more_b) store_b(BBUF == 2 ? (bbuf ^ 1) : 0);
+        if (more_a) {
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) store_a(abuf ^ 1, row * A_RPS + q, a_reg[q]);
+        }
         __syncthreads();
-        bbuf ^= 1;
-        if (++tap == 9) {
-            tap = 0;
+        if (BBUF == 2) bbuf ^= 1;
+        if (++row == 3) {
+            row = 0;
             ++chunk;
             abuf ^= 1;
         }
@@ -565,7 +581,7 @@ int split_weight_shift(const float *hwio, size_t count, bool f16)
 
 // HWIO (3,3,Cin,Cout) float32 (already multiplied by `scale[n]` if given) -> split records
 void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
-                             int shift, unsigned short *dst /* [9][Cin/16][cout_pad][32] */)
+                             int shift, unsigned short *dst /* [Cin/16][9][cout_pad][32] */)
 {
     const int chunks = Cin / 16;
     const float mul = ldexpf(1.0f, shift);
@@ -587,7 +603,7 @@ void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int
                     lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
                 }
                 const int chunk = c >> 4, g = (c >> 3) & 1, k = c & 7;
-                unsigned short *rec = dst + (((size_t)t * chunks + chunk) * cout_pad + n) * 32;
+                unsigned short *rec = dst + (((size_t)chunk * 9 + t) * cout_pad + n) * 32;
                 rec[(g * 2 + 0) * 8 + k] = hi;
                 rec[(g * 2 + 1) * 8 + k] = lo;
             }

@@ -275,6 +275,14 @@ static void plan_arena(rpn_model *m)
         if (op.in >= 0) m->tensors[op.in].last_use = i;
         if (op.residual >= 0) m->tensors[op.residual].last_use = i;
     }
+    // a split conv fused with its max-pool writes the POOL's output while it still reads its own input:
+    // the pooled tensor becomes live one op earlier
+    if (!m->keep_all)
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            const Op &op = m->ops[i], &nx = m->ops[i + 1];
+            if (op.kind == OP_CONV && op.split && !op.out_f32 && nx.kind == OP_POOL && nx.split && nx.in == op.out)
+                m->tensors[nx.out].def = (int)i;
+        }
     size_t top = 0;
     std::vector<int> placed;
     for (int ti = 0; ti < (int)m->tensors.size(); ++ti) {
