@@ -28,6 +28,7 @@
 #include "conv_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace rpn {
@@ -113,7 +114,7 @@ struct SplitConvArgs {
 // wave between barriers, and the LDS fragment reads of tap s+1 overlap the MFMAs of tap s.
 // BBUF: weight-tile buffers in LDS (2 = double buffered, one barrier per step; 1 = single buffered with a
 // second barrier, used where two buffers would not leave room for two workgroups per CU).
-template <int TH, int WN, bool F16, bool POOL>
+template <int TH, int WN, int BBUF, bool F16, bool POOL>
 __global__ void __launch_bounds__(kSplitThreads, 2)
 conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -127,7 +128,6 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     constexpr int A_RPS = (A_ROUNDS + 2) / 3;                         // halo rounds issued per step
     constexpr int B_PIECES = 3 * BN * 4;                              // one filter row of weight records
     constexpr int B_ROUNDS = B_PIECES / kSplitThreads;
-    constexpr int BBUF = (2 * HP * 4 + 2 * B_PIECES) * 16 <= 80 * 1024 ? 2 : 1;
     static_assert(MI * WM == TH && B_PIECES % kSplitThreads == 0, "tile shape");
     constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
     constexpr int LDS_PIPE = 2 * HP * 4 + BBUF * B_PIECES;           // uint4 units
@@ -192,7 +192,8 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         const int e = round * kSplitThreads + tid;
         if (round < A_ROUNDS && e < A_PIECES) {
             const int pix = e >> 2, pc = e & 3;
-            As[(buf * HP + pix) * 4 + (pc ^ ((pix >> 2) & 3))] = src;
+            const int hx = pix % HW;                                  // swizzle by halo COLUMN only, so that
+            As[(buf * HP + pix) * 4 + (pc ^ ((hx >> 2) & 3))] = src;    // fragment addresses are linear in the row
         }
     };
 
@@ -204,7 +205,10 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // B fragment addresses are step-invariant (relative to the tap's tile)
+    // fragment addresses: A depends on the lane and the tap column s only (column swizzle), B on the lane only
+    int a_off[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) a_off[s3] = (lm + s3) * 4 + ((2 * kh) ^ (((lm + s3) >> 2) & 3));
     int b_off[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -233,15 +237,14 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
             for (int q = 0; q < A_RPS; ++q) load_a(chunk + 1, row * A_RPS + q, a_reg[q]);
         }
 
+        const uint4 *arow = As + (abuf * HP + (wm * MI + row) * HW) * 4;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {                    // the 3 taps of filter row `row`
             uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int pix = (wm * MI + i + row) * HW + lm + s;
-                const int idx = (abuf * HP + pix) * 4 + ((2 * kh) ^ ((pix >> 2) & 3));
-                ahi[i] = As[idx];
-                alo[i] = As[idx ^ 1];
+            for (int i = 0; i < MI; ++i) {                   // a_off[s] is lane-constant; i * HW * 4 is an immediate
+                ahi[i] = arow[i * HW * 4 + a_off[s]];
+                alo[i] = arow[i * HW * 4 + (a_off[s] ^ 1)];
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -648,7 +651,7 @@ hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool 
     return hipGetLastError();
 }
 
-template <int TH, int WN, bool F16, bool POOL>
+template <int TH, int WN, int BBUF, bool F16, bool POOL>
 static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
 {
     constexpr int BN = WN * 64;
@@ -656,9 +659,17 @@ static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
     const int n_tiles = (a.Cout + BN - 1) / BN;
     const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, F16, POOL>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0, s,
-                       a, tiles_x, tiles_y, n_tiles);
+    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, BBUF, F16, POOL>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0,
+                       s, a, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
+}
+
+// experiment knobs (speed only, never results): RPN_SPLIT_TILE = 82 | 81 | 42 | 41 forces a tile shape,
+// RPN_SPLIT_BBUF = 1 | 2 the number of weight buffers
+static int env_int(const char *name)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
 }
 
 template <bool F16, bool POOL>
@@ -666,13 +677,30 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
 {
     // tile choice: 64-wide N tiles for Cout <= 64; shorter / narrower tiles when the grid would not put
     // two workgroups on each of the 256 CUs
+    static const int force_tile = env_int("RPN_SPLIT_TILE"), force_bbuf = env_int("RPN_SPLIT_BBUF");
     const long long mt8 = (long long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
     const long long mt4 = (long long)((a.W + 31) / 32) * ((a.H + 3) / 4) * a.B;
     const int nt128 = (a.Cout + 127) / 128;
-    if (a.Cout <= 64) return launch_split_variant<8, 1, F16, POOL>(a, s);
-    if (mt8 * nt128 >= 512) return launch_split_variant<8, 2, F16, POOL>(a, s);
-    if (mt4 * nt128 >= 512 || POOL) return launch_split_variant<4, 2, F16, POOL>(a, s);
-    if constexpr (!POOL) return launch_split_variant<4, 1, F16, false>(a, s);
+    int tile;
+    if (a.Cout <= 64) tile = 81;
+    else if (mt8 * nt128 >= 512) tile = 82;
+    else if (mt4 * nt128 >= 512 || POOL) tile = 42;
+    else tile = 41;
+    if (force_tile && a.Cout > 64 && !(POOL && force_tile == 41)) tile = force_tile;
+    // default buffers: two wherever LDS still admits two workgroups per CU (<= 80 KB)
+    int bbuf = (tile == 82) ? 1 : 2;
+    if (force_bbuf) bbuf = force_bbuf;
+    if (tile == 82 && bbuf == 2) bbuf = 1;                   // 92 KB: one workgroup per CU, not offered
+    switch (tile * 10 + bbuf) {
+        case 821: return launch_split_variant<8, 2, 1, F16, POOL>(a, s);
+        case 811: return launch_split_variant<8, 1, 1, F16, POOL>(a, s);
+        case 812: return launch_split_variant<8, 1, 2, F16, POOL>(a, s);
+        case 421: return launch_split_variant<4, 2, 1, F16, POOL>(a, s);
+        case 422: return launch_split_variant<4, 2, 2, F16, POOL>(a, s);
+        case 411: if constexpr (!POOL) return launch_split_variant<4, 1, 1, F16, false>(a, s); else break;
+        case 412: if constexpr (!POOL) return launch_split_variant<4, 1, 2, F16, false>(a, s); else break;
+        default: break;
+    }
     return hipErrorInvalidValue;
 }
 
