@@ -1,0 +1,34 @@
+"""Time the NMS kernel with RPN_NMS_STOP set by the caller (outputs are garbage when it is set)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import cases
+from oracle import bbox_oracle as bo
+from tf_rpn_amd import _lib as L
+VAR = np.float32([0.1, 0.1, 0.2, 0.2])
+anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
+A = len(anchors)
+for B, kind in ((8, "perm"), (8, "model-like"), (64, "perm")):
+    rng = np.random.RandomState(2)
+    deltas = rng.standard_normal((B, A, 4)).astype(np.float32)
+    if kind == "perm":
+        scores = cases.permutation_scores(np.random.RandomState(3), B, A)
+    else:   # smooth score field: neighbours have similar scores -> deep walks (like a conv head's output)
+        f = rng.standard_normal((B, 31, 31, 9)).astype(np.float32)
+        for _ in range(3):
+            f = (f + np.roll(f, 1, 1) + np.roll(f, 1, 2) + np.roll(f, -1, 1) + np.roll(f, -1, 2)) / 5
+        scores = (1 / (1 + np.exp(-8 * f))).reshape(B, A).astype(np.float32)
+    d, s, a = torch.from_numpy(deltas).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(anchors).cuda()
+    ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device="cuda")
+    oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    keep, vptr = L.host_floats(VAR)
+    def run():
+        L.check(L.lib().rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, 0.7, float("-inf"), 1, L.ptr(ob),
+                                       L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    print("stop=%s B=%d %s: %.1f us" % (os.environ.get("RPN_NMS_STOP", "0"), B, kind, e0.elapsed_time(e1) / 20 * 1e3), flush=True)

@@ -191,12 +191,42 @@ def test_nms_thresholds_sizes_and_limits():
     _check_nms(b4, s3, max_output_size_per_class=7, max_total_size=7, iou_threshold=0.0)
     _check_nms(b4, s3, max_output_size_per_class=7, max_total_size=7, iou_threshold=-1.0)          # IoU 0 > thr: only the top box
     _check_nms(b4, s3, max_output_size_per_class=0, max_total_size=5)
-    # N = 1, N = 2 and the largest N the single-workgroup sort takes
+    # N = 1, N = 2, and N beyond one band of the radix select (4096 sorted candidates per band)
     _check_nms(b4[:, :1], s3[:, :1], max_output_size_per_class=3, max_total_size=3)
     _check_nms(b4[:, :2], s3[:, :2], max_output_size_per_class=3, max_total_size=3)
     big = cases.clustered_boxes(rng, 1, 16384, n_clusters=200)
     _check_nms(big[:, :, None, :], cases.permutation_scores(rng, 1, 16384)[:, :, None],
                max_output_size_per_class=300, max_total_size=300)
+
+
+def test_nms_walks_several_bands():
+    """Selections that need more candidates than one 4096-key band: tight clusters (deep walk), huge output
+    sizes, and all-equal scores (the radix select must descend into the index bits of the key)."""
+    rng = np.random.RandomState(15)
+    boxes = cases.clustered_boxes(rng, 2, 20000, n_clusters=60, jitter=0.002)
+    scores = cases.permutation_scores(rng, 2, 20000)
+    got = _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                     iou_threshold=0.4)
+    assert (got[3] < 300).all()                                    # every band was consumed
+    spread = cases.random_boxes(rng, (1, 12000), smin=0.01, smax=0.03)
+    _check_nms(spread[:, :, None, :], cases.permutation_scores(rng, 1, 12000)[:, :, None],
+               max_output_size_per_class=2000, max_total_size=2000, iou_threshold=0.5)
+    const = np.full((1, 9000, 1), 0.25, np.float32)
+    _check_nms(spread[:, :9000, None, :], const, max_output_size_per_class=1500, max_total_size=1500)
+
+
+def test_nms_c5_anchor_count():
+    """BASELINE config C5: 64x64 feature map x 15 anchors = 61 440 candidates per image."""
+    hp = bo.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64, anchor_ratios=[1., 2., .5, 3., 1 / 3.])
+    anchors = bo.generate_anchors(hp)
+    A = len(anchors)
+    assert A == 61440
+    deltas = np.random.RandomState(2).standard_normal((2, A, 4)).astype(np.float32)
+    scores = cases.permutation_scores(np.random.RandomState(3), 2, A)
+    fb, fs, fi, fv = bbox_utils.decode_and_nms(anchors, deltas, scores, VAR, 300, iou_threshold=0.7)
+    gpu_boxes = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)
+    rb, rs, _rc, rv, ri = co.combined_nms(gpu_boxes[:, :, None, :], scores[:, :, None], 300, 300, iou_threshold=0.7)
+    assert np.array_equal(fv, rv) and np.array_equal(fi, ri) and np.array_equal(fb, rb)
 
 
 def test_nms_empty_inputs():

@@ -1,40 +1,45 @@
 // nms_kernels.hip -- per-image greedy NMS (tf.image.combined_non_max_suppression semantics,
-// utils/bbox_utils.py:48-70) as wavefront-level HIP for gfx950.  No MFMA: the work is
-// compares, one IEEE divide per pair, LDS traffic and cross-lane ballots.
+// utils/bbox_utils.py:48-70) as wavefront-level HIP for gfx950.  No MFMA: the work is compares, one IEEE
+// divide per pair, LDS traffic and cross-lane ballots / readlanes.
 //
-// One 1024-thread workgroup per (image, class):
-//   1. keys   : 64-bit (orderable(score) << 32 | ~index) for every candidate with
-//               score > score_threshold, 0 otherwise, staged in LDS;
-//   2. sort   : bitonic sort of the LDS keys, descending  => score desc, lower index first;
-//   3. greedy : the sorted candidates are consumed in chunks of 256.  For a chunk,
-//               (A) all 16 waves test chunk candidates against the already selected boxes
-//                   (selected boxes are broadcast LDS reads),
-//               (B) all waves build the 256x256 "j is suppressed by i" bit matrix of the chunk,
-//               (C) wave 0 walks the chunk in order with wave-uniform 64-bit live masks
-//                   (__ballot / readfirstlane / ffs), appending to the selected list.
-//               The loop stops as soon as max_output_size_per_class boxes are selected, so a
-//               typical image touches 2-4 chunks, not all A candidates.
-//   4. output : selected boxes gathered (and clipped) straight into the padded outputs.
-// Per image the HBM traffic is 4*A (scores) + 16 B per visited candidate + the outputs; the
-// kernel is latency-bound, the serial part is step (C): ~1 LDS round trip
-// per selected box.
+// One 1024-thread workgroup per (image, class).  Candidates are ordered by the 64-bit key
+// (orderable(score) << 32 | ~index): descending key == descending score, ties lower index first.
+//   1. band   : instead of sorting all N keys, a radix select (11-bit digits, LDS histogram, keys recomputed
+//               from the L2-resident scores on every pass) finds the threshold that isolates the next
+//               <= 4096 best candidates; only that band is compacted into LDS and bitonic-sorted.  If the
+//               band is exhausted before max_output_size boxes are selected (rare), the next band is taken.
+//               Any N works (no LDS-capacity limit on the number of candidates).
+//   2. greedy : the sorted band is consumed in chunks of 256.  For a chunk,
+//               (A) all 16 waves test chunk candidates against the already selected boxes (broadcast reads),
+//               (B) all waves build the 256x256 "j is suppressed by i" bit matrix for live (i, j) only,
+//               (C) wave 0 walks the chunk in order: lanes 0-3 hold the four 64-bit live masks, one LDS round
+//                   trip (the selected row of the bit matrix) per selected box; the selected boxes are copied
+//                   to the selected list afterwards, in parallel.
+//               The loop stops as soon as max_output_size_per_class boxes are selected.
+//   3. output : selected boxes gathered (and clipped) straight into the padded outputs.
+// Per image the HBM traffic is 4*A (scores) + 16 B per visited candidate + the outputs; the kernel is
+// latency-bound: the serial part is step (C).
 //
 // DECODE variant: candidate boxes are decoded on the fly from (anchor, delta*variance)
 // (utils/bbox_utils.py:72-96, predictor.py:55), so decoded boxes never exist in HBM.
 //
-// C > 1: each (image, class) block writes its selection to a staging area; a second
-// kernel merges the classes (score desc, ties class asc then selection order).
+// C > 1: each (image, class) block writes its selection to a staging area; a second kernel merges the
+// classes (score desc, ties class asc then selection order).
 // Compiled with -ffp-contract=off.
 #include "bbox_core.h"
 #include "rpn_common.h"
 
+#include <cstdlib>
+
 namespace rpn {
 
 constexpr int kNmsThreads = 1024;
-constexpr int kNmsMaxSort = 16384;     // candidates per (image, class) sortable in LDS
+constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
+constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
+constexpr int kDigitBits = 11;
+constexpr int kBins = 1 << kDigitBits;
 constexpr int kChunk = 256;
 constexpr int kChunkWords = kChunk / 64;
-constexpr int kKeysPerThread = kNmsMaxSort / kNmsThreads;
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct NmsArgs {
@@ -44,7 +49,6 @@ struct NmsArgs {
     float var[4];
     int var_enabled;
     int B, N, q, C;
-    int n_sort;              // power of two >= N
     int max_sel;             // min(max_per_class, [C==1: max_total])
     int max_total;
     float iou_thr, score_thr;
@@ -55,6 +59,7 @@ struct NmsArgs {
     // per-class staging (C > 1): sel index (B,C,max_sel) and count (B,C)
     int *stage_idx;
     int *stage_cnt;
+    int stop_after;          // timing experiments only (RPN_NMS_STOP): 2 = stop after the first band sort; 0 = run all
 };
 
 // Descending bitonic sort of n (power of two) 64-bit keys in LDS by the whole workgroup.
@@ -97,116 +102,208 @@ __device__ __forceinline__ Box fetch_box(const NmsArgs &p, int b, int idx, int q
     }
 }
 
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+// 64-bit candidate key of box i (0 = not a candidate: score <= threshold or NaN)
+__device__ __forceinline__ unsigned long long make_key(float s, float thr, int i)
 {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
+    if (!(s > thr)) return 0ull;
+    return ((unsigned long long)orderable(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
 }
 
-// LDS carve-up (dynamic, 16-byte aligned):
-//   [0, 8*n_sort)                 keys; after the sort the first 4*n_sort bytes hold `order`
-//   sel_c   : max_sel * 5 floats  canonical selected boxes (SoA)
-//   sel_idx : max_sel ints
-//   cbox    : kChunk * 5 floats   canonical chunk boxes (SoA)
-//   mask    : kChunk * kChunkWords u64
-//   dead    : kChunk ints
-//   ctl     : 4 ints  {ncand, nsel, pos, _}
+// LDS carve-up (dynamic, 16-byte aligned)
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 struct LdsLayout {
-    size_t keys, sel_c, sel_idx, cbox, mask, dead, ctl, total;
+    size_t band, hist, sel_c, sel_idx, cbox, mask, dead, picked, ctl, total;
 };
 
-__host__ __device__ inline LdsLayout lds_layout(int n_sort, int max_sel)
+__host__ __device__ inline LdsLayout lds_layout(int max_sel)
 {
     LdsLayout l;
     size_t o = 0;
-    l.keys = o;    o = align16(o + (size_t)8 * n_sort);
-    l.sel_c = o;   o = align16(o + (size_t)20 * max_sel);
+    l.band = o;    o = align16(o + (size_t)8 * kBandCap);               // u64 keys, later u32 order in place
+    l.hist = o;    o = align16(o + (size_t)4 * kBins);
+    l.sel_c = o;   o = align16(o + (size_t)20 * max_sel);               // canonical selected boxes [5][max_sel]
     l.sel_idx = o; o = align16(o + (size_t)4 * max_sel);
-    l.cbox = o;    o = align16(o + (size_t)20 * kChunk);
-    l.mask = o;    o = align16(o + (size_t)8 * kChunk * kChunkWords);
-    l.dead = o;    o = align16(o + (size_t)4 * kChunk);
-    l.ctl = o;     o = align16(o + 16);
+    l.cbox = o;    o = align16(o + (size_t)20 * kChunk);                // canonical chunk boxes [5][kChunk]
+    l.mask = o;    o = align16(o + (size_t)8 * kChunk * kChunkWords);   // [kChunk][4] u64
+    l.dead = o;    o = align16(o + (size_t)8 * kChunkWords);            // 4 u64 words
+    l.picked = o;  o = align16(o + (size_t)4 * kChunk);
+    l.ctl = o;     o = align16(o + 64);
     l.total = o;
     return l;
 }
+
+// ctl words
+enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_ABOVE = 2, CTL_DIGIT = 3, CTL_BINCOUNT = 4, CTL_POS = 5, CTL_NCAND = 6 };
 
 template <bool DECODE>
 __global__ void __launch_bounds__(kNmsThreads)
 nms_kernel(NmsArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(p.n_sort, p.max_sel);
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + L.keys);
-    unsigned *order = reinterpret_cast<unsigned *>(smem + L.keys);
-    float *sel_c = reinterpret_cast<float *>(smem + L.sel_c);          // [5][max_sel]
+    const LdsLayout L = lds_layout(p.max_sel);
+    unsigned long long *band = reinterpret_cast<unsigned long long *>(smem + L.band);
+    unsigned *order = reinterpret_cast<unsigned *>(smem + L.band);
+    unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
+    float *sel_c = reinterpret_cast<float *>(smem + L.sel_c);
     int *sel_idx = reinterpret_cast<int *>(smem + L.sel_idx);
-    float *cbox = reinterpret_cast<float *>(smem + L.cbox);            // [5][kChunk]
-    unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem + L.mask);   // [kChunk][4]
-    int *dead = reinterpret_cast<int *>(smem + L.dead);
+    float *cbox = reinterpret_cast<float *>(smem + L.cbox);
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem + L.mask);
+    unsigned long long *deadw = reinterpret_cast<unsigned long long *>(smem + L.dead);
+    int *picked = reinterpret_cast<int *>(smem + L.picked);
     int *ctl = reinterpret_cast<int *>(smem + L.ctl);
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int b = blockIdx.x / p.C;
     const int c = blockIdx.x - b * p.C;
     const int qc = (p.q == 1) ? 0 : c;
-    const int N = p.N, n_sort = p.n_sort, max_sel = p.max_sel;
+    const int N = p.N, max_sel = p.max_sel;
+    const float *__restrict__ sc = p.scores + (size_t)b * N * p.C + c;
+    const int C = p.C;
 
-    if (tid < 4) ctl[tid] = 0;
+    if (tid < 16) ctl[tid] = 0;
     __syncthreads();
 
-    // ---- 1. keys -------------------------------------------------------------------
-    {
-        int my_cand = 0;
-        for (int i = tid; i < n_sort; i += kNmsThreads) {
-            unsigned long long key = 0ull;
-            if (i < N) {
-                const float s = p.scores[((size_t)b * N + i) * p.C + c];
-                if (s > p.score_thr) {          // strict; NaN never qualifies
-                    key = ((unsigned long long)orderable(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-                    ++my_cand;
+    unsigned long long hi_bound = ~0ull;       // keys of the current band are < hi_bound (exclusive)
+    bool first_band = true;
+
+    while (true) {
+        // ================= 1. pick the next band: keys in [thr, hi_bound) ==========================
+        // radix select on 11-bit digits, most significant first; `prefix` holds the digits fixed so far
+        unsigned long long thr = 1ull;          // accept everything below hi_bound unless narrowed
+        int above = 0;                          // keys strictly above the current prefix's bin range
+        {
+            unsigned long long prefix = 0ull;
+            int shift = 64;                     // bits [shift, 64) are fixed by `prefix`
+            bool narrowed = true;
+            while (narrowed && shift > 0) {
+                const int bits = shift >= kDigitBits ? kDigitBits : shift;
+                const int dshift = shift - bits;
+                for (int i = tid; i < kBins; i += kNmsThreads) hist[i] = 0u;
+                __syncthreads();
+                for (int i = tid; i < N; i += kNmsThreads) {
+                    const unsigned long long key = make_key(sc[(size_t)i * C], p.score_thr, i);
+                    if (key != 0ull && key < hi_bound && (shift == 64 || (key >> shift) == (prefix >> shift)))
+                        atomicAdd(&hist[(unsigned)(key >> dshift) & ((1u << bits) - 1u)], 1u);
                 }
+                __syncthreads();
+                // wave 0: suffix sums over the (1 << bits) bins, top digit first; find the digit where the
+                // running count reaches the target
+                if (tid < 64) {
+                    const int nb = 1 << bits;
+                    const int per = (nb + 63) / 64;                       // bins per lane, lane 0 = top bins
+                    const int top = nb - 1 - lane * per;                  // this lane's highest bin
+                    unsigned mine = 0u;
+                    for (int k = 0; k < per; ++k)
+                        if (top - k >= 0) mine += hist[top - k];
+                    unsigned incl = mine;                                 // inclusive scan over lanes (top first)
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned v = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += v;
+                    }
+                    const unsigned total = __shfl(incl, 63, 64);
+                    const int want = kBandTarget - above;                 // still needed from this prefix
+                    const unsigned excl = incl - mine;
+                    // the lane whose range contains the crossing (or the last non-empty lane if total < want)
+                    const bool cross = (int)excl < want && (int)incl >= want;
+                    const unsigned long long bal = __ballot(cross);
+                    if (total == 0u) {
+                        if (lane == 0) { ctl[CTL_DIGIT] = -1; ctl[CTL_BINCOUNT] = 0; }
+                    } else if (bal == 0ull) {                             // fewer than `want` keys in total: take all
+                        if (lane == 0) { ctl[CTL_DIGIT] = -2; ctl[CTL_BINCOUNT] = (int)total; }
+                    } else if (cross) {
+                        unsigned run = excl;
+                        int d = top;
+                        for (int k = 0; k < per; ++k) {
+                            d = top - k;
+                            run += hist[d];
+                            if ((int)run >= want) break;
+                        }
+                        ctl[CTL_DIGIT] = d;
+                        ctl[CTL_BINCOUNT] = (int)hist[d];
+                        ctl[CTL_ABOVE] = above + (int)(run - hist[d]);    // keys above bin d (all levels)
+                    }
+                }
+                __syncthreads();
+                const int digit = ctl[CTL_DIGIT];
+                const int bin_count = ctl[CTL_BINCOUNT];
+                if (first_band && shift == 64) {                          // level 0 sees every candidate once
+                    // ncand is only needed to know whether anything is left after a band
+                }
+                if (digit == -1) {                   // no candidate below hi_bound at all
+                    thr = 0ull;
+                    narrowed = false;
+                } else if (digit == -2) {            // everything (within prefix) fits the target: take all of it
+                    thr = (shift == 64) ? 1ull : (prefix & ~((1ull << shift) - 1ull));
+                    if (thr == 0ull) thr = 1ull;
+                    above += bin_count;
+                    narrowed = false;
+                } else {
+                    above = ctl[CTL_ABOVE];
+                    prefix = (shift == 64 ? 0ull : (prefix & ~((1ull << shift) - 1ull))) |
+                             ((unsigned long long)(unsigned)digit << dshift);
+                    shift = dshift;
+                    thr = prefix;                    // accept the whole bin `digit` ...
+                    if (above + bin_count <= kBandCap || shift == 0) {
+                        above += bin_count;
+                        narrowed = false;            // ... if the band still fits; otherwise refine inside it
+                    }
+                }
+                __syncthreads();
             }
-            keys[i] = key;
+            if (thr == 0ull && above == 0) break;    // nothing left
+            if (thr == 0ull) thr = 1ull;
         }
-        // wave-level reduction, one LDS atomic per wave
-        for (int off = 32; off > 0; off >>= 1) my_cand += __shfl_down(my_cand, off, 64);
-        if ((tid & 63) == 0 && my_cand) atomicAdd(&ctl[0], my_cand);
-    }
-    __syncthreads();
-    const int ncand = ctl[0];
+        first_band = false;
 
-    // ---- 2. sort, then compact the keys to 32-bit indices in place --------------------
-    if (ncand > 0) bitonic_sort_desc(keys, n_sort);
-    {
-        unsigned idx_reg[kKeysPerThread];
-#pragma unroll
-        for (int j = 0; j < kKeysPerThread; ++j) {
-            const int i = tid + j * kNmsThreads;
-            idx_reg[j] = (i < n_sort) ? (0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull)) : 0u;
+        // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
+        if (tid == 0) ctl[CTL_BANDN] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += kNmsThreads) {
+            const unsigned long long key = make_key(sc[(size_t)i * C], p.score_thr, i);
+            if (key >= thr && key < hi_bound && key != 0ull) {
+                const int slot = atomicAdd(&ctl[CTL_BANDN], 1);
+                if (slot < kBandCap) band[slot] = key;
+            }
         }
         __syncthreads();
+        int band_n = ctl[CTL_BANDN];
+        if (band_n > kBandCap) band_n = kBandCap;    // cannot happen: the select guarantees <= kBandCap
+        if (band_n == 0) break;
+        int n_sort = 2;
+        while (n_sort < band_n) n_sort <<= 1;
+        for (int i = band_n + tid; i < n_sort; i += kNmsThreads) band[i] = 0ull;
+        __syncthreads();
+        bitonic_sort_desc(band, n_sort);
+        if (p.stop_after == 2) return;
+        {   // keys -> 32-bit box indices, in place (read all, barrier, write)
+            unsigned idx_reg[kBandCap / kNmsThreads];
 #pragma unroll
-        for (int j = 0; j < kKeysPerThread; ++j) {
-            const int i = tid + j * kNmsThreads;
-            if (i < n_sort) order[i] = idx_reg[j];
+            for (int j = 0; j < kBandCap / kNmsThreads; ++j) {
+                const int i = tid + j * kNmsThreads;
+                idx_reg[j] = (i < band_n) ? (0xFFFFFFFFu - (unsigned)(band[i] & 0xFFFFFFFFull)) : 0u;
+            }
+            const unsigned long long lowest = band[band_n - 1];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kBandCap / kNmsThreads; ++j) {
+                const int i = tid + j * kNmsThreads;
+                if (i < band_n) order[i] = idx_reg[j];
+            }
+            hi_bound = lowest;                       // the next band continues strictly below this one
         }
-    }
-    __syncthreads();
+        if (tid == 0) ctl[CTL_POS] = 0;
+        __syncthreads();
 
-    // ---- 3. greedy selection over chunks of the sorted candidates -----------------------
-    while (true) {
-        const int nsel = ctl[1];
-        const int pos = ctl[2];
-        if (nsel >= max_sel || pos >= ncand) break;
-        const int T = min(kChunk, ncand - pos);
+        // ================= 2. greedy selection over chunks of the sorted band ===============================
+        while (true) {
+            const int nsel = ctl[CTL_NSEL];
+            const int pos = ctl[CTL_POS];
+            if (nsel >= max_sel || pos >= band_n) break;
+            const int T = min(kChunk, band_n - pos);
 
-        // chunk boxes -> canonical form in LDS
-        if (tid < kChunk) {
-            dead[tid] = (tid < T) ? 0 : 1;
-            if (tid < T) {
+            if (tid < kChunk && tid < T) {           // chunk boxes -> canonical form in LDS
                 const CBox cb = canonical(fetch_box<DECODE>(p, b, (int)order[pos + tid], qc));
                 cbox[0 * kChunk + tid] = cb.ymin;
                 cbox[1 * kChunk + tid] = cb.xmin;
@@ -214,83 +311,95 @@ nms_kernel(NmsArgs p)
                 cbox[3 * kChunk + tid] = cb.xmax;
                 cbox[4 * kChunk + tid] = cb.area;
             }
-        }
-        __syncthreads();
+            if (tid < kChunkWords) deadw[tid] = 0ull;
+            __syncthreads();
 
-        // (A) chunk candidate t vs selected boxes j = part, part+4, ...  (4 waves per part;
-        //     every lane of a wave reads the same selected box: LDS broadcast)
-        {
-            const int t = tid & (kChunk - 1);
-            const int part = tid >> 8;
-            if (t < T && nsel > 0) {
-                const CBox ci{cbox[0 * kChunk + t], cbox[1 * kChunk + t], cbox[2 * kChunk + t],
-                              cbox[3 * kChunk + t], cbox[4 * kChunk + t]};
-                bool hit = false;
-                for (int j = part; j < nsel; j += 4) {
-                    const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
-                                  sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
-                    hit |= nms_iou(ci, sj) > p.iou_thr;
+            // (A) chunk candidate t vs selected boxes j = part, part+4, ...  (4 waves per part; every lane of
+            //     a wave reads the same selected box: LDS broadcast); dead bits gathered with one ballot per wave
+            {
+                const int t = tid & (kChunk - 1);
+                const int part = tid >> 8;
+                bool hit = t >= T;                                      // slots past the band end count as dead
+                if (t < T && nsel > 0) {
+                    const CBox ci{cbox[0 * kChunk + t], cbox[1 * kChunk + t], cbox[2 * kChunk + t],
+                                  cbox[3 * kChunk + t], cbox[4 * kChunk + t]};
+                    for (int j = part; j < nsel; j += 4) {
+                        const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
+                                      sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
+                        hit |= nms_iou(ci, sj) > p.iou_thr;
+                    }
                 }
-                if (hit) dead[t] = 1;
+                const unsigned long long bal = __ballot(hit);
+                if (lane == 0 && bal) atomicOr(&deadw[(tid >> 6) & (kChunkWords - 1)], bal);
             }
-        }
-        __syncthreads();
+            __syncthreads();
 
-        // (B) intra-chunk suppression bits: mask[i][w] bit jj set iff candidate j = 64w+jj (j > i)
-        //     would be suppressed by candidate i.  Rows of dead candidates are never read.
-        {
-            const int i = tid >> 2;
-            const int w = tid & 3;
-            unsigned long long bits = 0ull;
-            if (i < T && !dead[i] && (w * 64 + 63) > i) {
-                const CBox si{cbox[0 * kChunk + i], cbox[1 * kChunk + i], cbox[2 * kChunk + i],
-                              cbox[3 * kChunk + i], cbox[4 * kChunk + i]};
-                const int j0 = w * 64;
-                for (int jj = 0; jj < 64; ++jj) {
-                    const int j = j0 + jj;
-                    if (j > i && j < T) {
+            // (B) intra-chunk suppression bits for live pairs only: mask[i][w] bit jj set iff live candidate
+            //     j = 64w+jj (j > i) would be suppressed by live candidate i
+            {
+                const int i = tid >> 2;
+                const int w = tid & 3;
+                unsigned long long bits = 0ull;
+                const bool i_dead = (deadw[i >> 6] >> (i & 63)) & 1ull;
+                if (!i_dead && (w * 64 + 63) > i) {
+                    const CBox si{cbox[0 * kChunk + i], cbox[1 * kChunk + i], cbox[2 * kChunk + i],
+                                  cbox[3 * kChunk + i], cbox[4 * kChunk + i]};
+                    unsigned long long todo = ~deadw[w];
+                    if ((i >> 6) == w) todo &= (~0ull << (i & 63)) << 1;       // only j > i
+                    while (todo) {
+                        const int jj = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const int j = w * 64 + jj;
                         const CBox cj{cbox[0 * kChunk + j], cbox[1 * kChunk + j], cbox[2 * kChunk + j],
                                       cbox[3 * kChunk + j], cbox[4 * kChunk + j]};
                         if (nms_iou(cj, si) > p.iou_thr) bits |= (1ull << jj);
                     }
                 }
+                mask[i * kChunkWords + w] = bits;
             }
-            if (i < kChunk) mask[i * kChunkWords + w] = bits;
-        }
-        __syncthreads();
+            __syncthreads();
 
-        // (C) serial walk by wave 0 with wave-uniform live masks
-        if (tid < 64) {
-            unsigned long long rem[kChunkWords];
-#pragma unroll
-            for (int w = 0; w < kChunkWords; ++w) rem[w] = __ballot(dead[w * 64 + tid] != 0);
-            int cur = nsel;
-#pragma unroll
-            for (int w = 0; w < kChunkWords; ++w) {
+            // (C) serial walk by wave 0: lane w < 4 owns live-mask word w; per selected box one LDS round trip
+            if (tid < 64) {
+                unsigned long long rem = (lane < kChunkWords) ? deadw[lane] : ~0ull;
+                int cur = nsel;
                 while (cur < max_sel) {
-                    const unsigned long long avail = ~rem[w];
-                    if (avail == 0ull) break;
-                    const int bit = __ffsll((long long)avail) - 1;
-                    const int i = w * 64 + bit;
-                    if (tid < 5) sel_c[tid * max_sel + cur] = cbox[tid * kChunk + i];
-                    if (tid == 5) sel_idx[cur] = (int)order[pos + i];
+                    const unsigned long long avail = ~rem;
+                    const int mine = avail ? (lane * 64 + __ffsll((long long)avail) - 1) : (1 << 30);
+                    int first = __builtin_amdgcn_readlane(mine, 0);
+                    first = min(first, __builtin_amdgcn_readlane(mine, 1));
+                    first = min(first, __builtin_amdgcn_readlane(mine, 2));
+                    first = min(first, __builtin_amdgcn_readlane(mine, 3));
+                    if (first >= T) break;
+                    if (lane == 0) picked[cur - nsel] = first;
                     ++cur;
-                    rem[w] |= (1ull << bit);
+                    if (lane < kChunkWords) {
+                        rem |= mask[first * kChunkWords + lane];
+                        if ((first >> 6) == lane) rem |= 1ull << (first & 63);
+                    }
+                }
+                // copy the picked boxes to the selected list (all 64 lanes)
+                const int npick = cur - nsel;
+                for (int t = lane; t < npick; t += 64) {
+                    const int i = picked[t];
 #pragma unroll
-                    for (int w2 = 0; w2 < kChunkWords; ++w2)
-                        if (w2 >= w) rem[w2] |= uniform64(mask[i * kChunkWords + w2]);
+                    for (int k = 0; k < 5; ++k) sel_c[k * max_sel + nsel + t] = cbox[k * kChunk + i];
+                    sel_idx[nsel + t] = (int)order[pos + i];
+                }
+                if (lane == 0) {
+                    ctl[CTL_NSEL] = cur;
+                    ctl[CTL_POS] = pos + T;
                 }
             }
-            if (tid == 0) {
-                ctl[1] = cur;
-                ctl[2] = pos + T;
-            }
+            __syncthreads();
         }
+        if (ctl[CTL_NSEL] >= max_sel) break;
         __syncthreads();
     }
+    __syncthreads();
 
-    // ---- 4. outputs ------------------------------------------------------------------
-    const int nsel = ctl[1];
+    // ================= 3. outputs =================================================================
+    const int nsel = ctl[CTL_NSEL];
     if (p.C == 1) {
         const int M = p.max_total;
         const int nvalid = min(nsel, M);
@@ -400,10 +509,12 @@ static size_t stage_bytes(int B, int C, int max_sel)
 template <bool DECODE>
 static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    const LdsLayout L = lds_layout(p.n_sort, p.max_sel);
+    static const int stop = getenv("RPN_NMS_STOP") ? atoi(getenv("RPN_NMS_STOP")) : 0;
+    p.stop_after = stop;
+    const LdsLayout L = lds_layout(p.max_sel);
     if (L.total > kLdsLimit)
-        return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (N=%d, max per class=%d) > %zu",
-                    L.total, p.N, p.max_sel, kLdsLimit);
+        return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,
+                    kLdsLimit);
     if (p.C > 1) {
         const size_t need = stage_bytes(p.B, p.C, p.max_sel);
         if (!d_workspace || workspace_bytes < need)
@@ -454,15 +565,11 @@ extern "C" int rpn_combined_nms(const float *d_boxes, const float *d_scores, int
     if (B == 0 || max_total == 0) return RPN_OK;
     RPN_REQUIRE(d_out_boxes && d_out_scores && d_out_valid, "rpn_combined_nms: null output pointer");
     RPN_REQUIRE(N == 0 || (d_boxes && d_scores), "rpn_combined_nms: null input pointer");
-    if (N > kNmsMaxSort)
-        return fail(RPN_ERR_UNSUPPORTED, "rpn_combined_nms: N=%d > %d candidates per image not supported yet", N,
-                    kNmsMaxSort);
     RPN_REQUIRE_DEVICE();
     NmsArgs p{};
     p.boxes = d_boxes;
     p.scores = d_scores;
     p.B = B; p.N = N; p.q = q; p.C = C;
-    p.n_sort = next_pow2(N);
     p.max_sel = (C == 1) ? (max_per_class < max_total ? max_per_class : max_total) : max_per_class;
     if (p.max_sel < 1) p.max_sel = 1;
     if (max_per_class == 0) p.max_sel = 1;
@@ -485,9 +592,6 @@ extern "C" int rpn_decode_nms(const float *d_anchors, const float *d_deltas, con
     if (B == 0 || max_total == 0) return RPN_OK;
     RPN_REQUIRE(d_out_boxes && d_out_scores && d_out_valid, "rpn_decode_nms: null output pointer");
     RPN_REQUIRE(A == 0 || (d_anchors && d_deltas && d_scores), "rpn_decode_nms: null input pointer");
-    if (A > kNmsMaxSort)
-        return fail(RPN_ERR_UNSUPPORTED, "rpn_decode_nms: A=%d > %d candidates per image not supported yet", A,
-                    kNmsMaxSort);
     RPN_REQUIRE_DEVICE();
     NmsArgs p{};
     p.boxes = d_deltas;
@@ -498,7 +602,6 @@ extern "C" int rpn_decode_nms(const float *d_anchors, const float *d_deltas, con
         p.var_enabled = 1;
     }
     p.B = B; p.N = A; p.q = 1; p.C = 1;
-    p.n_sort = next_pow2(A);
     p.max_sel = max_total;
     p.max_total = max_total;
     p.iou_thr = iou_threshold;
