@@ -13,8 +13,9 @@ echo "pytest exit $?" >> $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 echo "smoke exit $?" >> $OUT/smoke.log
 for P in f32 bf16x3 f16x3; do
-  timeout 600 python bench.py --steps 10 --warmup 2 --layers --precision $P --no-cpu-baseline > $OUT/bench_$P.json 2> $OUT/bench_layers_$P.txt
+  timeout 600 python bench.py --steps 20 --warmup 3 --layers --precision $P --no-cpu-baseline > $OUT/bench_$P.json 2> $OUT/bench_layers_$P.txt
   echo "bench exit $?" >> $OUT/bench_layers_$P.txt
 done
 timeout 300 python scripts/nms_probe.py > $OUT/nms_probe.txt 2>&1
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 grep -E "passed|failed|error" $OUT/pytest.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench_*.json; cat $OUT/nms_probe.txt

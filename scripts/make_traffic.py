@@ -1,0 +1,26 @@
+"""profiles/<tag>_traffic.json from a pmc_round directory: HBM bytes per launch per kernel family,
+FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide coalesced reads are tallied at 1/2),
+WRITE_SIZE as is; both are reported by rocprofv3 in KiB."""
+import csv, glob, json, os, sys, collections
+root, out = sys.argv[1], sys.argv[2]
+fam = lambda k: ("conv3x3_split" if "conv3x3_split_kernel" in k else "conv_igemm_f32" if "conv_igemm_f32" in k else
+                 "nms_kernel" if "nms_kernel" in k else "conv_cin3" if "conv_cin3" in k else None)
+acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_fetch": 0, "n_write": 0})
+for name in ("fetch", "write"):
+    for path in glob.glob(os.path.join(root, name, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            f = fam(row["Kernel_Name"])
+            if f and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                key = "fetch" if row["Counter_Name"] == "FETCH_SIZE" else "write"
+                acc[f][key + "_kib"] += float(row["Counter_Value"])
+                acc[f]["n_" + key] += 1
+res = {}
+for f, d in acc.items():
+    if d["n_fetch"] and d["n_write"]:
+        fetch = 2.0 * 1024 * d["fetch_kib"] / d["n_fetch"]
+        write = 1024 * d["write_kib"] / d["n_write"]
+        res[f] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+                  "launches_sampled": d["n_fetch"]}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1, B=8",
+           "kernels": res}, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
