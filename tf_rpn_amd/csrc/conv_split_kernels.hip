@@ -114,24 +114,25 @@ struct SplitConvArgs {
 // wave between barriers, and the LDS fragment reads of tap s+1 overlap the MFMAs of tap s.
 // BBUF: weight-tile buffers in LDS (2 = double buffered, one barrier per step; 1 = single buffered with a
 // second barrier, used where two buffers would not leave room for two workgroups per CU).
-template <int TH, int WN, int BBUF, bool F16, bool POOL>
-__global__ void __launch_bounds__(kSplitThreads, 2)
+template <int TH, int WN, int BBUF, int NW, bool F16, bool POOL>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
 conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    constexpr int WM = 4 / WN;               // waves along M
+    constexpr int NT = 64 * NW;              // threads per workgroup (NW = 4 or 8 waves)
+    constexpr int WM = NW / WN;              // waves along M
     constexpr int MI = TH / WM;              // 32-pixel rows per wave
     constexpr int NI = 2;                    // 32-channel blocks per wave
     constexpr int BN = WN * NI * 32;
     constexpr int HP = (TH + 2) * HW;        // halo pixels
     constexpr int A_PIECES = HP * 4;
-    constexpr int A_ROUNDS = (A_PIECES + kSplitThreads - 1) / kSplitThreads;
+    constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT;
     constexpr int A_RPS = (A_ROUNDS + 2) / 3;                         // halo rounds issued per step
     constexpr int B_PIECES = 3 * BN * 4;                              // one filter row of weight records
-    constexpr int B_ROUNDS = B_PIECES / kSplitThreads;
-    static_assert(MI * WM == TH && B_PIECES % kSplitThreads == 0, "tile shape");
+    constexpr int B_ROUNDS = B_PIECES / NT;
+    static_assert(MI * WM == TH && B_PIECES % NT == 0, "tile shape");
     constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
     constexpr int LDS_PIPE = 2 * HP * 4 + BBUF * B_PIECES;           // uint4 units
-    constexpr int LDS_STAGE = (4 * 32 * STAGE_LD * 4 + 15) / 16;     // uint4 units (4 waves x 32 rows)
+    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;    // uint4 units (NW waves x 32 rows)
     constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
 
     __shared__ uint4 lds[LDS_UINT4];
@@ -165,7 +166,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         const uint4 *src = a.w + ((size_t)step * 3 * a.cout_pad + n0) * 4;    // step = chunk*3 + row
 #pragma unroll
         for (int i = 0; i < B_ROUNDS; ++i) {
-            const int e = tid + i * kSplitThreads;
+            const int e = tid + i * NT;
             const int t = e / (BN * 4), rem = e - t * (BN * 4);
             const bool v = n0 + (rem >> 2) < a.cout_pad;
             b_reg[i] = v ? src[(size_t)t * a.cout_pad * 4 + rem] : make_uint4(0u, 0u, 0u, 0u);
@@ -174,14 +175,14 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     auto store_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < B_ROUNDS; ++i) {
-            const int e = tid + i * kSplitThreads;
+            const int e = tid + i * NT;
             const int t = e / (BN * 4), rem = e - t * (BN * 4);
             const int n = rem >> 2, pc = rem & 3;
             Bs[((buf * 3 + t) * BN + n) * 4 + (pc ^ ((n >> 2) & 3))] = b_reg[i];
         }
     };
     auto load_a = [&](int chunk, int round, uint4 &dst) {   // one 16-byte piece of the (TH+2) x 34 halo of `chunk`
-        const int e = round * kSplitThreads + tid;
+        const int e = round * NT + tid;
         const int pix = e >> 2, pc = e & 3;
         const int hy = pix / HW, hx = pix - hy * HW;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
@@ -189,7 +190,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         dst = v ? xin[((size_t)iy * a.W + ix) * in_pix_stride + (size_t)chunk * 4 + pc] : make_uint4(0u, 0u, 0u, 0u);
     };
     auto store_a = [&](int buf, int round, const uint4 &src) {
-        const int e = round * kSplitThreads + tid;
+        const int e = round * NT + tid;
         if (round < A_ROUNDS && e < A_PIECES) {
             const int pix = e >> 2, pc = e & 3;
             const int hx = pix % HW;                                  // swizzle by halo COLUMN only, so that
@@ -454,18 +455,21 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
                  const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
                  int Cout, int stride, int pad_t, int pad_l, int act, long long npairs)
 {
-    extern __shared__ __attribute__((aligned(16))) float wl[];       // [27][Cout] + bias[Cout]
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [27][Cout] + bias[Cout], then the stage
     const int CG = Cout >> 4;
+    uint4 *stage = reinterpret_cast<uint4 *>(wl + 28 * Cout);         // [2 * 256 / CG pixels][4 * CG pieces]
     for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.0f;
     __syncthreads();
     const int PW = (OW + 1) >> 1;                                     // pixel pairs per output row
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cg = (int)(t % CG);
-    const long long pair = t / CG;
-    if (pair >= npairs) return;
+    const int pairs_per_block = 256 / CG;
+    const long long pair0 = (long long)blockIdx.x * pairs_per_block;
+    const int cg = threadIdx.x % CG;
+    const int pairl = threadIdx.x / CG;
+    const long long pair = pair0 + pairl;
+    const bool live = pair < npairs;
     const int px2 = (int)(pair % PW);
-    long long rest = pair / PW;
+    const long long rest = pair / PW;
     const int oy = (int)(rest % OH);
     const int img = (int)(rest / OH);
     const int ox = 2 * px2;
@@ -473,42 +477,43 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     float acc[2][16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) acc[0][n] = acc[1][n] = wl[27 * Cout + cg * 16 + n];
-    const float *ximg = x + (size_t)img * H * W * 3;
+    if (live) {
+        const float *ximg = x + (size_t)img * H * W * 3;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {           // rolled: keeps the weight fragment at 16 registers
-        const int r = tap / 3, s = tap - 3 * r;
-        const int iy = oy * stride + r - pad_t;
-        float in[2][3];
+        for (int tap = 0; tap < 9; ++tap) {           // rolled: keeps the weight fragment at 16 registers
+            const int r = tap / 3, s = tap - 3 * r;
+            const int iy = oy * stride + r - pad_t;
+            float in[2][3];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int ix = (ox + p) * stride + s - pad_l;
-            const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float *src = ximg + ((size_t)(v ? iy : 0) * W + (v ? ix : 0)) * 3;
+            for (int p = 0; p < 2; ++p) {
+                const int ix = (ox + p) * stride + s - pad_l;
+                const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float *src = ximg + ((size_t)(v ? iy : 0) * W + (v ? ix : 0)) * 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) in[p][c] = v ? src[c] : 0.0f;
-        }
+                for (int c = 0; c < 3; ++c) in[p][c] = v ? src[c] : 0.0f;
+            }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float4 *wk = reinterpret_cast<const float4 *>(&wl[(tap * 3 + c) * Cout + cg * 16]);
-            const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
-            const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                  w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+            for (int c = 0; c < 3; ++c) {
+                const float4 *wk = reinterpret_cast<const float4 *>(&wl[(tap * 3 + c) * Cout + cg * 16]);
+                const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
+                const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                acc[0][n] = fmaf(in[0][c], ws[n], acc[0][n]);
-                acc[1][n] = fmaf(in[1][c], ws[n], acc[1][n]);
+                for (int n = 0; n < 16; ++n) {
+                    acc[0][n] = fmaf(in[0][c], ws[n], acc[0][n]);
+                    acc[1][n] = fmaf(in[1][c], ws[n], acc[1][n]);
+                }
             }
         }
     }
+    // stage this thread's 2 x 4 pieces, block-local layout [pixel = 2*pairl + p][piece = 4*cg + k]
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        if (ox + p >= OW) break;
-        const size_t pix = ((size_t)img * OH + oy) * OW + ox + p;
         float v[16];
 #pragma unroll
         for (int n = 0; n < 16; ++n) v[n] = act_apply(acc[p][n], act);
+        uint4 *dst = stage + ((2 * pairl + p) * CG + cg) * 4;
         if constexpr (OUT_SPLIT) {
-            uint4 *dst = reinterpret_cast<uint4 *>(out) + (pix * CG + cg) * 4;
             const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
             const float hi8[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
             dst[0] = split_piece<F16>(lo8, false);
@@ -516,12 +521,28 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
             dst[2] = split_piece<F16>(hi8, false);
             dst[3] = split_piece<F16>(hi8, true);
         } else {
-            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + pix * Cout + cg * 16);
-            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-            dst[2] = make_float4(v[8], v[9], v[10], v[11]);
-            dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dst[k] = make_uint4(__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]),
+                                    __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3]));
         }
+    }
+    __syncthreads();
+    // block-linear stores: consecutive lanes write consecutive 16-byte pieces (1 KB per wave instruction);
+    // both layouts (SPLIT16 records, float32 NHWC) are 4*CG pieces per pixel in the same order
+    const int ppp = 4 * CG;                                           // pieces per pixel
+    const int total = 2 * pairs_per_block * ppp;                      // = 2048
+    uint4 *gout = reinterpret_cast<uint4 *>(out);
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int pl = e / ppp, q = e - pl * ppp;
+        const long long gp = pair0 + (pl >> 1);
+        if (gp >= npairs) continue;
+        const int gx2 = (int)(gp % PW);
+        const long long grest = gp / PW;
+        const int gox = 2 * gx2 + (pl & 1);
+        if (gox >= OW) continue;
+        const size_t pix = ((size_t)(grest / OH) * OH + (size_t)(grest % OH)) * OW + gox;
+        gout[pix * ppp + q] = stage[e];
     }
 }
 
@@ -530,12 +551,12 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
                             int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
                             hipStream_t s)
 {
-    if (Cout % 16 != 0 || Cout > 256) return hipErrorInvalidValue;
+    if (Cout % 16 != 0 || Cout > 256 || 256 % (Cout / 16) != 0) return hipErrorInvalidValue;
     const long long npairs = (long long)B * OH * ((OW + 1) / 2);
     const long long threads = npairs * (Cout / 16);
     if (threads <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((threads + 255) / 256);
-    const size_t lds = (size_t)28 * Cout * sizeof(float);
+    const size_t lds = (size_t)28 * Cout * sizeof(float) + (size_t)2048 * 16;   // weights + bias + staged records
     if (out_fmt == 0)
         hipLaunchKernelGGL((conv_cin3_kernel<false, false>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
                            OW, Cout, stride, pad_t, pad_l, act, npairs);
@@ -651,15 +672,15 @@ hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool 
     return hipGetLastError();
 }
 
-template <int TH, int WN, int BBUF, bool F16, bool POOL>
+template <int TH, int WN, int BBUF, bool F16, bool POOL, int NW = 4>
 static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
 {
-    constexpr int BN = WN * 64;
+    constexpr int BN = (NW == 8 ? WN * 64 : WN * 64);
     const int tiles_x = (a.W + TWS - 1) / TWS, tiles_y = (a.H + TH - 1) / TH;
     const int n_tiles = (a.Cout + BN - 1) / BN;
     const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, BBUF, F16, POOL>), dim3((unsigned)nblocks), dim3(kSplitThreads), 0,
+    hipLaunchKernelGGL((conv3x3_split_kernel<TH, WN, BBUF, NW, F16, POOL>), dim3((unsigned)nblocks), dim3(64 * NW), 0,
                        s, a, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
@@ -691,6 +712,8 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
     int bbuf = (tile == 82) ? 1 : 2;
     if (force_bbuf) bbuf = force_bbuf;
     if (tile == 82 && bbuf == 2) bbuf = 1;                   // 92 KB: one workgroup per CU, not offered
+    static const int force_waves = env_int("RPN_SPLIT_WAVES");        // 8: 512-thread workgroups on the 8x32 x 128 tile
+    if (tile == 82 && force_waves == 8) return launch_split_variant<8, 2, 1, F16, POOL, 8>(a, s);
     switch (tile * 10 + bbuf) {
         case 821: return launch_split_variant<8, 2, 1, F16, POOL>(a, s);
         case 811: return launch_split_variant<8, 1, 1, F16, POOL>(a, s);
