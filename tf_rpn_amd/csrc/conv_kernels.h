@@ -55,8 +55,8 @@ hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const fl
 
 // ---- x3-split 16-bit MFMA path (conv_split_kernels.hip) ----------------------------------------
 // SPLIT16 activation layout: [B][H][W][C/16][64 B] = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} (bf16 or f16).
-// Split weights: [Cin/16][9][cout_pad][64 B], cout_pad = round_up(Cout, 64).
-inline int split_cout_pad(int Cout) { return (Cout + 63) / 64 * 64; }
+// Split weights: [Cin/16][9][cout_pad][64 B], cout_pad = 64 for Cout <= 64, else round_up(Cout, 128).
+inline int split_cout_pad(int Cout) { return Cout <= 64 ? 64 : (Cout + 127) / 128 * 128; }   // a multiple of the N tile
 inline size_t split_weight_bytes(int Cin, int Cout) { return (size_t)9 * (Cin / 16) * split_cout_pad(Cout) * 64; }
 // power-of-two pre-scale of the weights (f16 only; 0 for bf16) so that their lo halves stay normal
 int split_weight_shift(const float *hwio, size_t count, bool f16);

@@ -36,6 +36,7 @@ namespace rpn {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kSplitThreads = 256;
 constexpr int TWS = 32;                 // tile width in pixels = one MFMA M-block
@@ -46,7 +47,7 @@ template <bool F16> struct Half;
 template <> struct Half<false> {
     using vec = bf16x8;
     using elem = __bf16;
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c)
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                        0, 0, 0);
@@ -55,7 +56,7 @@ template <> struct Half<false> {
 template <> struct Half<true> {
     using vec = f16x8;
     using elem = _Float16;
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c)
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
                                                       0, 0);
@@ -131,13 +132,16 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     constexpr int B_ROUNDS = B_PIECES / NT;
     static_assert(MI * WM == TH && B_PIECES % NT == 0, "tile shape");
     constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
-    constexpr int LDS_PIPE = 2 * HP * 4 + BBUF * B_PIECES;           // uint4 units
+    constexpr int ABUF = HP * 4 + 4;                                 // one halo buffer + a dummy slot for idle lanes
+    constexpr int LDS_PIPE = 2 * ABUF + BBUF * B_PIECES;             // uint4 units
     constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;    // uint4 units (NW waves x 32 rows)
     constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
 
     __shared__ uint4 lds[LDS_UINT4];
-    uint4 *As = lds;                          // [2][HP][4]
-    uint4 *Bs = lds + 2 * HP * 4;             // [BBUF][3][BN][4]
+    // native vector type for everything staged: struct copies of HIP's uint4 lower to memcpy, which keeps the
+    // staging registers in scratch memory across a barrier
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);               // [2][ABUF]
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;    // [BBUF][3][BN][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,44 +163,51 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     const size_t in_pix_stride = (size_t)chunks * 4;                     // uint4 per input pixel
     const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
 
-    // ---- global -> register staging ---------------------------------------------------------
-    uint4 b_reg[B_ROUNDS];
-    uint4 a_reg[A_RPS];
-    auto load_b = [&](int step) {          // weight records of (chunk, filter row): 3 taps x rows n0 .. n0+BN
-        const uint4 *src = a.w + ((size_t)step * 3 * a.cout_pad + n0) * 4;    // step = chunk*3 + row
+    // ---- global -> register staging: every per-thread address is loop-invariant ----------------------
+    // Halo pieces go through a raw buffer descriptor over THIS image: an out-of-image piece gets an offset
+    // beyond num_records and the hardware range check returns zeros (no branch, no exec masking); the
+    // 16-channel slice is selected by the scalar offset.  Weight pieces are plain global loads at
+    // (uniform tile base) + (loop-invariant per-thread offset); cout_pad is a multiple of BN, no bounds check.
+    constexpr int A_SLOTS = 3 * A_RPS;                                 // halo rounds per slice (some may be empty)
+    constexpr unsigned kOob = 0x80000000u;                            // > any per-image tensor size (< 2 GiB)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
+    unsigned a_goff[A_SLOTS];          // byte offset of this thread's piece of slice 0 (or kOob)
+    int a_loff[A_SLOTS];               // uint4 index inside one halo buffer (dummy slot HP*4 when unused)
 #pragma unroll
-        for (int i = 0; i < B_ROUNDS; ++i) {
-            const int e = tid + i * NT;
-            const int t = e / (BN * 4), rem = e - t * (BN * 4);
-            const bool v = n0 + (rem >> 2) < a.cout_pad;
-            b_reg[i] = v ? src[(size_t)t * a.cout_pad * 4 + rem] : make_uint4(0u, 0u, 0u, 0u);
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < B_ROUNDS; ++i) {
-            const int e = tid + i * NT;
-            const int t = e / (BN * 4), rem = e - t * (BN * 4);
-            const int n = rem >> 2, pc = rem & 3;
-            Bs[((buf * 3 + t) * BN + n) * 4 + (pc ^ ((n >> 2) & 3))] = b_reg[i];
-        }
-    };
-    auto load_a = [&](int chunk, int round, uint4 &dst) {   // one 16-byte piece of the (TH+2) x 34 halo of `chunk`
-        const int e = round * NT + tid;
+    for (int R = 0; R < A_SLOTS; ++R) {
+        const int e = R * NT + tid;
         const int pix = e >> 2, pc = e & 3;
         const int hy = pix / HW, hx = pix - hy * HW;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool v = round < A_ROUNDS && e < A_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        dst = v ? xin[((size_t)iy * a.W + ix) * in_pix_stride + (size_t)chunk * 4 + pc] : make_uint4(0u, 0u, 0u, 0u);
-    };
-    auto store_a = [&](int buf, int round, const uint4 &src) {
-        const int e = round * NT + tid;
-        if (round < A_ROUNDS && e < A_PIECES) {
-            const int pix = e >> 2, pc = e & 3;
-            const int hx = pix % HW;                                  // swizzle by halo COLUMN only, so that
-            As[(buf * HP + pix) * 4 + (pc ^ ((hx >> 2) & 3))] = src;    // fragment addresses are linear in the row
-        }
-    };
+        const bool piece = e < A_PIECES;
+        const bool inimg = piece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        a_loff[R] = piece ? (pix * 4 + (pc ^ ((hx >> 2) & 3))) : HP * 4;
+        a_goff[R] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + pc) * 16) : kOob;
+    }
+    u32x4 b_reg[B_ROUNDS];
+    u32x4 a_reg[A_RPS];
+    // (written as macros, not lambdas: a by-reference capture keeps the staging arrays in scratch memory)
+#define RPN_LOAD_B(STEP)                                                                               \
+    {                                                                                                  \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(a.w) + ((size_t)(STEP) * 3 * a.cout_pad + n0) * 4;   \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                      \
+            const int e_ = tid + i_ * NT;                                                              \
+            const int t_ = e_ / (BN * 4), rem_ = e_ - t_ * (BN * 4);          /* powers of two */      \
+            b_reg[i_] = src_[(size_t)t_ * a.cout_pad * 4 + rem_];                                      \
+        }                                                                                              \
+    }
+#define RPN_STORE_B(BUF)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                      \
+            const int e_ = tid + i_ * NT;                                                              \
+            const int t_ = e_ / (BN * 4), rem_ = e_ - t_ * (BN * 4);                                   \
+            const int n_ = rem_ >> 2, pc_ = rem_ & 3;                                                  \
+            Bs[(((BUF) * 3 + t_) * BN + n_) * 4 + (pc_ ^ ((n_ >> 2) & 3))] = b_reg[i_];                \
+        }                                                                                              \
+    }
+#define RPN_LOAD_A(CHUNK, R) \
+    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 64, 0))
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -217,66 +228,63 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         b_off[j] = n * 4 + ((2 * kh) ^ ((n >> 2) & 3));
     }
 
-    // ---- prologue: halo of chunk 0, weights of step 0 -------------------------------------------
-#pragma unroll 1
-    for (int r = 0; r < A_ROUNDS; ++r) {
-        load_a(0, r, a_reg[0]);
-        store_a(0, r, a_reg[0]);
-    }
-    load_b(0);
-    store_b(0);
+    // ---- prologue: halo of slice 0, weights of step 0 -------------------------------------------
+#pragma unroll
+    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN_LOAD_A(0, R);
+    RPN_LOAD_B(0);
+    RPN_STORE_B(0);
     __syncthreads();
 
-    int abuf = 0, bbuf = 0, row = 0, chunk = 0;
+    int abuf = 0, bbuf = 0;
 #pragma unroll 1
-    for (int step = 0; step < steps; ++step) {
-        const bool more_b = step + 1 < steps;
-        const bool more_a = chunk + 1 < chunks;
-        if (more_b) load_b(step + 1);
-        if (more_a) {
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        // the prefetch past the last slice / step is clamped to the last one: its data lands in the idle
+        // buffers and is never read, which keeps the loop free of branches
+        const int next_chunk = chunk + 1 < chunks ? chunk + 1 : chunk;
 #pragma unroll
-            for (int q = 0; q < A_RPS; ++q) load_a(chunk + 1, row * A_RPS + q, a_reg[q]);
-        }
+        for (int row = 0; row < 3; ++row) {              // unrolled: halo slot indices are compile-time
+            const int step = chunk * 3 + row;
+            RPN_LOAD_B(step + 1 < steps ? step + 1 : step);
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN_LOAD_A(next_chunk, row * A_RPS + q);
 
-        const uint4 *arow = As + (abuf * HP + (wm * MI + row) * HW) * 4;
+            const u32x4 *arow = As + (abuf * ABUF + (wm * MI + row) * HW * 4);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {                    // the 3 taps of filter row `row`
-            uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
+            for (int s = 0; s < 3; ++s) {                    // the 3 taps of filter row `row`
+                u32x4 ahi[MI], alo[MI], bhi[NI], blo[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {                   // a_off[s] is lane-constant; i * HW * 4 is an immediate
-                ahi[i] = arow[i * HW * 4 + a_off[s]];
-                alo[i] = arow[i * HW * 4 + (a_off[s] ^ 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                bhi[j] = Bs[(bbuf * 3 + s) * BN * 4 + b_off[j]];
-                blo[j] = Bs[(bbuf * 3 + s) * BN * 4 + (b_off[j] ^ 1)];
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i) {               // a_off[s] is lane-constant; i * HW * 4 is an immediate
+                    ahi[i] = arow[i * HW * 4 + a_off[s]];
+                    alo[i] = arow[i * HW * 4 + (a_off[s] ^ 1)];
+                }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = Half<F16>::mfma(alo[i], bhi[j], acc[i][j]);
-                    acc[i][j] = Half<F16>::mfma(ahi[i], blo[j], acc[i][j]);
-                    acc[i][j] = Half<F16>::mfma(ahi[i], bhi[j], acc[i][j]);
+                    bhi[j] = Bs[(bbuf * 3 + s) * BN * 4 + b_off[j]];
+                    blo[j] = Bs[(bbuf * 3 + s) * BN * 4 + (b_off[j] ^ 1)];
                 }
-        }
-
-        if (BBUF == 1) __syncthreads();                  // every wave is done reading the single weight buffer
-        if (more_b) store_b(BBUF == 2 ? (bbuf ^ 1) : 0);
-        if (more_a) {
 #pragma unroll
-            for (int q = 0; q < A_RPS; ++q) store_a(abuf ^ 1, row * A_RPS + q, a_reg[q]);
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = Half<F16>::mfma(alo[i], bhi[j], acc[i][j]);
+                        acc[i][j] = Half<F16>::mfma(ahi[i], blo[j], acc[i][j]);
+                        acc[i][j] = Half<F16>::mfma(ahi[i], bhi[j], acc[i][j]);
+                    }
+            }
+
+            if (BBUF == 1) __syncthreads();              // every wave is done reading the single weight buffer
+            RPN_STORE_B(BBUF == 2 ? (bbuf ^ 1) : 0);
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
+            __syncthreads();
+            if (BBUF == 2) bbuf ^= 1;
         }
-        __syncthreads();
-        if (BBUF == 2) bbuf ^= 1;
-        if (++row == 3) {
-            row = 0;
-            ++chunk;
-            abuf ^= 1;
-        }
+        abuf ^= 1;
     }
 
+#undef RPN_LOAD_B
+#undef RPN_STORE_B
+#undef RPN_LOAD_A
     // ---- epilogue: scale + bias + activation (+ fused 2x2 max-pool), transpose through LDS, 16-byte stores --
     float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
     float bias_v[NI];
