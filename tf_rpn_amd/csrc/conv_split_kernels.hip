@@ -38,7 +38,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int kSplitThreads = 256;
+// (workgroups are 64 * NW threads; NW = 4 or 8)
 constexpr int TWS = 32;                 // tile width in pixels = one MFMA M-block
 constexpr int HW = TWS + 2;             // halo width
 constexpr int kStagePad = 4;            // floats of padding per staged row (keeps 16-byte alignment)
@@ -457,7 +457,11 @@ maxpool_split_kernel(const uint4 *__restrict__ x, int H, int W, int G, int OH, i
 // either as float32 NHWC or directly as SPLIT16 records (one 64-byte record per thread and pixel), which
 // removes the separate float32 -> SPLIT16 pass in front of the split-precision layers.
 // HBM-bound in principle (12 B read + 4*Cout B written per pixel); VALU-bound in practice.
-template <bool F16, bool OUT_SPLIT>
+struct __attribute__((packed, aligned(4))) F4u {      // float4 at 4-byte alignment (still one global_load_dwordx4)
+    float x, y, z, w;
+};
+
+template <bool F16, bool OUT_SPLIT, int STRIDE>
 __global__ void __launch_bounds__(256)
 conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27, Cout) */,
                  const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
@@ -481,35 +485,48 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     const int oy = (int)(rest % OH);
     const int img = (int)(rest / OH);
     const int ox = 2 * px2;
+    (void)stride;
 
     float acc[2][16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) acc[0][n] = acc[1][n] = wl[27 * Cout + cg * 16 + n];
     if (live) {
+        // per filter row: the 2 output pixels read (STRIDE + 3) consecutive input pixels = 12 or 15 contiguous
+        // floats; interior threads fetch them as 4 wide loads, border threads element by element with zero fill
         const float *ximg = x + (size_t)img * H * W * 3;
+        const int c0 = ox * STRIDE - pad_l;                              // first input column of the window
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {           // rolled: keeps the weight fragment at 16 registers
-            const int r = tap / 3, s = tap - 3 * r;
-            const int iy = oy * stride + r - pad_t;
-            float in[2][3];
+        for (int r = 0; r < 3; ++r) {                                    // rolled: keeps registers low
+            const int iy = oy * STRIDE + r - pad_t;
+            const bool row_ok = iy >= 0 && iy < H;
+            float win[16];
+            if (row_ok && c0 >= 0 && c0 * 3 + 16 <= W * 3) {
+                const F4u *src = reinterpret_cast<const F4u *>(ximg + ((size_t)iy * W + c0) * 3);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int ix = (ox + p) * stride + s - pad_l;
-                const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float *src = ximg + ((size_t)(v ? iy : 0) * W + (v ? ix : 0)) * 3;
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const F4u v = src[v4];
+                    win[4 * v4] = v.x; win[4 * v4 + 1] = v.y; win[4 * v4 + 2] = v.z; win[4 * v4 + 3] = v.w;
+                }
+            } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) in[p][c] = v ? src[c] : 0.0f;
+                for (int j = 0; j < 15; ++j) {
+                    const int col = c0 + j / 3;
+                    const bool v = row_ok && col >= 0 && col < W && j < 3 * (STRIDE + 3);
+                    win[j] = v ? ximg[((size_t)iy * W + col) * 3 + j % 3] : 0.0f;
+                }
+                win[15] = 0.0f;
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 *wk = reinterpret_cast<const float4 *>(&wl[(tap * 3 + c) * Cout + cg * 16]);
+            for (int sc = 0; sc < 9; ++sc) {                             // (tap column s, channel c) = (sc / 3, sc % 3)
+                const float4 *wk = reinterpret_cast<const float4 *>(&wl[(r * 9 + sc) * Cout + cg * 16]);
                 const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
                 const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
                                       w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                const float in0 = win[sc], in1 = win[sc + 3 * STRIDE];    // pixel p reads column p*STRIDE + s
 #pragma unroll
                 for (int n = 0; n < 16; ++n) {
-                    acc[0][n] = fmaf(in[0][c], ws[n], acc[0][n]);
-                    acc[1][n] = fmaf(in[1][c], ws[n], acc[1][n]);
+                    acc[0][n] = fmaf(in0, ws[n], acc[0][n]);
+                    acc[1][n] = fmaf(in1, ws[n], acc[1][n]);
                 }
             }
         }
@@ -565,15 +582,18 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
     if (threads <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     const size_t lds = (size_t)28 * Cout * sizeof(float) + (size_t)2048 * 16;   // weights + bias + staged records
-    if (out_fmt == 0)
-        hipLaunchKernelGGL((conv_cin3_kernel<false, false>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
-                           OW, Cout, stride, pad_t, pad_l, act, npairs);
-    else if (f16)
-        hipLaunchKernelGGL((conv_cin3_kernel<true, true>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
-                           OW, Cout, stride, pad_t, pad_l, act, npairs);
-    else
-        hipLaunchKernelGGL((conv_cin3_kernel<false, true>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, H, W, OH,
-                           OW, Cout, stride, pad_t, pad_l, act, npairs);
+#define RPN_CIN3(F16_, SPLIT_, STRIDE_)                                                                       \
+    hipLaunchKernelGGL((conv_cin3_kernel<F16_, SPLIT_, STRIDE_>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, \
+                       H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs)
+    if (stride != 1 && stride != 2) return hipErrorInvalidValue;
+    if (out_fmt == 0) {
+        if (stride == 1) RPN_CIN3(false, false, 1); else RPN_CIN3(false, false, 2);
+    } else if (f16) {
+        if (stride == 1) RPN_CIN3(true, true, 1); else RPN_CIN3(true, true, 2);
+    } else {
+        if (stride == 1) RPN_CIN3(false, true, 1); else RPN_CIN3(false, true, 2);
+    }
+#undef RPN_CIN3
     return hipGetLastError();
 }
 

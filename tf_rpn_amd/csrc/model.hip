@@ -121,7 +121,8 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     const Tensor ti = m->tensors[in];
     Op op;
     op.split = split;
-    op.cin3 = ti.C == 3 && R == 3 && Cout % 16 == 0 && Cout <= 256 && 256 % (Cout / 16) == 0 && residual < 0;
+    op.cin3 = ti.C == 3 && R == 3 && (stride == 1 || stride == 2) && Cout % 16 == 0 && Cout <= 256 &&
+              256 % (Cout / 16) == 0 && residual < 0;
     op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
@@ -755,7 +756,8 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): kernel failed: %s", hipGetErrorString(e2));
         return RPN_OK;
     }
-    if (Cin == 3 && R == 3 && S == 3 && Cout % 16 == 0 && Cout <= 256 && 256 % (Cout / 16) == 0) {   // first-layer direct kernel
+    if (Cin == 3 && R == 3 && S == 3 && (stride == 1 || stride == 2) && Cout % 16 == 0 && Cout <= 256 &&
+        256 % (Cout / 16) == 0) {   // first-layer direct kernel
         const hipError_t e = launch_conv_cin3(d_x, d_w, d_bias, d_out, B, H, W, OH, OW, Cout, stride, pad_t, pad_l, act,
                                               0, false, s);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(cin3): launch failed: %s", hipGetErrorString(e));
