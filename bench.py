@@ -33,8 +33,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--backbone", default="vgg16", choices=["vgg16", "mobilenet_v2"])
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="BASELINE.json config: c2 = configs[1] (default: VGG16, 500x500, batch 8 per GPU); c4 = configs[3] "
+                         "(VGG16, 32 images per GPU = batch 256 on 8 GPUs); c5 = configs[4] (MobileNetV2, 1024x1024, 15 "
+                         "anchors per cell, 1 image per GPU = batch 8 on 8 GPUs)")
+    ap.add_argument("--backbone", default=None, choices=["vgg16", "mobilenet_v2"])
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"],
                     help="conv arithmetic: exact f32 MFMA, or f32 operands carried as hi+lo bf16/f16 halves with 3 MFMAs per "
                          "product and f32 accumulation (DESIGN.md 4.1: f16x3 measures as accurate as exact f32)")
@@ -142,7 +146,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
-    hp = dict(train_utils.get_hyper_params(args.backbone))
+    if args.backbone is None:
+        args.backbone = "mobilenet_v2" if args.config == "c5" else "vgg16"
+    if args.batch is None:
+        args.batch = {"c2": 8, "c4": 32, "c5": 1}[args.config]
+    if args.config == "c5":     # 3 scales x 5 aspect ratios; BASELINE.json names no ratio set: {1, 2, 1/2, 3, 1/3}
+        hp = dict(train_utils.get_hyper_params(args.backbone, img_size=1024, feature_map_shape=64,
+                                               anchor_ratios=[1., 2., 1. / 2., 3., 1. / 3.]))
+    else:
+        hp = dict(train_utils.get_hyper_params(args.backbone))
     weights = synthetic_weights(args.backbone, hp, seed=1)
     prop = Proposer(args.backbone, hyper_params=hp, weights=weights, precision=args.precision,
                     max_batch=args.batch, iou_threshold=args.iou_threshold)
@@ -226,8 +238,10 @@ def main():
                            "f16x3": "float32 operands as hi+lo float16 halves, 3 MFMAs per product, float32 accumulate",
                            "bf16x3": "float32 operands as hi+lo bfloat16 halves, 3 MFMAs per product, float32 accumulate"
                            }[args.precision],
-            "config": {"workload": "configs[1]: 500x500x3 synthetic batch=%d per GPU, %s backbone + RPN head, "
-                                   "decode + NMS(300), %dxMI355X" % (B, args.backbone, world),
+            "config": {"workload": "configs[%d]: %dx%dx3 synthetic batch=%d per GPU, %s backbone + RPN head, %d anchors/cell, "
+                                   "decode + NMS(300), %dxMI355X" % ({"c2": 1, "c4": 3, "c5": 4}[args.config], hp["img_size"],
+                                                                      hp["img_size"], B, args.backbone, hp["anchor_count"],
+                                                                      world),
                        "per_gpu_batch": B, "global_batch": world * B, "img_size": hp["img_size"],
                        "anchors_per_image": prop.total_anchors, "nms_topn": M, "iou_threshold": args.iou_threshold,
                        "weights": "random-init (seeded He-normal)",

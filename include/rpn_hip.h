@@ -75,6 +75,11 @@ int rpn_decode(const float *d_anchors, int anchors_batched, const float *d_delta
 int rpn_encode(const float *d_bboxes, int bboxes_batched, const float *d_gt_boxes, int B, int A,
                float *d_deltas, void *stream);
 
+/* normalize_bboxes / denormalize_bboxes(bboxes, height, width)     utils/bbox_utils.py:152-166 / :168-182
+ *   nboxes boxes of 4 floats; denormalize != 0 multiplies and rounds half-to-even (tf.round), else divides */
+int rpn_scale_boxes(const float *d_boxes, long long nboxes, float height, float width, int denormalize,
+                    float *d_out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * generate_iou_map(bboxes, gt_boxes) -> (B,A,G)              utils/bbox_utils.py:126-150
  *   d_bboxes is (A,4) when bboxes_batched == 0 (the utils/train_utils.py:106 call shape).

@@ -71,6 +71,14 @@ def encode(bboxes, gt):
     return out
 
 
+def scale_boxes(bboxes, height, width, denormalize):
+    b = _f32(bboxes)
+    out = np.empty_like(b)
+    lib().orc_scale_boxes(_p(b), ctypes.c_longlong(b.size // 4), ctypes.c_float(height), ctypes.c_float(width),
+                          int(bool(denormalize)), _p(out))
+    return out
+
+
 def iou_map(bboxes, gt):
     bboxes, gt = _f32(bboxes), _f32(gt)
     B, G = gt.shape[0], gt.shape[1]

@@ -114,6 +114,21 @@ void orc_encode(const float *bboxes, int bboxes_batched, const float *gt, int B,
         }
 }
 
+/* ---- normalize / denormalize: utils/bbox_utils.py:152-182 (tf.round = half to even = rintf) ---- */
+void orc_scale_boxes(const float *in, long long n, float height, float width, int denorm, float *out)
+{
+    for (long long i = 0; i < n; ++i) {
+        const float *b = in + 4 * i;
+        float *o = out + 4 * i;
+        if (denorm) {
+            o[0] = rintf(b[0] * height); o[1] = rintf(b[1] * width);
+            o[2] = rintf(b[2] * height); o[3] = rintf(b[3] * width);
+        } else {
+            o[0] = b[0] / height; o[1] = b[1] / width; o[2] = b[2] / height; o[3] = b[3] / width;
+        }
+    }
+}
+
 /* ---- IoU map: utils/bbox_utils.py:126-150 -------------------------------- */
 static float fmaxx(float a, float b) { return a > b ? a : b; }   /* tf.maximum on finite data */
 static float fminn(float a, float b) { return a < b ? a : b; }

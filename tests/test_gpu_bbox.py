@@ -87,6 +87,16 @@ def test_encode_matches_oracle_and_round_trips(golden_dir):
     assert np.abs(back - g["gt_per_anchor"])[keep].max() <= 4e-6
 
 
+def test_normalize_denormalize_bit_exact():
+    rng = np.random.RandomState(8)
+    px = rng.uniform(-20, 520, size=(3, 1000, 4)).astype(np.float32)
+    assert np.array_equal(bbox_utils.normalize_bboxes(px, 375, 500), bo.normalize_bboxes(px, 375, 500))
+    nb = rng.uniform(-0.1, 1.1, size=(3, 1000, 4)).astype(np.float32)
+    nb[0, 0] = [0.5 / 4, 1.5 / 4, 2.5 / 4, 3.5 / 4]
+    assert np.array_equal(bbox_utils.denormalize_bboxes(nb, 375, 500), bo.denormalize_bboxes(nb, 375, 500))
+    assert bbox_utils.denormalize_bboxes(nb[:1, :1], 4, 4).tolist() == [[[0, 2, 2, 4]]]     # tf.round: half to even
+
+
 # ---- IoU map: bit-exact ---------------------------------------------------------------------
 @pytest.mark.parametrize("B,G,backbone", [(1, 1, "vgg16"), (3, 7, "vgg16"), (64, 42, "vgg16"), (8, 42, "mobilenet_v2")])
 def test_iou_map_bit_exact(B, G, backbone):

@@ -142,6 +142,16 @@ def test_encode_decode_round_trip():
     np.testing.assert_allclose(bo.get_bboxes_from_deltas(anchors, deltas), gt, rtol=0, atol=2e-6)
 
 
+def test_normalize_denormalize_numpy_vs_c():
+    rng = np.random.RandomState(8)
+    px = rng.uniform(-20, 520, size=(3, 17, 4)).astype(np.float32)
+    assert np.array_equal(bo.normalize_bboxes(px, 375, 500), co.scale_boxes(px, 375, 500, False))
+    nb = rng.uniform(-0.1, 1.1, size=(3, 17, 4)).astype(np.float32)
+    nb[0, 0] = [0.5 / 375, 1.5 / 500, 2.5 / 375, 0.0]             # exact .5 cases: half to even
+    assert np.array_equal(bo.denormalize_bboxes(nb, 375, 500), co.scale_boxes(nb, 375, 500, True))
+    assert bo.denormalize_bboxes(np.float32([[0.5 / 4, 1.5 / 4, 2.5 / 4, 3.5 / 4]]), 4, 4).tolist() == [[0, 2, 2, 4]]
+
+
 def test_iou_map_invariants():
     rng = np.random.RandomState(6)
     b = cases.random_boxes(rng, (1, 40))

@@ -48,14 +48,15 @@ struct Variances {
     int enabled;
 };
 
+// grid.y = image; 32-bit indices inside an image (64-bit div/mod per element costs more than the box math)
 __global__ void __launch_bounds__(kThreads)
 decode_kernel(const float *__restrict__ anchors, int anchors_batched, const float *__restrict__ deltas,
-              Variances var, int A, long long total, float *__restrict__ out)
+              Variances var, int A, float *__restrict__ out)
 {
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
-         i += (long long)gridDim.x * kThreads) {
-        const long long ai = anchors_batched ? i : (i % A);
-        const Box an = load_box(anchors + 4 * ai);
+    const size_t img_off = (size_t)blockIdx.y * A;
+    for (int a = blockIdx.x * kThreads + threadIdx.x; a < A; a += gridDim.x * kThreads) {
+        const size_t i = img_off + a;
+        const Box an = load_box(anchors + 4 * (anchors_batched ? i : (size_t)a));
         const float4 d = *reinterpret_cast<const float4 *>(deltas + 4 * i);
         float dy = d.x, dx = d.y, dh = d.z, dw = d.w;
         if (var.enabled) {                      // predictor.py:55
@@ -70,60 +71,84 @@ decode_kernel(const float *__restrict__ anchors, int anchors_batched, const floa
 
 __global__ void __launch_bounds__(kThreads)
 encode_kernel(const float *__restrict__ bboxes, int bboxes_batched, const float *__restrict__ gt, int A,
-              long long total, float *__restrict__ out)
+              float *__restrict__ out)
 {
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
-         i += (long long)gridDim.x * kThreads) {
-        const long long bi = bboxes_batched ? i : (i % A);
-        const float4 d = encode_box(load_box(bboxes + 4 * bi), load_box(gt + 4 * i));
+    const size_t img_off = (size_t)blockIdx.y * A;
+    for (int a = blockIdx.x * kThreads + threadIdx.x; a < A; a += gridDim.x * kThreads) {
+        const size_t i = img_off + a;
+        const float4 d = encode_box(load_box(bboxes + 4 * (bboxes_batched ? i : (size_t)a)), load_box(gt + 4 * i));
         *reinterpret_cast<float4 *>(out + 4 * i) = d;
     }
 }
 
-// IoU map: each lane produces 4 consecutive floats of the flat (B,A,G) output and stores
-// them with one 16-byte store (when the total is a multiple of 4; otherwise the tail lane
-// falls back to scalar stores).  The (anchor, gt) operands are a few hundred KB and are
+// IoU map: grid.y = image; each lane produces 4 consecutive floats of that image's (A,G) slab and stores them
+// with one 16-byte store (the slab base is 16-byte aligned when A*G % 4 == 0; otherwise scalar stores).  All
+// index math is 32-bit with one division per lane.  The (anchor, gt) operands are a few hundred KB and are
 // served by L1/L2; the kernel is bound by the 4*B*A*G output bytes.
 __global__ void __launch_bounds__(kThreads)
 iou_map_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt,
-               int G, long long total, float *__restrict__ out)
+               int G, int vec_ok, float *__restrict__ out)
 {
-    const long long nvec = (total + 3) / 4;
-    for (long long v = (long long)blockIdx.x * kThreads + threadIdx.x; v < nvec;
-         v += (long long)gridDim.x * kThreads) {
-        const long long e0 = v * 4;
-        long long row = e0 / G;                 // row = b*A + a
-        int g = (int)(e0 - row * G);
+    const int b = blockIdx.y;
+    const int per_img = A * G;
+    const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
+    const float *__restrict__ bbb = bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0);
+    float *__restrict__ outb = out + (size_t)b * per_img;
+    const int nvec = (per_img + 3) >> 2;
+    for (int v = blockIdx.x * kThreads + threadIdx.x; v < nvec; v += gridDim.x * kThreads) {
+        const int e0 = v << 2;
+        int a = e0 / G;
+        int g = e0 - a * G;
+        Box bb = load_box(bbb + 4 * (size_t)a);
+        float barea = box_area_plain(bb);                       // :139
         float r[4];
-        long long cur_row = -1;
-        Box bb{};
-        float barea = 0.0f;
-        long long b = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (e0 + j < total) {
-                if (row != cur_row) {
-                    b = row / A;
-                    const long long a = row - b * A;
-                    bb = load_box(bboxes + 4 * (bboxes_batched ? row : a));
-                    barea = box_area_plain(bb);             // :139
-                    cur_row = row;
-                }
-                const Box gg = load_box(gt + 4 * (b * G + g));
+            if (e0 + j < per_img) {
+                const Box gg = load_box(gtb + 4 * g);
                 r[j] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
                 if (++g == G) {
                     g = 0;
-                    ++row;
+                    ++a;
+                    if (j < 3 && e0 + j + 1 < per_img) {
+                        bb = load_box(bbb + 4 * (size_t)a);
+                        barea = box_area_plain(bb);
+                    }
                 }
             } else {
                 r[j] = 0.0f;
             }
         }
-        if (e0 + 3 < total) {
-            *reinterpret_cast<float4 *>(out + e0) = make_float4(r[0], r[1], r[2], r[3]);
+        if (vec_ok && e0 + 3 < per_img) {
+            *reinterpret_cast<float4 *>(outb + e0) = make_float4(r[0], r[1], r[2], r[3]);
         } else {
-            for (int j = 0; j < 4 && e0 + j < total; ++j) out[e0 + j] = r[j];
+            for (int j = 0; j < 4 && e0 + j < per_img; ++j) outb[e0 + j] = r[j];
         }
+    }
+}
+
+// normalize_bboxes / denormalize_bboxes (utils/bbox_utils.py:152-182): per-coordinate divide / multiply by the
+// image height (y) or width (x); denormalize rounds half-to-even like tf.round (rintf in the default mode)
+__global__ void __launch_bounds__(kThreads)
+scale_boxes_kernel(const float *__restrict__ in, float height, float width, int denorm, long long nboxes,
+                   float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nboxes;
+         i += (long long)gridDim.x * kThreads) {
+        const Box b = load_box(in + 4 * i);
+        Box o;
+        if (denorm) {
+            o.y1 = rintf(b.y1 * height);
+            o.x1 = rintf(b.x1 * width);
+            o.y2 = rintf(b.y2 * height);
+            o.x2 = rintf(b.x2 * width);
+        } else {
+            o.y1 = b.y1 / height;
+            o.x1 = b.x1 / width;
+            o.y2 = b.y2 / height;
+            o.x2 = b.x2 / width;
+        }
+        store_box(out + 4 * i, o);
     }
 }
 
@@ -184,9 +209,9 @@ extern "C" int rpn_decode(const float *d_anchors, int anchors_batched, const flo
         for (int i = 0; i < 4; ++i) var.v[i] = variances[i];
         var.enabled = 1;
     }
-    const long long total = (long long)B * A;
-    hipLaunchKernelGGL(decode_kernel, dim3(grid_for(total)), dim3(kThreads), 0, as_stream(stream), d_anchors,
-                       anchors_batched, d_deltas, var, A, total, d_boxes);
+    RPN_REQUIRE(B <= 65535, "rpn_decode: batch %d > 65535", B);
+    hipLaunchKernelGGL(decode_kernel, dim3(grid_for(A), B), dim3(kThreads), 0, as_stream(stream), d_anchors,
+                       anchors_batched, d_deltas, var, A, d_boxes);
     RPN_CHECK_LAUNCH();
     return RPN_OK;
 }
@@ -198,9 +223,9 @@ extern "C" int rpn_encode(const float *d_bboxes, int bboxes_batched, const float
     if ((long long)B * A == 0) return RPN_OK;
     RPN_REQUIRE(d_bboxes && d_gt && d_deltas, "rpn_encode: null pointer");
     RPN_REQUIRE_DEVICE();
-    const long long total = (long long)B * A;
-    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(total)), dim3(kThreads), 0, as_stream(stream), d_bboxes,
-                       bboxes_batched, d_gt, A, total, d_deltas);
+    RPN_REQUIRE(B <= 65535, "rpn_encode: batch %d > 65535", B);
+    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(A), B), dim3(kThreads), 0, as_stream(stream), d_bboxes,
+                       bboxes_batched, d_gt, A, d_deltas);
     RPN_CHECK_LAUNCH();
     return RPN_OK;
 }
@@ -213,8 +238,23 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     if (total == 0) return RPN_OK;
     RPN_REQUIRE(d_bboxes && d_gt && d_iou, "rpn_iou_map: null pointer");
     RPN_REQUIRE_DEVICE();
-    hipLaunchKernelGGL(iou_map_kernel, dim3(grid_for((total + 3) / 4)), dim3(kThreads), 0, as_stream(stream),
-                       d_bboxes, bboxes_batched, A, d_gt, G, total, d_iou);
+    RPN_REQUIRE((long long)A * G < (1ll << 31) && B <= 65535, "rpn_iou_map: A*G or B too large");
+    const int per_img = A * G;
+    hipLaunchKernelGGL(iou_map_kernel, dim3(grid_for((per_img + 3) / 4), B), dim3(kThreads), 0, as_stream(stream),
+                       d_bboxes, bboxes_batched, A, d_gt, G, (per_img % 4 == 0) ? 1 : 0, d_iou);
+    RPN_CHECK_LAUNCH();
+    return RPN_OK;
+}
+
+extern "C" int rpn_scale_boxes(const float *d_boxes, long long nboxes, float height, float width, int denormalize,
+                               float *d_out, void *stream)
+{
+    RPN_REQUIRE(nboxes >= 0, "rpn_scale_boxes: negative size");
+    if (nboxes == 0) return RPN_OK;
+    RPN_REQUIRE(d_boxes && d_out, "rpn_scale_boxes: null pointer");
+    RPN_REQUIRE_DEVICE();
+    hipLaunchKernelGGL(scale_boxes_kernel, dim3(grid_for(nboxes)), dim3(kThreads), 0, as_stream(stream), d_boxes,
+                       height, width, denormalize ? 1 : 0, nboxes, d_out);
     RPN_CHECK_LAUNCH();
     return RPN_OK;
 }

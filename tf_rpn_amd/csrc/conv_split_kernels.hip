@@ -473,17 +473,24 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.0f;
     __syncthreads();
+    // index math in 32 bits with ONE division per block (the host checks npairs < 2^31): 64-bit div/mod per
+    // thread and per stored piece used to double this kernel's VALU instruction count
     const int PW = (OW + 1) >> 1;                                     // pixel pairs per output row
     const int pairs_per_block = 256 / CG;
-    const long long pair0 = (long long)blockIdx.x * pairs_per_block;
+    const unsigned pair0 = blockIdx.x * (unsigned)pairs_per_block;
+    const unsigned row0 = pair0 / (unsigned)PW;                       // flattened (img, oy) row of the block's first pair
+    const int x0 = (int)(pair0 - row0 * (unsigned)PW);
     const int cg = threadIdx.x % CG;
     const int pairl = threadIdx.x / CG;
-    const long long pair = pair0 + pairl;
-    const bool live = pair < npairs;
-    const int px2 = (int)(pair % PW);
-    const long long rest = pair / PW;
-    const int oy = (int)(rest % OH);
-    const int img = (int)(rest / OH);
+    const bool live = pair0 + (unsigned)pairl < (unsigned)npairs;
+    int px2 = x0 + pairl;
+    unsigned rowf = row0;
+    while (px2 >= PW) {                                               // at most pairs_per_block / PW + 1 turns
+        px2 -= PW;
+        ++rowf;
+    }
+    const int img = (int)(rowf / (unsigned)OH);
+    const int oy = (int)(rowf - (unsigned)img * (unsigned)OH);
     const int ox = 2 * px2;
     (void)stride;
 
@@ -560,14 +567,16 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     uint4 *gout = reinterpret_cast<uint4 *>(out);
     for (int e = threadIdx.x; e < total; e += 256) {
         const int pl = e / ppp, q = e - pl * ppp;
-        const long long gp = pair0 + (pl >> 1);
-        if (gp >= npairs) continue;
-        const int gx2 = (int)(gp % PW);
-        const long long grest = gp / PW;
+        if (pair0 + (unsigned)(pl >> 1) >= (unsigned)npairs) continue;
+        int gx2 = x0 + (pl >> 1);
+        unsigned grow = row0;
+        while (gx2 >= PW) {
+            gx2 -= PW;
+            ++grow;
+        }
         const int gox = 2 * gx2 + (pl & 1);
         if (gox >= OW) continue;
-        const size_t pix = ((size_t)(grest / OH) * OH + (size_t)(grest % OH)) * OW + gox;
-        gout[pix * ppp + q] = stage[e];
+        gout[((size_t)grow * OW + gox) * ppp + q] = stage[e];
     }
 }
 
@@ -580,6 +589,7 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
     const long long npairs = (long long)B * OH * ((OW + 1) / 2);
     const long long threads = npairs * (Cout / 16);
     if (threads <= 0) return hipSuccess;
+    if (npairs >= 0x7fffffffll || threads / 256 >= 0x7fffffffll) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     const size_t lds = (size_t)28 * Cout * sizeof(float) + (size_t)2048 * 16;   // weights + bias + staged records
 #define RPN_CIN3(F16_, SPLIT_, STRIDE_)                                                                       \

@@ -5,6 +5,7 @@
     get_bboxes_from_deltas(anchors, deltas)         -> rpn_decode             (bbox_utils.py:72-96)
     get_deltas_from_bboxes(bboxes, gt_boxes)        -> rpn_encode             (bbox_utils.py:98-124)
     generate_iou_map(bboxes, gt_boxes)              -> rpn_iou_map            (bbox_utils.py:126-150)
+    normalize_bboxes / denormalize_bboxes(...)      -> rpn_scale_boxes        (bbox_utils.py:152-182)
     non_max_suppression(pred_bboxes, pred_labels, **kwargs) -> rpn_combined_nms (bbox_utils.py:48-70)
 
 Arguments may be torch tensors (any device; results come back as CUDA tensors) or numpy
@@ -92,6 +93,27 @@ def generate_iou_map(bboxes, gt_boxes):
     st = L.lib().rpn_iou_map(L.ptr(b), batched, A, L.ptr(g), B, G, L.ptr(out), L.stream_ptr())
     L.check(st, "generate_iou_map")
     return L.from_device(out, was_np)
+
+
+def _scale_boxes(bboxes, height, width, denormalize):
+    b, was_np = L.to_device(bboxes)
+    if b.shape[-1] != 4:
+        raise ValueError("bboxes must end in 4 coordinates, got %s" % (tuple(b.shape),))
+    out = torch.empty_like(b)
+    st = L.lib().rpn_scale_boxes(L.ptr(b), b.numel() // 4, float(height), float(width), int(denormalize), L.ptr(out),
+                                 L.stream_ptr())
+    L.check(st, "denormalize_bboxes" if denormalize else "normalize_bboxes")
+    return L.from_device(out, was_np)
+
+
+def normalize_bboxes(bboxes, height, width):
+    """(…, [y1, x1, y2, x2]) in pixels -> normalised [0, 1] (utils/bbox_utils.py:152-166)."""
+    return _scale_boxes(bboxes, height, width, False)
+
+
+def denormalize_bboxes(bboxes, height, width):
+    """Normalised boxes -> pixels, rounded half-to-even like tf.round (utils/bbox_utils.py:168-182)."""
+    return _scale_boxes(bboxes, height, width, True)
 
 
 _NMS_KWARGS = ("max_output_size_per_class", "max_total_size", "iou_threshold", "score_threshold",
