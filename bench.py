@@ -43,6 +43,9 @@ def parse_args():
                     help="conv arithmetic: exact f32 MFMA, or f32 operands carried as hi+lo bf16/f16 halves with 3 MFMAs per "
                          "product and f32 accumulation (DESIGN.md 4.1: f16x3 measures as accurate as exact f32)")
     ap.add_argument("--iou-threshold", type=float, default=0.7)
+    ap.add_argument("--serial-nms", action="store_true",
+                    help="run decode+NMS on the conv stream (default: NMS of step k overlaps the convs of step k+1 on a "
+                         "second HIP stream; every step's work still completes inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
@@ -156,8 +159,9 @@ def main():
     else:
         hp = dict(train_utils.get_hyper_params(args.backbone))
     weights = synthetic_weights(args.backbone, hp, seed=1)
+    overlap = not args.serial_nms and world == 1     # with N > 1 the all-gather consumes the proposals every step
     prop = Proposer(args.backbone, hyper_params=hp, weights=weights, precision=args.precision,
-                    max_batch=args.batch, iou_threshold=args.iou_threshold)
+                    max_batch=args.batch, iou_threshold=args.iou_threshold, overlap_nms=overlap)
     B = args.batch
     gen = torch.Generator(device="cuda")
     gen.manual_seed(rank)
@@ -185,6 +189,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if overlap:
+            prop.propose(imgs)                    # convs on this stream, decode+NMS on the side stream
+            continue
         deltas, scores = prop.forward(imgs)
         nms_ev[k][0].record()                     # same stream as the launches (torch's current stream)
         prop_out = prop._boxes[:B], prop._scores[:B], prop._idx[:B], prop._valid[:B]
@@ -197,12 +204,29 @@ def main():
         if world > 1:
             rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3])
             dist.all_gather_into_tensor(gathered, rec)
+    if overlap:
+        prop.wait()                               # the last step's NMS must finish inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     # mean per-op durations over the K timed steps (events were recorded on the launch stream, read here)
     last_ms, _kept = model.profile_ms()
     model.set_profiling(0)
-    nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / args.steps
+    if overlap:                                   # time decode+NMS alone, after the region, for the report
+        torch.cuda.synchronize()
+        d_, s_ = prop._bufs[0]["reg"][:B].view(B, -1, 4), prop._bufs[0]["cls"][:B].view(B, -1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            _lib.check(_lib.lib().rpn_decode_nms(_lib.ptr(prop.anchors), _lib.ptr(d_), prop._vptr, _lib.ptr(s_), B,
+                                                 prop.total_anchors, M, prop.iou_threshold, prop.score_threshold, 1,
+                                                 _lib.ptr(prop._boxes[:B]), _lib.ptr(prop._scores[:B]),
+                                                 _lib.ptr(prop._idx[:B]), _lib.ptr(prop._valid[:B]), _lib.vp(0), 0,
+                                                 _lib.stream_ptr()), "rpn_decode_nms")
+        e1.record()
+        torch.cuda.synchronize()
+        nms_ms = e0.elapsed_time(e1) / 5
+    else:
+        nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / args.steps
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -245,7 +269,9 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "img_size": hp["img_size"],
                        "anchors_per_image": prop.total_anchors, "nms_topn": M, "iou_threshold": args.iou_threshold,
                        "weights": "random-init (seeded He-normal)",
-                       "parallelism": "image-sharded dp%d, one RCCL all-gather of proposals" % world},
+                       "parallelism": "image-sharded dp%d, one RCCL all-gather of proposals" % world,
+                       "nms_overlap": "decode+NMS of step k on a second HIP stream, overlapping the convs of step k+1"
+                                      if overlap else "serial on the conv stream"},
             "nms_boxes_per_sec": round(B * prop.total_anchors / (nms_ms * 1e-3), 1),
             "roofline": roofline,
         }

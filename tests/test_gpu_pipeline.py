@@ -79,3 +79,24 @@ def test_propose_split_precision_full_size(precision):
     rb, rs, _rc, rv, ri = co.combined_nms(dec[:, :, None, :], obj.cpu().numpy()[:, :, None], 300, 300, iou_threshold=0.7)
     assert np.array_equal(valid, rv) and np.array_equal(idx, ri)
     assert np.abs(boxes - rb).max() <= 1e-4 and np.array_equal(scores, rs)
+
+
+def test_pipelined_propose_matches_serial():
+    """overlap_nms=True (NMS on a side stream, double-buffered) returns exactly what the serial path returns,
+    also when batches alternate and are consumed late."""
+    hp = dict(bo.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("vgg16", hp, seed=3)
+    serial = Proposer("vgg16", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    piped = Proposer("vgg16", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3", overlap_nms=True)
+    gen = torch.Generator().manual_seed(5)
+    batches = [torch.rand((2, 160, 160, 3), generator=gen).cuda() for _ in range(5)]
+    want = [[t.clone() for t in serial.propose(x)] for x in batches]
+    got = []
+    for x in batches:                               # issue everything back to back, read afterwards
+        out = piped.propose(x)
+        piped.wait()
+        got.append([t.clone() for t in out])
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert torch.equal(a, b)

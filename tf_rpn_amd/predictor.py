@@ -22,7 +22,7 @@ class Proposer(object):
     """anchors once (predictor.py:46), then ``propose(imgs)`` per batch."""
 
     def __init__(self, backbone="vgg16", hyper_params=None, weights="synthetic", precision="f32",
-                 max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1):
+                 max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1, overlap_nms=False):
         if backbone == "mobilenet_v2":
             from .models.rpn_mobilenet_v2 import get_model
         else:
@@ -54,6 +54,20 @@ class Proposer(object):
         self._valid = torch.zeros((max_batch,), dtype=torch.int32, device=dev)
         _keep, self._vptr = L.host_floats(self.variances)
         self._vkeep = _keep
+        # optional 2-stage pipeline across batches: the NMS of batch k (one workgroup per image: 8 of 256 CUs)
+        # runs on a side stream while the conv stack of batch k+1 runs on the main stream.  Head outputs and
+        # proposal buffers are double buffered; ordering is by HIP events only (no host synchronisation).
+        self.overlap_nms = bool(overlap_nms)
+        if self.overlap_nms:
+            self._nms_stream = torch.cuda.Stream()
+            self._slot = 0
+            self._bufs = []
+            for _ in range(2):
+                self._bufs.append({
+                    "reg": torch.empty_like(self._reg), "cls": torch.empty_like(self._cls),
+                    "boxes": torch.zeros_like(self._boxes), "scores": torch.zeros_like(self._scores),
+                    "idx": torch.full_like(self._idx, -1), "valid": torch.zeros_like(self._valid),
+                    "conv_done": torch.cuda.Event(), "nms_done": torch.cuda.Event(), "used": False})
 
     # -- the hot path ---------------------------------------------------------------------
     def forward(self, imgs):
@@ -65,6 +79,8 @@ class Proposer(object):
 
     def propose(self, imgs):
         """imgs -> (boxes (B,300,4), scores (B,300), valid (B,) int32, indices (B,300) int32)."""
+        if self.overlap_nms:
+            return self._propose_pipelined(imgs)
         B = int(imgs.shape[0])
         deltas, scores = self.forward(imgs)
         ob, osc, oi, ov = self._boxes[:B], self._scores[:B], self._idx[:B], self._valid[:B]
@@ -73,6 +89,37 @@ class Proposer(object):
                                     L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr())
         L.check(st, "rpn_decode_nms")
         return ob, osc, ov, oi
+
+    def _propose_pipelined(self, imgs):
+        """Same results as ``propose``; the returned tensors are complete once the CURRENT stream has passed the
+        wait this method enqueues (consumers on the current stream see finished data, as with ``propose``), but the
+        next call's conv stack may start while this call's NMS is still running."""
+        B = int(imgs.shape[0])
+        main = torch.cuda.current_stream()
+        buf = self._bufs[self._slot]
+        self._slot ^= 1
+        if buf["used"]:
+            main.wait_event(buf["nms_done"])          # the NMS that last read this slot's head outputs is done
+        reg, cls = buf["reg"][:B], buf["cls"][:B]
+        self.rpn_model.forward_into(imgs, reg, cls)
+        buf["conv_done"].record(main)
+        ob, osc, oi, ov = buf["boxes"][:B], buf["scores"][:B], buf["idx"][:B], buf["valid"][:B]
+        with torch.cuda.stream(self._nms_stream):
+            self._nms_stream.wait_event(buf["conv_done"])
+            st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(reg.view(B, -1, 4)), self._vptr,
+                                        L.ptr(cls.view(B, -1)), B, self.total_anchors, self.topn, self.iou_threshold,
+                                        self.score_threshold, 1, L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0,
+                                        L.stream_ptr())
+            L.check(st, "rpn_decode_nms")
+            buf["nms_done"].record(self._nms_stream)
+        buf["used"] = True
+        self._last = buf
+        return ob, osc, ov, oi
+
+    def wait(self):
+        """Make the current stream wait for the proposals returned by the last ``propose`` (pipelined mode)."""
+        if self.overlap_nms and getattr(self, "_last", None) is not None:
+            torch.cuda.current_stream().wait_event(self._last["nms_done"])
 
     def propose_unfused(self, imgs):
         """Same result through the reference's separate calls (decode, then NMS)."""
@@ -114,6 +161,7 @@ class Proposer(object):
         "nccl") returns every rank's records on every rank: (world*B_local, M*5+1)."""
         import torch.distributed as dist
         boxes, scores, valid, _ = self.propose(local_imgs)
+        self.wait()
         rec = self.pack_records(boxes, scores, valid)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return rec
