@@ -84,16 +84,6 @@ __device__ __forceinline__ float join(unsigned short hi, unsigned short lo)
     return (float)__builtin_bit_cast(E, hi) + (float)__builtin_bit_cast(E, lo);
 }
 
-__device__ __forceinline__ float act_apply(float v, int act)
-{
-    switch (act) {
-        case ACT_RELU: return v > 0.0f ? v : 0.0f;
-        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        case ACT_RELU6: return v < 0.0f ? 0.0f : (v > 6.0f ? 6.0f : v);
-        default: return v;
-    }
-}
-
 __device__ __forceinline__ int xcd_remap_s(int bid, int nwg)
 {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -293,6 +283,9 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         const int n = n0 + wn * (NI * 32) + j * 32 + lm;
         bias_v[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     }
+    // activation as a branch-free clamp: linear / relu / relu6 (the launcher rejects sigmoid)
+    const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
     const int cout_chunks = a.Cout >> 4;
     const int nbase = n0 + wn * (NI * 32);                             // first channel of this wave's 64
     // write NPX staged pixels x 64 channels of output row `oy` (output image OHo x OWo, first column oxb)
@@ -347,7 +340,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     const float v0 = fmaxf(acc[2 * ip][j][2 * e2], acc[2 * ip][j][2 * e2 + 1]);
                     const float v1 = fmaxf(acc[2 * ip + 1][j][2 * e2], acc[2 * ip + 1][j][2 * e2 + 1]);
                     const int m2 = (e2 & 1) + 4 * (e2 >> 1) + 2 * kh;             // pooled column 0..15
-                    stage[m2 * STAGE_LD + j * 32 + lm] = act_apply(fmaxf(v0, v1) * a.out_scale + bias_v[j], a.act);
+                    stage[m2 * STAGE_LD + j * 32 + lm] = fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
             __syncthreads();
             store_stage(4, (oy0 + wm * MI + 2 * ip) >> 1, ox0 >> 1, OHo, OWo);
@@ -361,7 +354,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    stage[m * STAGE_LD + j * 32 + lm] = act_apply(acc[i][j][e] * a.out_scale + bias_v[j], a.act);
+                    stage[m * STAGE_LD + j * 32 + lm] = fminf(fmaxf(acc[i][j][e] * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
             __syncthreads();
             store_stage(5, oy0 + wm * MI + i, ox0, a.H, a.W);
@@ -539,11 +532,14 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
         }
     }
     // stage this thread's 2 x 4 pieces, block-local layout [pixel = 2*pairl + p][piece = 4*cg + k]
+    // activation as a branch-free clamp (linear / relu / relu6 only; the host rejects sigmoid for this kernel)
+    const float act_lo = act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = act == ACT_RELU6 ? 6.0f : INFINITY;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         float v[16];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) v[n] = act_apply(acc[p][n], act);
+        for (int n = 0; n < 16; ++n) v[n] = fminf(fmaxf(acc[p][n], act_lo), act_hi);
         uint4 *dst = stage + ((2 * pairl + p) * CG + cg) * 4;
         if constexpr (OUT_SPLIT) {
             const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
@@ -585,7 +581,7 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
                             int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
                             hipStream_t s)
 {
-    if (Cout % 16 != 0 || Cout > 256 || 256 % (Cout / 16) != 0) return hipErrorInvalidValue;
+    if (Cout % 16 != 0 || Cout > 256 || 256 % (Cout / 16) != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     const long long npairs = (long long)B * OH * ((OW + 1) / 2);
     const long long threads = npairs * (Cout / 16);
     if (threads <= 0) return hipSuccess;
@@ -771,7 +767,7 @@ hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
                                 bool pool, hipStream_t s)
 {
-    if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0) return hipErrorInvalidValue;
+    if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;

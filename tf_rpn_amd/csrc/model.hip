@@ -107,6 +107,7 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
                     bool force_f32_out = false, bool cin3_out_split = false)
 {
     const bool split = m->use_split && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && residual < 0 &&
+                       act != ACT_SIGMOID &&
                        m->tensors[in].C % 16 == 0 && Cout % 16 == 0 && !m->tensors[in].external;
     if (split && !m->tensors[in].split_fmt) {          // float32 producer -> SPLIT16 copy for the split kernel
         const Tensor tsrc = m->tensors[in];
@@ -122,7 +123,7 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     Op op;
     op.split = split;
     op.cin3 = ti.C == 3 && R == 3 && (stride == 1 || stride == 2) && Cout % 16 == 0 && Cout <= 256 &&
-              256 % (Cout / 16) == 0 && residual < 0;
+              256 % (Cout / 16) == 0 && residual < 0 && act != ACT_SIGMOID;
     op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
@@ -731,7 +732,7 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
     if (precision != RPN_PRECISION_F32) {
         // x3-split path: 3x3 / stride 1 / pad 1 only; converts x to SPLIT16 and packs the weights on the host
         if (!(R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && Cin % 16 == 0 &&
-              Cout % 16 == 0))
+              Cout % 16 == 0 && act != ACT_SIGMOID))
             return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the split path needs 3x3 s1 'same', Cin,Cout %% 16 == 0");
         const bool f16 = precision == RPN_PRECISION_F16X3;
         const size_t wcount = (size_t)9 * Cin * Cout;
@@ -757,7 +758,7 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         return RPN_OK;
     }
     if (Cin == 3 && R == 3 && S == 3 && (stride == 1 || stride == 2) && Cout % 16 == 0 && Cout <= 256 &&
-        256 % (Cout / 16) == 0) {   // first-layer direct kernel
+        256 % (Cout / 16) == 0 && act != ACT_SIGMOID) {   // first-layer direct kernel
         const hipError_t e = launch_conv_cin3(d_x, d_w, d_bias, d_out, B, H, W, OH, OW, Cout, stride, pad_t, pad_l, act,
                                               0, false, s);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(cin3): launch failed: %s", hipGetErrorString(e));
