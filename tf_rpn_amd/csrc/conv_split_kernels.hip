@@ -763,6 +763,12 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
     if (tile == 82 && bbuf == 2) bbuf = 1;                   // 92 KB: one workgroup per CU, not offered
     static const int force_waves = env_int("RPN_SPLIT_WAVES");        // 8: 512-thread workgroups on the 8x32 x 128 tile
     if (tile == 82 && force_waves == 8) return launch_split_variant<8, 2, 1, F16, POOL, 8>(a, s);
+    // experiment (RPN_SPLIT_SMALL=2): 128 px x 128 ch tiles shared by 8 waves for small feature maps.  Measured on
+    // 31x31x512, batch 8: 0.137 ms vs 0.126 ms for the default 4-wave 128 x 64 tiles, so it stays off.
+    static const int small_mode = env_int("RPN_SPLIT_SMALL");
+    if constexpr (!POOL) {
+        if (tile == 41 && small_mode == 2 && mt4 * nt128 >= 256) return launch_split_variant<4, 2, 2, F16, false, 8>(a, s);
+    }
     switch (tile * 10 + bbuf) {
         case 821: return launch_split_variant<8, 2, 1, F16, POOL>(a, s);
         case 811: return launch_split_variant<8, 1, 1, F16, POOL>(a, s);
