@@ -116,6 +116,15 @@ int rpn_decode_nms(const float *d_anchors, const float *d_deltas, const float *v
                    void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * preprocessing(image_data, final_height, final_width)            utils/data_utils.py:25-28
+ *   one image: uint8 (H,W,3) -> float32 (out_h,out_w,3) in [0,1]: tf.image.convert_image_dtype (x * 1/255),
+ *   tf.image.resize (bilinear, half-pixel centres, no antialias), optional tf.image.flip_left_right
+ *   (flip_horizontally, utils/data_utils.py:63).  d_out may point into a (B,out_h,out_w,3) batch.
+ * ---------------------------------------------------------------------------------- */
+int rpn_preprocess_image(const unsigned char *d_img_u8, int H, int W, int out_h, int out_w, int flip,
+                         float *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * get_model(hyper_params) -> rpn_model            models/rpn_vgg16.py:6-22,
  *                                                 models/rpn_mobilenet_v2.py:6-22
  * rpn_model.predict_on_batch(imgs) -> [reg, cls]  predictor.py:50

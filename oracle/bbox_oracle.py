@@ -290,3 +290,51 @@ def top_k_indices(scores, k):
     scores = np.asarray(scores, F32)
     order = np.argsort(-scores, axis=-1, kind="stable")
     return order[..., :k].astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# input preprocessing  (reference: utils/data_utils.py:25-28, 54-68; TF 2.0 kernels restated)
+# --------------------------------------------------------------------------
+def convert_image_dtype_uint8(img_u8):
+    """tf.image.convert_image_dtype(img, tf.float32) for uint8 input (data_utils.py:25):
+    cast to float32, then ONE float32 multiply by float32(1/255)."""
+    return (np.asarray(img_u8, np.uint8).astype(F32) * F32(1.0 / 255.0)).astype(F32)
+
+
+def resize_bilinear(img, out_h, out_w):
+    """tf.image.resize(img, (h, w)) of TF 2.x (data_utils.py:26): bilinear, half-pixel centres, no antialias.
+    Restated from resize_bilinear_op.cc: in = (i + 0.5) * scale - 0.5 (float32, scale = in_size / out_size),
+    lower = max(floor(in), 0), upper = min(ceil(in), in_size - 1), lerp = in - floor(in);
+    out = top + (bottom - top) * y_lerp with top = tl + (tr - tl) * x_lerp, all float32, one rounding per op."""
+    img = np.asarray(img, F32)
+    H, W = img.shape[0], img.shape[1]
+
+    def weights(out_size, in_size):
+        scale = F32(in_size) / F32(out_size)
+        i = np.arange(out_size, dtype=F32)
+        src = ((i + F32(0.5)) * scale - F32(0.5)).astype(F32)
+        fl = np.floor(src)
+        lower = np.maximum(fl.astype(np.int64), 0)
+        upper = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
+        return lower, upper, (src - fl).astype(F32)
+
+    ylo, yhi, yl = weights(out_h, H)
+    xlo, xhi, xl = weights(out_w, W)
+    tl, tr = img[ylo][:, xlo], img[ylo][:, xhi]
+    bl, br = img[yhi][:, xlo], img[yhi][:, xhi]
+    xl3, yl3 = xl[None, :, None], yl[:, None, None]
+    top = (tl + ((tr - tl) * xl3).astype(F32)).astype(F32)
+    bottom = (bl + ((br - bl) * xl3).astype(F32)).astype(F32)
+    return (top + ((bottom - top) * yl3).astype(F32)).astype(F32)
+
+
+def preprocess_image(img_u8, final_height, final_width, flip=False):
+    """data_utils.py:25-28: convert to float32 [0,1], resize, optional tf.image.flip_left_right."""
+    out = resize_bilinear(convert_image_dtype_uint8(img_u8), final_height, final_width)
+    return out[:, ::-1, :].copy() if flip else out
+
+
+def flip_boxes_horizontally(gt_boxes):
+    """data_utils.py:64-67: [y1, 1 - x2, y2, 1 - x1]."""
+    g = np.asarray(gt_boxes, F32)
+    return np.stack([g[..., 0], F32(1.0) - g[..., 3], g[..., 2], F32(1.0) - g[..., 1]], axis=-1).astype(F32)

@@ -298,3 +298,27 @@ def test_decode_nms_fused_equals_two_step(backbone, B):
     rb, rs, _rc, rv, ri = co.combined_nms(gpu_boxes[:, :, None, :], scores[:, :, None], 300, 300, iou_threshold=0.7)
     assert np.array_equal(fv, rv) and np.array_equal(fi, ri)
     assert np.array_equal(fb, rb) and np.array_equal(fs, rs)
+
+
+# ---- preprocessing (data_utils.py:25-28): bit-exact -----------------------------------------------------------
+@pytest.mark.parametrize("shape,out", [((375, 500), 500), ((500, 333), 500), ((64, 64), 64), ((1, 1), 9),
+                                        ((720, 1280), 1024), ((37, 53), 32)])
+def test_preprocess_image_bit_exact(shape, out):
+    from tf_rpn_amd.utils import data_utils
+    img = np.random.RandomState(shape[0]).randint(0, 256, size=shape + (3,)).astype(np.uint8)
+    for flip in (False, True):
+        got = data_utils.preprocess_image(img, out, out, flip=flip)
+        assert got.dtype == np.float32 and got.shape == (out, out, 3)
+        assert np.array_equal(got, bo.preprocess_image(img, out, out, flip=flip))
+
+
+def test_preprocess_batch_feeds_the_model_layout():
+    from tf_rpn_amd.utils import data_utils
+    rng = np.random.RandomState(1)
+    imgs = [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in ((375, 500), (500, 375), (281, 500))]
+    batch = data_utils.preprocess_batch(imgs, 500, 500, flips=[False, True, False])
+    assert batch.shape == (3, 500, 500, 3) and batch.is_contiguous() and batch.dtype == torch.float32
+    for i, im in enumerate(imgs):
+        assert np.array_equal(batch[i].cpu().numpy(), bo.preprocess_image(im, 500, 500, flip=(i == 1)))
+    g = torch.tensor([[[0.1, 0.2, 0.5, 0.6]]])
+    assert np.allclose(data_utils.flip_boxes_horizontally(g).numpy(), bo.flip_boxes_horizontally(g.numpy()))

@@ -182,3 +182,22 @@ def test_nms_tie_order_and_padding():
 
 def test_top_k_ties_lower_index():
     assert list(bo.top_k_indices(np.float32([[0.2, 0.9, 0.9, 0.1]]), 3)[0]) == [1, 2, 0]
+
+
+def test_preprocess_oracle_properties():
+    """convert_image_dtype + TF2 bilinear resize restatement: identity at equal size, exact on constants,
+    half-pixel sampling on a 2x upscale, flip = mirrored columns."""
+    rng = np.random.RandomState(9)
+    img = rng.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    f = bo.convert_image_dtype_uint8(img)
+    assert f.dtype == np.float32 and f.max() <= 1.0 and f[0, 0, 0] == np.float32(img[0, 0, 0]) * np.float32(1 / 255)
+    assert np.array_equal(bo.resize_bilinear(f, 37, 53), f)
+    const = np.full((5, 7, 3), 0.25, np.float32)
+    assert np.array_equal(bo.resize_bilinear(const, 11, 3), np.full((11, 3, 3), 0.25, np.float32))
+    ramp = np.arange(4, dtype=np.float32)[None, :, None].repeat(3, 2)          # 1x4 row: 0 1 2 3
+    up = bo.resize_bilinear(ramp, 1, 8)[0, :, 0]
+    np.testing.assert_allclose(up, [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.0], atol=1e-6)   # edges clamp
+    out = bo.preprocess_image(img, 50, 50)
+    assert np.array_equal(bo.preprocess_image(img, 50, 50, flip=True), out[:, ::-1])
+    b = np.float32([[0.1, 0.2, 0.5, 0.6]])
+    assert np.allclose(bo.flip_boxes_horizontally(b), [[0.1, 0.4, 0.5, 0.8]])

@@ -152,6 +152,38 @@ scale_boxes_kernel(const float *__restrict__ in, float height, float width, int 
     }
 }
 
+// Input preprocessing (utils/data_utils.py:25-28): uint8 HWC -> float32 in [0,1] (one multiply by 1/255, as
+// tf.image.convert_image_dtype), bilinear resize with half-pixel centres and no antialias (TF 2.x
+// tf.image.resize; op order of resize_bilinear_op.cc), optional tf.image.flip_left_right.  One thread per output
+// pixel (3 channels); HBM-bound: ~4 source pixels x 3 B read (L2-served) + 12 B written per output pixel.
+__global__ void __launch_bounds__(kThreads)
+preprocess_kernel(const unsigned char *__restrict__ img, int H, int W, int OH, int OW, int flip,
+                  float *__restrict__ out)
+{
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    const float k255 = (float)(1.0 / 255.0);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < OH * OW; i += gridDim.x * kThreads) {
+        const int oy = i / OW, oxo = i - oy * OW;
+        const int ox = flip ? (OW - 1 - oxo) : oxo;               // flip_left_right of the resized image
+        const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        const float fyf = floorf(fy), fxf = floorf(fx);
+        const int y0 = max((int)fyf, 0), y1 = min((int)ceilf(fy), H - 1);
+        const int x0 = max((int)fxf, 0), x1 = min((int)ceilf(fx), W - 1);
+        const float ly = fy - fyf, lx = fx - fxf;
+        const unsigned char *p00 = img + ((size_t)y0 * W + x0) * 3, *p01 = img + ((size_t)y0 * W + x1) * 3;
+        const unsigned char *p10 = img + ((size_t)y1 * W + x0) * 3, *p11 = img + ((size_t)y1 * W + x1) * 3;
+        float *o = out + (size_t)i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float tl = (float)p00[c] * k255, tr = (float)p01[c] * k255;
+            const float bl = (float)p10[c] * k255, br = (float)p11[c] * k255;
+            const float top = tl + (tr - tl) * lx;
+            const float bottom = bl + (br - bl) * lx;
+            o[c] = top + (bottom - top) * ly;
+        }
+    }
+}
+
 static int grid_for(long long work_items)
 {
     long long g = (work_items + kThreads - 1) / kThreads;
@@ -255,6 +287,20 @@ extern "C" int rpn_scale_boxes(const float *d_boxes, long long nboxes, float hei
     RPN_REQUIRE_DEVICE();
     hipLaunchKernelGGL(scale_boxes_kernel, dim3(grid_for(nboxes)), dim3(kThreads), 0, as_stream(stream), d_boxes,
                        height, width, denormalize ? 1 : 0, nboxes, d_out);
+    RPN_CHECK_LAUNCH();
+    return RPN_OK;
+}
+
+extern "C" int rpn_preprocess_image(const unsigned char *d_img_u8, int H, int W, int out_h, int out_w, int flip,
+                                    float *d_out, void *stream)
+{
+    RPN_REQUIRE(d_img_u8 && d_out, "rpn_preprocess_image: null pointer");
+    RPN_REQUIRE(H >= 1 && W >= 1 && out_h >= 1 && out_w >= 1 && (long long)out_h * out_w < (1ll << 31) &&
+                    (long long)H * W < (1ll << 31),
+                "rpn_preprocess_image: bad size");
+    RPN_REQUIRE_DEVICE();
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((long long)out_h * out_w)), dim3(kThreads), 0,
+                       as_stream(stream), d_img_u8, H, W, out_h, out_w, flip ? 1 : 0, d_out);
     RPN_CHECK_LAUNCH();
     return RPN_OK;
 }
