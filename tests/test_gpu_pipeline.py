@@ -100,3 +100,30 @@ def test_pipelined_propose_matches_serial():
     for w, g in zip(want, got):
         for a, b in zip(w, g):
             assert torch.equal(a, b)
+
+
+def test_propose_is_graph_capturable():
+    """The whole step (conv stack + fused decode/NMS) performs no allocation or synchronisation, so it can be
+    captured into a HIP graph and replayed; replays give the eager result bit for bit."""
+    hp = dict(bo.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("vgg16", hp, seed=3)
+    prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    gen = torch.Generator().manual_seed(6)
+    a, b = [torch.rand((2, 160, 160, 3), generator=gen).cuda() for _ in range(2)]
+    want_a = [t.clone() for t in prop.propose(a)]
+    want_b = [t.clone() for t in prop.propose(b)]
+    static_in = a.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on the capture stream
+        prop.propose(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = prop.propose(static_in)
+    for src, want in ((b, want_b), (a, want_a), (b, want_b)):
+        static_in.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            assert torch.equal(o, w)

@@ -743,16 +743,16 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         std::vector<unsigned short> packed(split_weight_bytes(Cin, Cout) / 2);
         pack_weights_split_host(hw.data(), nullptr, Cin, Cout, cpad, f16, wshift, packed.data());
         void *d_ws = nullptr, *d_xs = nullptr;
-        RPN_HIP_CHECK(hipMalloc(&d_ws, packed.size() * 2));
-        RPN_HIP_CHECK(hipMalloc(&d_xs, (size_t)B * H * W * Cin * sizeof(float)));
-        RPN_HIP_CHECK(hipMemcpy(d_ws, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
-        hipError_t e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
+        hipError_t e = hipMalloc(&d_ws, packed.size() * 2);
+        if (e == hipSuccess) e = hipMalloc(&d_xs, (size_t)B * H * W * Cin * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_ws, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
         if (e == hipSuccess)
             e = launch_conv3x3_split(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad, ldexpf(1.0f, -wshift), act,
                                      true, f16, false, s);
         const hipError_t e2 = hipStreamSynchronize(s);
-        (void)hipFree(d_ws);
-        (void)hipFree(d_xs);
+        if (d_ws) (void)hipFree(d_ws);                  // freed on every path
+        if (d_xs) (void)hipFree(d_xs);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): launch failed: %s", hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(split): kernel failed: %s", hipGetErrorString(e2));
         return RPN_OK;
