@@ -116,6 +116,20 @@ int rpn_decode_nms(const float *d_anchors, const float *d_deltas, const float *v
                    void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params)   utils/train_utils.py:84-144
+ *   (+ randomly_select_xyz_mask :50-65) -- the consumer of generate_iou_map; the (B,A,G) map is never written.
+ *   d_gt_labels (B,G) int32, -1 = padding.  d_random_pos / d_random_neg (B,A) int32 >= 1 replace the two
+ *   tf.random.uniform draws (priority order: larger first, ties lower index).  variances: HOST pointer, 4 floats.
+ *   Outputs: d_bbox_deltas (B,A,4) = encoded deltas / variances (zero for non-positive anchors),
+ *   d_bbox_labels (B,A) float32 in {1, 0, -1} (caller views it as (B,F,F,K)).
+ * ---------------------------------------------------------------------------------- */
+size_t rpn_targets_workspace_bytes(int B, int A, int G);
+int rpn_rpn_targets(const float *d_anchors, const float *d_gt_boxes, const int32_t *d_gt_labels, int B, int A, int G,
+                    int total_pos, int total_neg, const float *variances, const int32_t *d_random_pos,
+                    const int32_t *d_random_neg, float *d_bbox_deltas, float *d_bbox_labels, void *d_workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * preprocessing(image_data, final_height, final_width)            utils/data_utils.py:25-28
  *   one image: uint8 (H,W,3) -> float32 (out_h,out_w,3) in [0,1]: tf.image.convert_image_dtype (x * 1/255),
  *   tf.image.resize (bilinear, half-pixel centres, no antialias), optional tf.image.flip_left_right

@@ -338,3 +338,54 @@ def flip_boxes_horizontally(gt_boxes):
     """data_utils.py:64-67: [y1, 1 - x2, y2, 1 - x1]."""
     g = np.asarray(gt_boxes, F32)
     return np.stack([g[..., 0], F32(1.0) - g[..., 3], g[..., 2], F32(1.0) - g[..., 1]], axis=-1).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# training-target assignment  (reference: utils/train_utils.py:50-65, 84-144)
+# --------------------------------------------------------------------------
+def randomly_select_xyz_mask(mask, select_xyz, random_ints):
+    """utils/train_utils.py:50-65 with the random tensor made an explicit input (``tf.random.uniform(shape,
+    minval=1, maxval=max(select)*10, int32)`` cannot be reproduced outside TF).  multiplied = mask * random;
+    rank = argsort(argsort(multiplied, DESCENDING)); keep rank < select.  tf.argsort DESCENDING is built on
+    top_k, whose ties go to the lower index, i.e. a stable sort of the negated values."""
+    mask = np.asarray(mask, bool)
+    multiplied = mask.astype(np.int64) * np.asarray(random_ints, np.int64)                       # :61
+    sorted_mask = np.argsort(-multiplied, axis=-1, kind="stable")                                # :62
+    ranks = np.argsort(sorted_mask, axis=-1, kind="stable")                                      # :63
+    select = np.asarray(select_xyz, np.int64).reshape(-1, 1)                                     # :64 expand_dims
+    return np.logical_and(mask, ranks < select)                                                  # :65
+
+
+def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, random_pos, random_neg):
+    """utils/train_utils.py:84-144.  anchors (A,4), gt_boxes (B,G,4), gt_labels (B,G) int32 (-1 = padding),
+    random_pos / random_neg (B,A) int32 >= 1 stand in for the two tf.random.uniform draws.
+    Returns (bbox_deltas (B,A,4) f32, bbox_labels (B,F,F,K) f32 in {1, 0, -1})."""
+    anchors = np.asarray(anchors, F32)
+    gt_boxes = np.asarray(gt_boxes, F32)
+    gt_labels = np.asarray(gt_labels, np.int32)
+    B = gt_boxes.shape[0]
+    fm, K = hyper_params["feature_map_shape"], hyper_params["anchor_count"]
+    total_pos, total_neg = hyper_params["total_pos_bboxes"], hyper_params["total_neg_bboxes"]
+    variances = np.asarray(hyper_params["variances"], F32)
+    iou_map = generate_iou_map(anchors, gt_boxes)                                                 # :106
+    max_indices_each_row = np.argmax(iou_map, axis=2).astype(np.int32)                            # :108 first max
+    max_indices_each_column = np.argmax(iou_map, axis=1).astype(np.int32)                         # :110
+    merged_iou_map = np.max(iou_map, axis=2)                                                      # :112
+    pos_mask = merged_iou_map > F32(0.7)                                                          # :114
+    max_pos_mask = np.zeros_like(pos_mask)
+    for b in range(B):                                                                            # :116-121 scatter
+        for g in range(gt_labels.shape[1]):
+            if gt_labels[b, g] != -1:
+                max_pos_mask[b, max_indices_each_column[b, g]] = True
+    pos_mask = np.logical_or(pos_mask, max_pos_mask)                                              # :122
+    pos_mask = randomly_select_xyz_mask(pos_mask, np.array([total_pos]), random_pos)              # :123
+    pos_count = pos_mask.sum(axis=-1).astype(np.int32)                                            # :125
+    neg_count = (total_pos + total_neg) - pos_count                                               # :126
+    neg_mask = np.logical_and(merged_iou_map < F32(0.3), np.logical_not(pos_mask))                # :128
+    neg_mask = randomly_select_xyz_mask(neg_mask, neg_count, random_neg)                          # :129
+    pos_labels = np.where(pos_mask, F32(1.0), F32(-1.0))                                          # :131
+    bbox_labels = (pos_labels + neg_mask.astype(F32)).astype(F32)                                 # :132-133
+    gt_boxes_map = np.take_along_axis(gt_boxes, max_indices_each_row[..., None].astype(np.int64).repeat(4, -1), axis=1)
+    expanded_gt_boxes = np.where(pos_mask[..., None], gt_boxes_map, F32(0.0)).astype(F32)         # :137
+    bbox_deltas = (get_deltas_from_bboxes(anchors, expanded_gt_boxes) / variances).astype(F32)    # :139
+    return bbox_deltas, bbox_labels.reshape(B, fm, fm, K)                                         # :142

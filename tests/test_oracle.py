@@ -201,3 +201,46 @@ def test_preprocess_oracle_properties():
     assert np.array_equal(bo.preprocess_image(img, 50, 50, flip=True), out[:, ::-1])
     b = np.float32([[0.1, 0.2, 0.5, 0.6]])
     assert np.allclose(bo.flip_boxes_horizontally(b), [[0.1, 0.4, 0.5, 0.8]])
+
+
+def _target_case(backbone="vgg16", B=3, G=42, n_valid=6, seed=0):
+    hp = bo.get_hyper_params(backbone)
+    anchors = bo.generate_anchors(hp)
+    rng = np.random.RandomState(seed)
+    gt = cases.gt_boxes(rng, B, G=G, n_valid=n_valid)
+    labels = np.full((B, G), -1, np.int32)
+    labels[:, :n_valid] = rng.randint(1, 21, size=(B, n_valid))
+    A = len(anchors)
+    rp = rng.randint(1, 1280, size=(B, A)).astype(np.int32)
+    rn = rng.randint(1, 2560, size=(B, A)).astype(np.int32)
+    return hp, anchors, gt, labels, rp, rn
+
+
+def test_rpn_targets_oracle_properties():
+    """calculate_rpn_actual_outputs restatement: 256 sampled anchors per image, positives are IoU > 0.7 or the best
+    anchor of a valid gt, negatives IoU < 0.3, deltas of positives decode back to their gt box, the rest are zero."""
+    hp, anchors, gt, labels, rp, rn = _target_case()
+    deltas, lab = bo.calculate_rpn_actual_outputs(anchors, gt, labels, hp, rp, rn)
+    B, A = deltas.shape[0], deltas.shape[1]
+    lab = lab.reshape(B, A)
+    assert set(np.unique(lab)) <= {-1.0, 0.0, 1.0}
+    iou = bo.generate_iou_map(anchors, gt)
+    merged = iou.max(axis=2)
+    for b in range(B):
+        pos, neg = lab[b] == 1, lab[b] == 0
+        assert pos.sum() + neg.sum() == 256 and 0 < pos.sum() <= 128
+        best = {int(np.argmax(iou[b, :, g])) for g in range(6)}
+        assert all(merged[b, i] > np.float32(0.7) or i in best for i in np.nonzero(pos)[0])
+        assert (merged[b, neg] < np.float32(0.3)).all()
+        assert (deltas[b, ~pos] == 0).all()
+        back = bo.get_bboxes_from_deltas(anchors[pos], (deltas[b, pos] * np.float32(hp["variances"]))[None])[0]
+        np.testing.assert_allclose(back, gt[b, np.argmax(iou[b, pos], axis=1)], atol=3e-6)
+
+
+def test_randomly_select_ties_and_short_masks():
+    mask = np.array([[1, 0, 1, 1, 1, 0, 1]], bool)
+    rnd = np.array([[5, 9, 5, 7, 5, 9, 1]], np.int32)
+    got = bo.randomly_select_xyz_mask(mask, np.array([3]), rnd)
+    assert got.tolist() == [[True, False, True, True, False, False, False]]      # 7, then the two lowest-index 5s
+    assert np.array_equal(bo.randomly_select_xyz_mask(mask, np.array([10]), rnd), mask)          # fewer than asked
+    assert not bo.randomly_select_xyz_mask(mask, np.array([0]), rnd).any()

@@ -33,6 +33,9 @@ _SIGNATURES = {
     "rpn_decode": (ctypes.c_int, [vp, ctypes.c_int, vp, c_float_p, ctypes.c_int, ctypes.c_int, vp, vp]),
     "rpn_encode": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "rpn_scale_boxes": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp]),
+    "rpn_targets_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "rpn_rpn_targets": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       c_float_p, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "rpn_preprocess_image": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "rpn_iou_map": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "rpn_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),

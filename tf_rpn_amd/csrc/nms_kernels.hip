@@ -27,6 +27,7 @@
 // classes (score desc, ties class asc then selection order).
 // Compiled with -ffp-contract=off.
 #include "bbox_core.h"
+#include "radix_select.h"
 #include "rpn_common.h"
 
 #include <cstdlib>
@@ -36,8 +37,7 @@ namespace rpn {
 constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
 constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
-constexpr int kDigitBits = 11;
-constexpr int kBins = 1 << kDigitBits;
+constexpr int kBins = kRsBins;         // radix-select histogram (radix_select.h)
 constexpr int kChunk = 256;
 constexpr int kChunkWords = kChunk / 64;
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -134,7 +134,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
 }
 
 // ctl words
-enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_ABOVE = 2, CTL_DIGIT = 3, CTL_BINCOUNT = 4, CTL_POS = 5, CTL_NCAND = 6 };
+enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by radix_select */ };
 
 template <bool DECODE>
 __global__ void __launch_bounds__(kNmsThreads)
@@ -166,96 +166,14 @@ nms_kernel(NmsArgs p)
     __syncthreads();
 
     unsigned long long hi_bound = ~0ull;       // keys of the current band are < hi_bound (exclusive)
-    bool first_band = true;
 
     while (true) {
         // ================= 1. pick the next band: keys in [thr, hi_bound) ==========================
-        // radix select on 11-bit digits, most significant first; `prefix` holds the digits fixed so far
-        unsigned long long thr = 1ull;          // accept everything below hi_bound unless narrowed
-        int above = 0;                          // keys strictly above the current prefix's bin range
-        {
-            unsigned long long prefix = 0ull;
-            int shift = 64;                     // bits [shift, 64) are fixed by `prefix`
-            bool narrowed = true;
-            while (narrowed && shift > 0) {
-                const int bits = shift >= kDigitBits ? kDigitBits : shift;
-                const int dshift = shift - bits;
-                for (int i = tid; i < kBins; i += kNmsThreads) hist[i] = 0u;
-                __syncthreads();
-                for (int i = tid; i < N; i += kNmsThreads) {
-                    const unsigned long long key = make_key(sc[(size_t)i * C], p.score_thr, i);
-                    if (key != 0ull && key < hi_bound && (shift == 64 || (key >> shift) == (prefix >> shift)))
-                        atomicAdd(&hist[(unsigned)(key >> dshift) & ((1u << bits) - 1u)], 1u);
-                }
-                __syncthreads();
-                // wave 0: suffix sums over the (1 << bits) bins, top digit first; find the digit where the
-                // running count reaches the target
-                if (tid < 64) {
-                    const int nb = 1 << bits;
-                    const int per = (nb + 63) / 64;                       // bins per lane, lane 0 = top bins
-                    const int top = nb - 1 - lane * per;                  // this lane's highest bin
-                    unsigned mine = 0u;
-                    for (int k = 0; k < per; ++k)
-                        if (top - k >= 0) mine += hist[top - k];
-                    unsigned incl = mine;                                 // inclusive scan over lanes (top first)
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const unsigned v = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += v;
-                    }
-                    const unsigned total = __shfl(incl, 63, 64);
-                    const int want = kBandTarget - above;                 // still needed from this prefix
-                    const unsigned excl = incl - mine;
-                    // the lane whose range contains the crossing (or the last non-empty lane if total < want)
-                    const bool cross = (int)excl < want && (int)incl >= want;
-                    const unsigned long long bal = __ballot(cross);
-                    if (total == 0u) {
-                        if (lane == 0) { ctl[CTL_DIGIT] = -1; ctl[CTL_BINCOUNT] = 0; }
-                    } else if (bal == 0ull) {                             // fewer than `want` keys in total: take all
-                        if (lane == 0) { ctl[CTL_DIGIT] = -2; ctl[CTL_BINCOUNT] = (int)total; }
-                    } else if (cross) {
-                        unsigned run = excl;
-                        int d = top;
-                        for (int k = 0; k < per; ++k) {
-                            d = top - k;
-                            run += hist[d];
-                            if ((int)run >= want) break;
-                        }
-                        ctl[CTL_DIGIT] = d;
-                        ctl[CTL_BINCOUNT] = (int)hist[d];
-                        ctl[CTL_ABOVE] = above + (int)(run - hist[d]);    // keys above bin d (all levels)
-                    }
-                }
-                __syncthreads();
-                const int digit = ctl[CTL_DIGIT];
-                const int bin_count = ctl[CTL_BINCOUNT];
-                if (first_band && shift == 64) {                          // level 0 sees every candidate once
-                    // ncand is only needed to know whether anything is left after a band
-                }
-                if (digit == -1) {                   // no candidate below hi_bound at all
-                    thr = 0ull;
-                    narrowed = false;
-                } else if (digit == -2) {            // everything (within prefix) fits the target: take all of it
-                    thr = (shift == 64) ? 1ull : (prefix & ~((1ull << shift) - 1ull));
-                    if (thr == 0ull) thr = 1ull;
-                    above += bin_count;
-                    narrowed = false;
-                } else {
-                    above = ctl[CTL_ABOVE];
-                    prefix = (shift == 64 ? 0ull : (prefix & ~((1ull << shift) - 1ull))) |
-                             ((unsigned long long)(unsigned)digit << dshift);
-                    shift = dshift;
-                    thr = prefix;                    // accept the whole bin `digit` ...
-                    if (above + bin_count <= kBandCap || shift == 0) {
-                        above += bin_count;
-                        narrowed = false;            // ... if the band still fits; otherwise refine inside it
-                    }
-                }
-                __syncthreads();
-            }
-            if (thr == 0ull && above == 0) break;    // nothing left
-            if (thr == 0ull) thr = 1ull;
-        }
-        first_band = false;
+        int band_expected = 0;
+        const unsigned long long thr = radix_select<kNmsThreads>(
+            [&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound, kBandTarget, kBandCap, hist,
+            ctl + CTL_SEL, &band_expected);
+        if (thr == 0ull) break;              // nothing left
 
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
         if (tid == 0) ctl[CTL_BANDN] = 0;

@@ -35,3 +35,50 @@ def get_hyper_params(backbone, **kwargs):
     params.update({k: v for k, v in kwargs.items() if k in params and v})
     params["anchor_count"] = len(params["anchor_ratios"]) * len(params["anchor_scales"])
     return params
+
+
+def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, random_pos=None, random_neg=None):
+    """Training targets for one batch on the device -- utils/train_utils.py:84-144 (with
+    ``randomly_select_xyz_mask``, :50-65).
+
+    anchors (A,4); gt_boxes (B,G,4) padded with zeros; gt_labels (B,G) int, -1 = padding.
+    Returns (bbox_deltas (B,A,4), bbox_labels (B,F,F,K)) with labels 1 (positive), 0 (negative), -1 (ignored).
+    The reference draws two ``tf.random.uniform`` int tensors to subsample positives / negatives; pass them as
+    ``random_pos`` / ``random_neg`` ((B,A) int32 >= 1) for reproducible results, otherwise they come from torch's
+    generator.  The (B,A,G) IoU map is never materialised.
+    """
+    import torch
+
+    from .. import _lib as L
+    g, was_np = L.to_device(gt_boxes)
+    a, _ = L.to_device(anchors)
+    lab, _ = L.to_device(gt_labels, dtype=torch.int32)
+    if g.dim() != 3 or g.shape[-1] != 4 or tuple(lab.shape) != tuple(g.shape[:2]) or a.dim() != 2 or a.shape[-1] != 4:
+        raise ValueError("expected anchors (A,4), gt_boxes (B,G,4), gt_labels (B,G); got %s %s %s"
+                         % (tuple(a.shape), tuple(g.shape), tuple(lab.shape)))
+    B, G, A = int(g.shape[0]), int(g.shape[1]), int(a.shape[0])
+    fm, K = int(hyper_params["feature_map_shape"]), int(hyper_params["anchor_count"])
+    if fm * fm * K != A:
+        raise ValueError("anchors (%d) do not match feature_map_shape^2 * anchor_count (%d)" % (A, fm * fm * K))
+    total_pos, total_neg = int(hyper_params["total_pos_bboxes"]), int(hyper_params["total_neg_bboxes"])
+    maxval = max(2, (total_pos + total_neg) * 10)
+    rp = (L.to_device(random_pos, dtype=torch.int32)[0] if random_pos is not None
+          else torch.randint(1, maxval, (B, A), dtype=torch.int32, device="cuda"))
+    rn = (L.to_device(random_neg, dtype=torch.int32)[0] if random_neg is not None
+          else torch.randint(1, maxval, (B, A), dtype=torch.int32, device="cuda"))
+    if tuple(rp.shape) != (B, A) or tuple(rn.shape) != (B, A):
+        raise ValueError("random_pos / random_neg must be (B, A)")
+    deltas = torch.empty((B, A, 4), dtype=torch.float32, device="cuda")
+    labels = torch.empty((B, A), dtype=torch.float32, device="cuda")
+    if B > 0:
+        if G == 0:
+            raise ValueError("gt_boxes needs at least one (possibly padded) row per image")
+        lib = L.lib()
+        ws_bytes = int(lib.rpn_targets_workspace_bytes(B, A, G))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device="cuda")
+        _keep, vptr = L.host_floats(hyper_params["variances"])
+        st = lib.rpn_rpn_targets(L.ptr(a), L.ptr(g), L.ptr(lab), B, A, G, total_pos, total_neg, vptr, L.ptr(rp), L.ptr(rn),
+                                 L.ptr(deltas), L.ptr(labels), L.ptr(ws), ws_bytes, L.stream_ptr())
+        L.check(st, "calculate_rpn_actual_outputs")
+    labels = labels.view(B, fm, fm, K)
+    return L.from_device(deltas, was_np), L.from_device(labels, was_np)
