@@ -62,6 +62,12 @@ inline size_t split_weight_bytes(int Cin, int Cout) { return (size_t)9 * (Cin / 
 int split_weight_shift(const float *hwio, size_t count, bool f16);
 void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
                              int shift, unsigned short *dst);
+// 16x16x32-MFMA variant: weights in "split32" packing [Cin/32][9][cout_pad][128 B] (same byte count)
+void pack_weights_split32_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
+                               int shift, unsigned short *dst);
+hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                  int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
+                                  bool pool, hipStream_t s);
 hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, void *out, hipStream_t s);
 hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, float *out, hipStream_t s);
 hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);

@@ -375,6 +375,271 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
 }
 
+// ---- 16x16x32-MFMA variant -----------------------------------------------------------------------------
+// Same algorithm on v_mfma_f32_16x16x32_{f16,bf16}: on MI355X the chip holds a higher clock on this MFMA shape
+// than on 32x32x16 under load, so equal cycles per flop turn into more flops per second.  K = 32 per MFMA, so the
+// K-slice is 32 channels: 8 x 32 px x 128 ch tile, 8 waves (512 threads, each 64 px x 64 ch = 4 x 4 MFMA tiles),
+// one workgroup per CU (136 KB LDS: two halo buffers of 340 px x 128 B, one weight buffer of 3 taps x 128 x 128 B).
+// LDS rows hold 8 pieces [hi k0-7, hi k8-15, hi k16-23, hi k24-31, lo ...] XOR-swizzled by (column >> 1) & 7
+// (resp. (n >> 1) & 7): every ds_read_b128 fragment read is conflict-free.  Weights use the "split32" packing
+// [Cin/32][9][cout_pad][128 B] in that piece order; activations stay SPLIT16 in HBM (pieces re-ordered on staging).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16, bool POOL>
+__global__ void __launch_bounds__(512, 2)
+conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int NT = 512, TH = 8, BN = 128;
+    constexpr int HP = (TH + 2) * HW;                 // 340 halo pixels
+    constexpr int PPP = 8;                            // 16-byte pieces per 32-channel row
+    constexpr int ABUF = HP * PPP + 8;                // + dummy slot for idle lanes
+    constexpr int A_PIECES = HP * PPP;                // 2720
+    constexpr int A_RPS = 2, A_SLOTS = 6;             // 6 rounds of 512 >= 2720, two per step
+    constexpr int B_PIECES = 3 * BN * PPP;            // 3072 = one filter row of 32-channel weight rows
+    constexpr int B_ROUNDS = B_PIECES / NT;           // 6
+    constexpr int STAGE_LD = 64 + kStagePad;
+    constexpr int LDS_PIPE = 2 * ABUF + B_PIECES;
+    constexpr int LDS_STAGE = (8 * 32 * STAGE_LD * 4 + 15) / 16;
+    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
+    static_assert(A_SLOTS * NT >= A_PIECES && B_PIECES % NT == 0, "staging rounds");
+
+    __shared__ uint4 lds[LDS_UINT4];
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: rows {2wm, 2wm+1}, channels [64wn, +64)
+    const int lr = lane & 15, kg = lane >> 4;         // fragment row / k-group (8 channels) of this lane
+
+    int nt, mt;
+    {
+        const int m_tiles = tiles_x * tiles_y * a.B;
+        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+        const int NTl = (n_tiles + XN - 1) / XN;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nt = (slot % NTl) * XN + (xcd % XN);
+        mt = (slot / NTl) * XM + (xcd / XN);
+        if (nt >= n_tiles || mt >= m_tiles) return;
+    }
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
+
+    const int chunks = a.Cin >> 5;                    // 32-channel slices
+    const int steps = chunks * 3;
+    const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
+    const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
+    unsigned a_goff[A_SLOTS];
+    int a_loff[A_SLOTS];
+#pragma unroll
+    for (int R = 0; R < A_SLOTS; ++R) {
+        const int e = R * NT + tid;
+        const int pix = e >> 3, q = e & 7;            // q: piece of the pixel's 128-byte (2 x SPLIT16 record) slice
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool piece = e < A_PIECES;
+        const bool inimg = piece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int kgq = (q >> 2) * 2 + ((q >> 1) & 1), lo = q & 1;     // SPLIT16 record order -> (k-group, lo)
+        a_loff[R] = piece ? (pix * PPP + ((lo * 4 + kgq) ^ ((hx >> 1) & 7))) : HP * PPP;
+        a_goff[R] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + q) * 16) : kOob;
+    }
+    u32x4 b_reg[B_ROUNDS];
+    u32x4 a_reg[A_RPS];
+#define RPN16_LOAD_B(STEP)                                                                                   \
+    {                                                                                                        \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(a.w) + ((size_t)(STEP) * 3 * a.cout_pad + n0) * PPP; \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
+            const int e_ = tid + i_ * NT;                                                                    \
+            const int t_ = e_ >> 10, rem_ = e_ & 1023;                                                       \
+            b_reg[i_] = src_[(size_t)t_ * a.cout_pad * PPP + rem_];                                          \
+        }                                                                                                    \
+    }
+#define RPN16_STORE_B()                                                                                      \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
+            const int e_ = tid + i_ * NT;                                                                    \
+            const int t_ = e_ >> 10, rem_ = e_ & 1023;                                                       \
+            const int n_ = rem_ >> 3, pc_ = rem_ & 7;                                                        \
+            Bs[(t_ * BN + n_) * PPP + (pc_ ^ ((n_ >> 1) & 7))] = b_reg[i_];                                  \
+        }                                                                                                    \
+    }
+#define RPN16_LOAD_A(CHUNK, R) \
+    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 128, 0))
+
+    f32x4 acc[4][4];                                  // [M-tile = row i * 2 + half][N-tile j]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int a_off[3][2];                                  // [tap column s][16-px half]: lane-constant
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = 16 * hf + lr + s3;
+            a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
+        }
+    int b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + lr;
+        b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
+    }
+
+#pragma unroll
+    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN16_LOAD_A(0, R);
+    RPN16_LOAD_B(0);
+    RPN16_STORE_B();
+    __syncthreads();
+
+    int abuf = 0;
+#pragma unroll 1
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const int next_chunk = chunk + 1 < chunks ? chunk + 1 : chunk;
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            const int step = chunk * 3 + row;
+            RPN16_LOAD_B(step + 1 < steps ? step + 1 : step);
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN16_LOAD_A(next_chunk, row * A_RPS + q);
+
+            const u32x4 *arow = As + (abuf * ABUF + (2 * wm + row) * HW * PPP);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                u32x4 ahi[4], alo[4], bhi[4], blo[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {             // m = i * 2 + half
+                    const int idx = (m >> 1) * HW * PPP + a_off[s][m & 1];
+                    ahi[m] = arow[idx];
+                    alo[m] = arow[idx ^ 4];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bhi[j] = Bs[s * BN * PPP + b_off[j]];
+                    blo[j] = Bs[s * BN * PPP + (b_off[j] ^ 4)];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[m][j] = mfma16<F16>(alo[m], bhi[j], acc[m][j]);
+                        acc[m][j] = mfma16<F16>(ahi[m], blo[j], acc[m][j]);
+                        acc[m][j] = mfma16<F16>(ahi[m], bhi[j], acc[m][j]);
+                    }
+            }
+            __syncthreads();                              // every wave is done reading the weight buffer
+            RPN16_STORE_B();
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
+            __syncthreads();
+        }
+        abuf ^= 1;
+    }
+#undef RPN16_LOAD_B
+#undef RPN16_STORE_B
+#undef RPN16_LOAD_A
+
+    // ---- epilogue (as in the 32x32 kernel; C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg) --
+    float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
+    float bias_v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + lr;
+        bias_v[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+    }
+    const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
+    const int cout_chunks = a.Cout >> 4;
+    const int nbase = n0 + wn * 64;
+    auto store_stage = [&](int npx_log2, int oy, int oxb, int OHo, int OWo) {
+        if (oy >= OHo) return;
+        const int rounds = (16 << npx_log2) >> 6;
+        if (a.out_f32) {
+            float *out = reinterpret_cast<float *>(a.out);
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int e = rd * 64 + lane;
+                const int px = e >> 4, q = e & 15;
+                const int ox = oxb + px, n = nbase + 4 * q;
+                if (ox < OWo && n < a.Cout) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
+                    *reinterpret_cast<float4 *>(out + (((size_t)img * OHo + oy) * OWo + ox) * a.Cout + n) = v;
+                }
+            }
+        } else {
+            uint4 *out = reinterpret_cast<uint4 *>(a.out);
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int e = rd * 64 + lane;
+                const int px = e >> 4, q = e & 15;
+                const int ox = oxb + px;
+                const int cl = q >> 2, pc = q & 3;
+                const int n = nbase + cl * 16;
+                if (ox < OWo && n < a.Cout) {
+                    float xs[8];
+                    const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
+                    const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                    xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                    out[((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
+                        split_piece<F16>(xs, (pc & 1) != 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (POOL) {
+        const int OHo = a.H >> 1, OWo = a.W >> 1;     // rows (2wm, 2wm+1) are one pooling row pair
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const float v0 = fmaxf(acc[hf][j][2 * r2], acc[hf][j][2 * r2 + 1]);            // row i = 0
+                    const float v1 = fmaxf(acc[2 + hf][j][2 * r2], acc[2 + hf][j][2 * r2 + 1]);    // row i = 1
+                    const int px2 = 8 * hf + 2 * kg + r2;                                          // pooled column 0..15
+                    stage[px2 * STAGE_LD + j * 16 + lr] = fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + bias_v[j], act_lo), act_hi);
+                }
+        __syncthreads();
+        store_stage(4, (oy0 + 2 * wm) >> 1, ox0 >> 1, OHo, OWo);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int px = 16 * hf + 4 * kg + r;
+                        stage[px * STAGE_LD + j * 16 + lr] =
+                            fminf(fmaxf(acc[i * 2 + hf][j][r] * a.out_scale + bias_v[j], act_lo), act_hi);
+                    }
+            __syncthreads();
+            store_stage(5, oy0 + 2 * wm + i, ox0, a.H, a.W);
+            __syncthreads();
+        }
+    }
+}
+
 // ---- float32 NHWC <-> SPLIT16 ---------------------------------------------------------------
 template <bool F16>
 __global__ void __launch_bounds__(256)
@@ -679,6 +944,37 @@ void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int
             }
 }
 
+// "split32" packing for the 16x16x32-MFMA kernel: [Cin/32][9][cout_pad][8 pieces = hi k0-7, hi k8-15, hi k16-23,
+// hi k24-31, lo k0-7, ...] (128 bytes per output channel, tap and 32-channel slice)
+void pack_weights_split32_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
+                               int shift, unsigned short *dst /* [Cin/32][9][cout_pad][64] */)
+{
+    const int chunks = Cin / 32;
+    const float mul = ldexpf(1.0f, shift);
+    memset(dst, 0, (size_t)9 * chunks * cout_pad * 64 * sizeof(unsigned short));
+    for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < Cin; ++c)
+            for (int n = 0; n < Cout; ++n) {
+                float v = hwio[((size_t)t * Cin + c) * Cout + n];
+                if (scale) v *= scale[n];
+                v *= mul;
+                unsigned short hi, lo;
+                if (f16) {
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    memcpy(&hi, &h, 2);
+                    memcpy(&lo, &l, 2);
+                } else {
+                    hi = f32_to_bf16_rne(v);
+                    lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+                }
+                const int chunk = c >> 5, kgq = (c >> 3) & 3, k = c & 7;
+                unsigned short *rec = dst + (((size_t)chunk * 9 + t) * cout_pad + n) * 64;
+                rec[kgq * 8 + k] = hi;
+                rec[(4 + kgq) * 8 + k] = lo;
+            }
+}
+
 static int grid_cap(long long items)
 {
     long long g = (items + 255) / 256;
@@ -780,6 +1076,30 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
         default: break;
     }
     return hipErrorInvalidValue;
+}
+
+// 16x16x32-MFMA kernel (weights in "split32" packing).  Needs Cin % 32 == 0 and cout_pad % 128 == 0.
+hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                  int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
+                                  bool pool, hipStream_t s)
+{
+    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 128 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
+    SplitConvArgs a{};
+    a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
+    a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
+    const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8;
+    const int n_tiles = (Cout + 127) / 128;
+    const long long m_tiles = (long long)tiles_x * tiles_y * B;
+    const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+    const long long nblocks = 8ll * ((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
+    if (m_tiles <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+#define RPN_L16(F16_, POOL_) \
+    hipLaunchKernelGGL((conv3x3_split16_kernel<F16_, POOL_>), dim3((unsigned)nblocks), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles)
+    if (f16) { if (pool) RPN_L16(true, true); else RPN_L16(true, false); }
+    else     { if (pool) RPN_L16(false, true); else RPN_L16(false, false); }
+#undef RPN_L16
+    return hipGetLastError();
 }
 
 // 3x3 stride-1 'same' conv on SPLIT16 input (optionally followed by a fused 2x2 'valid' max-pool).

@@ -10,6 +10,7 @@
 // pass is a fixed sequence of kernel launches on the caller's stream: no allocation, no
 // synchronisation, so it can be captured into a hipGraph by the caller.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct Op {
     std::vector<int> params;
     bool cin3 = false;                 // first layer (Cin = 3, 3x3): direct vector-ALU kernel
     bool split = false;                // runs on the x3-split 16-bit MFMA kernel (SPLIT16 input)
+    bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
 };
@@ -81,6 +83,16 @@ struct rpn_model {
 };
 
 namespace rpn {
+
+// the 16x16x32-MFMA split kernel (one 512-thread workgroup per CU on 8 x 32 px x 128 ch tiles) is used where the
+// grid fills the chip; RPN_SPLIT_MFMA16=0 switches it off, =1 (default) on
+static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
+{
+    static const int mode = getenv("RPN_SPLIT_MFMA16") ? atoi(getenv("RPN_SPLIT_MFMA16")) : 0;
+    if (!mode || Cin % 32 != 0 || Cout <= 64) return false;
+    const long long blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
+    return blocks >= 256;
+}
 
 static int add_tensor(rpn_model *m, const std::string &name, int H, int W, int C, bool external = false)
 {
@@ -129,6 +141,7 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
     op.ps = packed_shape(R, R, ti.C, Cout);
+    op.k16 = split && use_mfma16(ti.C, Cout, ti.H, ti.W, m->max_batch);
     op.out = add_tensor(m, name, OH, OW, Cout);
     m->tensors[op.out].split_fmt = (split && !force_f32_out) || (op.cin3 && cin3_out_split);
     m->ops.push_back(op);
@@ -506,8 +519,12 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
         const int cpad = split_cout_pad(op.Cout);
         const int wshift = split_weight_shift(kernel, (size_t)9 * p.Cin * p.Cout, m->f16);
         std::vector<unsigned short> packed(split_weight_bytes(op.Cin, op.Cout) / sizeof(unsigned short));
-        pack_weights_split_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
-                                packed.data());
+        if (op.k16)
+            pack_weights_split32_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
+                                      packed.data());
+        else
+            pack_weights_split_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
+                                    packed.data());
         op.out_scale = ldexpf(1.0f, -wshift);
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(unsigned short),
                                 hipMemcpyHostToDevice));
@@ -569,9 +586,9 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                                  m->tensors[op.out].split_fmt ? 1 : 0, m->f16, s);
         } else if (op.kind == OP_CONV && op.split) {
             const int dst = fuse_pool ? m->ops[oi + 1].out : op.out;
-            e = launch_conv3x3_split(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
-                                     tensor_ptr(m, dst, d_imgs), B, op.H, op.W, op.Cin, op.Cout,
-                                     split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, fuse_pool, s);
+            e = (op.k16 ? launch_conv3x3_split16 : launch_conv3x3_split)(
+                x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, dst, d_imgs), B, op.H, op.W, op.Cin,
+                op.Cout, split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, fuse_pool, s);
             skip_next = fuse_pool;
         } else if (op.kind == OP_POOL && op.split) {
             e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
@@ -642,7 +659,7 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_CONV && op.split) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
         by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
-        k = m->f16 ? "conv3x3_split<f16x3>" : "conv3x3_split<bf16x3>";
+        k = m->f16 ? "conv3x3_split<f16x3>" : "conv3x3_split<bf16x3>";     // (16x16x32- and 32x32x16-MFMA variants)
     } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
         fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
         by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
@@ -741,15 +758,17 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         const int cpad = split_cout_pad(Cout);
         const int wshift = split_weight_shift(hw.data(), wcount, f16);
         std::vector<unsigned short> packed(split_weight_bytes(Cin, Cout) / 2);
-        pack_weights_split_host(hw.data(), nullptr, Cin, Cout, cpad, f16, wshift, packed.data());
+        const bool k16 = use_mfma16(Cin, Cout, H, W, B);
+        if (k16) pack_weights_split32_host(hw.data(), nullptr, Cin, Cout, cpad, f16, wshift, packed.data());
+        else pack_weights_split_host(hw.data(), nullptr, Cin, Cout, cpad, f16, wshift, packed.data());
         void *d_ws = nullptr, *d_xs = nullptr;
         hipError_t e = hipMalloc(&d_ws, packed.size() * 2);
         if (e == hipSuccess) e = hipMalloc(&d_xs, (size_t)B * H * W * Cin * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(d_ws, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
         if (e == hipSuccess)
-            e = launch_conv3x3_split(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad, ldexpf(1.0f, -wshift), act,
-                                     true, f16, false, s);
+            e = (k16 ? launch_conv3x3_split16 : launch_conv3x3_split)(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad,
+                                                                      ldexpf(1.0f, -wshift), act, true, f16, false, s);
         const hipError_t e2 = hipStreamSynchronize(s);
         if (d_ws) (void)hipFree(d_ws);                  // freed on every path
         if (d_xs) (void)hipFree(d_xs);
