@@ -394,23 +394,29 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool F16, bool POOL>
-__global__ void __launch_bounds__(512, 2)
+// TH: tile rows (8 | 4); WN: waves along N (2 -> 128 channels, 1 -> 64); NW: waves (8 | 4).  Each wave owns
+// RW = TH / (NW / WN) rows of 32 pixels x 64 channels.  <8,2,8>: one 136 KB workgroup per CU (large layers);
+// <4,1,4>: 77 KB, two workgroups per CU (small feature maps).
+template <int TH, int WN, int NW, bool F16, bool POOL>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 2)
 conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    constexpr int NT = 512, TH = 8, BN = 128;
-    constexpr int HP = (TH + 2) * HW;                 // 340 halo pixels
+    constexpr int NT = 64 * NW, BN = 64 * WN;
+    constexpr int WM = NW / WN, RW = TH / WM;          // rows of 32 pixels per wave
+    constexpr int MT = RW * 2;                         // 16-pixel MFMA tiles per wave along M
+    constexpr int HP = (TH + 2) * HW;                 // halo pixels
     constexpr int PPP = 8;                            // 16-byte pieces per 32-channel row
     constexpr int ABUF = HP * PPP + 8;                // + dummy slot for idle lanes
-    constexpr int A_PIECES = HP * PPP;                // 2720
-    constexpr int A_RPS = 2, A_SLOTS = 6;             // 6 rounds of 512 >= 2720, two per step
-    constexpr int B_PIECES = 3 * BN * PPP;            // 3072 = one filter row of 32-channel weight rows
-    constexpr int B_ROUNDS = B_PIECES / NT;           // 6
+    constexpr int A_PIECES = HP * PPP;
+    constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT;
+    constexpr int A_RPS = (A_ROUNDS + 2) / 3, A_SLOTS = 3 * A_RPS;
+    constexpr int B_PIECES = 3 * BN * PPP;            // one filter row of 32-channel weight rows
+    constexpr int B_ROUNDS = B_PIECES / NT;
     constexpr int STAGE_LD = 64 + kStagePad;
     constexpr int LDS_PIPE = 2 * ABUF + B_PIECES;
-    constexpr int LDS_STAGE = (8 * 32 * STAGE_LD * 4 + 15) / 16;
+    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;
     constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
-    static_assert(A_SLOTS * NT >= A_PIECES && B_PIECES % NT == 0, "staging rounds");
+    static_assert(RW * WM == TH && RW >= 1 && B_PIECES % NT == 0 && (!POOL || RW == 2), "tile shape");
 
     __shared__ uint4 lds[LDS_UINT4];
     u32x4 *As = reinterpret_cast<u32x4 *>(lds);
@@ -419,7 +425,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: rows {2wm, 2wm+1}, channels [64wn, +64)
+    const int wm = wave / WN, wn = wave % WN;         // rows [RW*wm, +RW), channels [64wn, +64)
     const int lr = lane & 15, kg = lane >> 4;         // fragment row / k-group (8 channels) of this lane
 
     int nt, mt;
@@ -467,7 +473,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         const u32x4 *src_ = reinterpret_cast<const u32x4 *>(a.w) + ((size_t)(STEP) * 3 * a.cout_pad + n0) * PPP; \
         _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
             const int e_ = tid + i_ * NT;                                                                    \
-            const int t_ = e_ >> 10, rem_ = e_ & 1023;                                                       \
+            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
             b_reg[i_] = src_[(size_t)t_ * a.cout_pad * PPP + rem_];                                          \
         }                                                                                                    \
     }
@@ -475,7 +481,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     {                                                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
             const int e_ = tid + i_ * NT;                                                                    \
-            const int t_ = e_ >> 10, rem_ = e_ & 1023;                                                       \
+            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
             const int n_ = rem_ >> 3, pc_ = rem_ & 7;                                                        \
             Bs[(t_ * BN + n_) * PPP + (pc_ ^ ((n_ >> 1) & 7))] = b_reg[i_];                                  \
         }                                                                                                    \
@@ -483,9 +489,9 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #define RPN16_LOAD_A(CHUNK, R) \
     __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 128, 0))
 
-    f32x4 acc[4][4];                                  // [M-tile = row i * 2 + half][N-tile j]
+    f32x4 acc[MT][4];                                 // [M-tile = row i * 2 + half][N-tile j]
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -521,12 +527,12 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN16_LOAD_A(next_chunk, row * A_RPS + q);
 
-            const u32x4 *arow = As + (abuf * ABUF + (2 * wm + row) * HW * PPP);
+            const u32x4 *arow = As + (abuf * ABUF + (RW * wm + row) * HW * PPP);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                u32x4 ahi[4], alo[4], bhi[4], blo[4];
+                u32x4 ahi[MT], alo[MT], bhi[4], blo[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {             // m = i * 2 + half
+                for (int m = 0; m < MT; ++m) {            // m = i * 2 + half
                     const int idx = (m >> 1) * HW * PPP + a_off[s][m & 1];
                     ahi[m] = arow[idx];
                     alo[m] = arow[idx ^ 4];
@@ -537,7 +543,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     blo[j] = Bs[s * BN * PPP + (b_off[j] ^ 4)];
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[m][j] = mfma16<F16>(alo[m], bhi[j], acc[m][j]);
@@ -606,7 +612,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     };
 
     if constexpr (POOL) {
-        const int OHo = a.H >> 1, OWo = a.W >> 1;     // rows (2wm, 2wm+1) are one pooling row pair
+        const int OHo = a.H >> 1, OWo = a.W >> 1;     // RW == 2: rows (2wm, 2wm+1) are one pooling row pair
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -614,7 +620,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
                     const float v0 = fmaxf(acc[hf][j][2 * r2], acc[hf][j][2 * r2 + 1]);            // row i = 0
-                    const float v1 = fmaxf(acc[2 + hf][j][2 * r2], acc[2 + hf][j][2 * r2 + 1]);    // row i = 1
+                    const float v1 = fmaxf(acc[(MT - 2) + hf][j][2 * r2], acc[(MT - 2) + hf][j][2 * r2 + 1]);    // row i = 1
                     const int px2 = 8 * hf + 2 * kg + r2;                                          // pooled column 0..15
                     stage[px2 * STAGE_LD + j * 16 + lr] = fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
@@ -622,7 +628,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         store_stage(4, (oy0 + 2 * wm) >> 1, ox0 >> 1, OHo, OWo);
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RW; ++i) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -634,7 +640,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                             fminf(fmaxf(acc[i * 2 + hf][j][r] * a.out_scale + bias_v[j], act_lo), act_hi);
                     }
             __syncthreads();
-            store_stage(5, oy0 + 2 * wm + i, ox0, a.H, a.W);
+            store_stage(5, oy0 + RW * wm + i, ox0, a.H, a.W);
             __syncthreads();
         }
     }
@@ -1088,16 +1094,27 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
-    const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8;
-    const int n_tiles = (Cout + 127) / 128;
+    // large grids: 8 x 32 px x 128 ch tiles, one 8-wave workgroup per CU; small feature maps (no pooling there):
+    // 4 x 32 px x 64 ch tiles, 4 waves, two workgroups per CU
+    const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
+    const bool small = big_blocks < 256 && !pool;
+    const int TH = small ? 4 : 8, BN = small ? 64 : 128;
+    const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + TH - 1) / TH;
+    const int n_tiles = (Cout + BN - 1) / BN;
     const long long m_tiles = (long long)tiles_x * tiles_y * B;
     const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
     const long long nblocks = 8ll * ((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
     if (m_tiles <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-#define RPN_L16(F16_, POOL_) \
-    hipLaunchKernelGGL((conv3x3_split16_kernel<F16_, POOL_>), dim3((unsigned)nblocks), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles)
-    if (f16) { if (pool) RPN_L16(true, true); else RPN_L16(true, false); }
-    else     { if (pool) RPN_L16(false, true); else RPN_L16(false, false); }
+#define RPN_L16(TH_, WN_, NW_, F16_, POOL_)                                                                          \
+    hipLaunchKernelGGL((conv3x3_split16_kernel<TH_, WN_, NW_, F16_, POOL_>), dim3((unsigned)nblocks), dim3(64 * NW_), 0, s, \
+                       a, tiles_x, tiles_y, n_tiles)
+    if (small) {
+        if (f16) RPN_L16(4, 1, 4, true, false); else RPN_L16(4, 1, 4, false, false);
+    } else if (f16) {
+        if (pool) RPN_L16(8, 2, 8, true, true); else RPN_L16(8, 2, 8, true, false);
+    } else {
+        if (pool) RPN_L16(8, 2, 8, false, true); else RPN_L16(8, 2, 8, false, false);
+    }
 #undef RPN_L16
     return hipGetLastError();
 }
