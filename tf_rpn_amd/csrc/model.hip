@@ -84,16 +84,14 @@ struct rpn_model {
 
 namespace rpn {
 
-// the 16x16x32-MFMA split kernel (one 512-thread workgroup per CU on 8 x 32 px x 128 ch tiles) is used where the
-// grid fills the chip; RPN_SPLIT_MFMA16=0 switches it off, =1 (default) on
+// The 16x16x32-MFMA split kernel is used for every eligible layer with Cin >= 128 (RPN_SPLIT_MFMA16=0 switches it
+// off).  Measured on VGG16, batch 8 (A/B in one process, same box): +4 % at Cin = 128, +8-12 % at Cin >= 256 on the
+// 8 x 32 px x 128 ch tiles, +20 % on the 31 x 31 layers (4 x 32 px x 64 ch tiles), -3 % at Cin = 64 (2 slices only).
 static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
 {
     static const int mode = getenv("RPN_SPLIT_MFMA16") ? atoi(getenv("RPN_SPLIT_MFMA16")) : 1;
-    // measured (VGG16, batch 8): +4 % at Cin = 128, +8-12 % at Cin >= 256, -3 % at Cin = 64 (only 2 slices of 32)
-    if (!mode || Cin % 32 != 0 || Cin < 128 || Cout <= 64) return false;
-    if (mode == 2) return true;                                       // experiment: also the small-map variant
-    const long long blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
-    return blocks >= 256;
+    (void)H; (void)W; (void)B;
+    return mode != 0 && Cin % 32 == 0 && Cin >= 128 && Cout > 64;
 }
 
 static int add_tensor(rpn_model *m, const std::string &name, int H, int W, int C, bool external = false)
