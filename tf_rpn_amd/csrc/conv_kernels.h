@@ -81,4 +81,11 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
                             int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
                             hipStream_t s);
 
+// first layer on the matrix cores (split precisions only): Cout in {32, 64}; w = pack_weights_cin3_mfma_host output
+void pack_weights_cin3_mfma_host(const float *hwio, const float *scale, int Cout, int cout_pad, bool f16, int shift,
+                                 unsigned short *dst);
+hipError_t launch_conv_cin3_mfma(const float *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                 int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, float out_scale,
+                                 int out_fmt, bool f16, hipStream_t s);
+
 }  // namespace rpn

@@ -646,6 +646,180 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
 }
 
+static inline unsigned short f32_to_bf16_rne(float f);
+static inline float bf16_to_f32(unsigned short h);
+
+// ---- first layer on the matrix cores (split-precision modes) ---------------------------------------------------
+// Cin = 3, 3x3: K = 27 is padded to 32 = ONE v_mfma_f32_16x16x32 step.  Workgroup = 8 x 32 output pixels x Cout
+// (Cout = 16 * NTILES <= 64), 4 waves, each 2 rows.  The float32 input patch is staged in LDS; every lane gathers
+// the 8 patch values of its (pixel, k-group) from LDS and splits them into hi / lo halves on the fly (the A
+// fragment of the im2col matrix, never materialised); the pre-split weights are read from LDS once and stay in
+// registers.  3 MFMAs per (16 px x 16 ch) tile.  ~4x fewer vector-ALU instructions per output than the direct
+// kernel, so the layer becomes bound by its 4*Cout bytes per pixel of output.
+template <bool F16, bool OUT_SPLIT, int STRIDE, int NTILES>
+__global__ void __launch_bounds__(256)
+conv_cin3_mfma_kernel(const float *__restrict__ x, const uint4 *__restrict__ w /* [Cout_pad][8 pieces] */,
+                      const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
+                      int pad_t, int pad_l, int act, float out_scale, int tiles_x, int tiles_y)
+{
+    constexpr int COUT = 16 * NTILES;
+    constexpr int PR = 7 * STRIDE + 3, PC = 31 * STRIDE + 3;            // input patch rows / columns
+    constexpr int PATCH = PR * PC * 3;
+    constexpr int STAGE_LD = COUT + kStagePad;
+    __shared__ __attribute__((aligned(16))) float patch[(PATCH + 3) / 4 * 4];
+    __shared__ uint4 wl[COUT * 8];
+    __shared__ __attribute__((aligned(16))) float stage_all[4 * 32 * STAGE_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, kg = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int img = t / tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const float *ximg = x + (size_t)img * H * W * 3;
+
+    for (int e = tid; e < PATCH; e += 256) {                             // patch rows are contiguous in the image
+        const int pr = e / (PC * 3), rem = e - pr * (PC * 3);
+        const int iy = iy0 + pr, ix = ix0 + rem / 3;
+        patch[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ximg[((size_t)iy * W + ix) * 3 + rem % 3] : 0.0f;
+    }
+    for (int e = tid; e < COUT * 8; e += 256) {
+        const int n = e >> 3, pc = e & 7;
+        reinterpret_cast<u32x4 *>(wl)[n * 8 + (pc ^ ((n >> 1) & 7))] = reinterpret_cast<const u32x4 *>(w)[e];
+    }
+    // k = 8 kg + j = (r * 3 + s) * 3 + c  ->  offset inside the patch relative to the pixel's top-left input
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * kg + j;
+        koff[j] = k < 27 ? (k / 9) * (PC * 3) + (k % 9) : -1;
+    }
+    __syncthreads();
+
+    u32x4 bhi[NTILES], blo[NTILES];
+#pragma unroll
+    for (int j = 0; j < NTILES; ++j) {
+        const int n = j * 16 + lr;
+        const int idx = n * 8 + (kg ^ ((n >> 1) & 7));
+        bhi[j] = reinterpret_cast<const u32x4 *>(wl)[idx];
+        blo[j] = reinterpret_cast<const u32x4 *>(wl)[idx ^ 4];
+    }
+    f32x4 acc[4][NTILES];                                                // [row i * 2 + half][N tile]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int prow = (2 * wave + (m >> 1)) * STRIDE, pcol = (16 * (m & 1) + lr) * STRIDE;
+        const int base = (prow * PC + pcol) * 3;
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = koff[j] >= 0 ? patch[base + koff[j]] : 0.0f;
+        const u32x4 ahi = __builtin_bit_cast(u32x4, split_piece<F16>(xs, false));
+        const u32x4 alo = __builtin_bit_cast(u32x4, split_piece<F16>(xs, true));
+#pragma unroll
+        for (int j = 0; j < NTILES; ++j) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+            c = mfma16<F16>(alo, bhi[j], c);
+            c = mfma16<F16>(ahi, blo[j], c);
+            acc[m][j] = mfma16<F16>(ahi, bhi[j], c);
+        }
+    }
+
+    float *stage = stage_all + wave * (32 * STAGE_LD);
+    float bias_v[NTILES];
+#pragma unroll
+    for (int j = 0; j < NTILES; ++j) bias_v[j] = bias ? bias[j * 16 + lr] : 0.0f;
+    const float act_lo = act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = act == ACT_RELU6 ? 6.0f : INFINITY;
+    constexpr int PPX = COUT / 4;                                        // 16-byte pieces per pixel (both formats)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < NTILES; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stage[(16 * hf + 4 * kg + r) * STAGE_LD + j * 16 + lr] =
+                        fminf(fmaxf(acc[i * 2 + hf][j][r] * out_scale + bias_v[j], act_lo), act_hi);
+        __syncthreads();
+        const int oy = oy0 + 2 * wave + i;
+        if (oy < OH) {
+            for (int e = lane; e < 32 * PPX; e += 64) {
+                const int px = e / PPX, q = e - px * PPX;
+                const int ox = ox0 + px;
+                if (ox >= OW) continue;
+                const size_t pix = ((size_t)img * OH + oy) * OW + ox;
+                if constexpr (OUT_SPLIT) {
+                    const int cl = q >> 2, pc = q & 3;
+                    float xs[8];
+                    const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
+                    const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                    xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                    reinterpret_cast<uint4 *>(out)[pix * PPX + q] = split_piece<F16>(xs, (pc & 1) != 0);
+                } else {
+                    reinterpret_cast<float4 *>(out)[pix * PPX + q] =
+                        *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// weights of the MFMA first layer: HWIO (3,3,3,Cout) -> [cout_pad][8 pieces] (k = (r*3+s)*3+c, zero for k >= 27)
+void pack_weights_cin3_mfma_host(const float *hwio, const float *scale, int Cout, int cout_pad, bool f16, int shift,
+                                 unsigned short *dst /* [cout_pad][64] */)
+{
+    const float mul = ldexpf(1.0f, shift);
+    memset(dst, 0, (size_t)cout_pad * 64 * sizeof(unsigned short));
+    for (int k = 0; k < 27; ++k)
+        for (int n = 0; n < Cout; ++n) {
+            float v = hwio[(size_t)k * Cout + n];
+            if (scale) v *= scale[n];
+            v *= mul;
+            unsigned short hi, lo;
+            if (f16) {
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);
+                memcpy(&hi, &h, 2);
+                memcpy(&lo, &l, 2);
+            } else {
+                hi = f32_to_bf16_rne(v);
+                lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+            }
+            unsigned short *rec = dst + (size_t)n * 64;
+            rec[(k >> 3) * 8 + (k & 7)] = hi;
+            rec[(4 + (k >> 3)) * 8 + (k & 7)] = lo;
+        }
+}
+
+hipError_t launch_conv_cin3_mfma(const float *x, const void *w, const float *bias, void *out, int B, int H, int W,
+                                 int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, float out_scale,
+                                 int out_fmt, bool f16, hipStream_t s)
+{
+    if ((Cout != 32 && Cout != 64) || (stride != 1 && stride != 2) || act == ACT_SIGMOID) return hipErrorInvalidValue;
+    const int tiles_x = (OW + 31) / 32, tiles_y = (OH + 7) / 8;
+    const long long nblocks = (long long)tiles_x * tiles_y * B;
+    if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+#define RPN_C3M(F16_, SPLIT_, STRIDE_, NT_)                                                                          \
+    hipLaunchKernelGGL((conv_cin3_mfma_kernel<F16_, SPLIT_, STRIDE_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, s, x, \
+                       (const uint4 *)w, bias, out, B, H, W, OH, OW, pad_t, pad_l, act, out_scale, tiles_x, tiles_y)
+#define RPN_C3M_FMT(F16_, STRIDE_, NT_) \
+    { if (out_fmt) RPN_C3M(F16_, true, STRIDE_, NT_); else RPN_C3M(F16_, false, STRIDE_, NT_); }
+#define RPN_C3M_ST(F16_, NT_) \
+    { if (stride == 1) RPN_C3M_FMT(F16_, 1, NT_) else RPN_C3M_FMT(F16_, 2, NT_) }
+    if (f16) { if (Cout == 64) RPN_C3M_ST(true, 4) else RPN_C3M_ST(true, 2) }
+    else     { if (Cout == 64) RPN_C3M_ST(false, 4) else RPN_C3M_ST(false, 2) }
+#undef RPN_C3M_ST
+#undef RPN_C3M_FMT
+#undef RPN_C3M
+    return hipGetLastError();
+}
+
 // ---- float32 NHWC <-> SPLIT16 ---------------------------------------------------------------
 template <bool F16>
 __global__ void __launch_bounds__(256)

@@ -53,7 +53,8 @@ struct Op {
     PackedShape ps{};
     size_t w_off = 0, b_off = 0;       // floats into the weight blob
     std::vector<int> params;
-    bool cin3 = false;                 // first layer (Cin = 3, 3x3): direct vector-ALU kernel
+    bool cin3 = false;                 // first layer (Cin = 3, 3x3): direct vector-ALU kernel ...
+    bool cin3_mfma = false;            // ... or, in the split-precision modes, the one-step MFMA kernel
     bool split = false;                // runs on the x3-split 16-bit MFMA kernel (SPLIT16 input)
     bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
@@ -136,6 +137,8 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     op.split = split;
     op.cin3 = ti.C == 3 && R == 3 && (stride == 1 || stride == 2) && Cout % 16 == 0 && Cout <= 256 &&
               256 % (Cout / 16) == 0 && residual < 0 && act != ACT_SIGMOID;
+    op.cin3_mfma = op.cin3 && m->use_split && (Cout == 32 || Cout == 64) &&
+                   !(getenv("RPN_CIN3_MFMA") && atoi(getenv("RPN_CIN3_MFMA")) == 0);
     op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
@@ -336,7 +339,7 @@ static void plan_weights(rpn_model *m)
     for (auto &op : m->ops) {
         if (op.kind == OP_CONV && op.cin3) {
             op.w_off = off;
-            off += ((size_t)27 * op.Cout + 63) & ~(size_t)63;
+            off += ((size_t)32 * op.Cout + 63) & ~(size_t)63;        // 27 x Cout floats, or Cout x 128 B of split records
             op.b_off = off;
             off += ((size_t)op.Cout + 63) & ~(size_t)63;
         } else if (op.kind == OP_CONV && op.split) {
@@ -507,6 +510,15 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                   hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+    } else if (op.cin3_mfma) {
+        const int wshift = split_weight_shift(kernel, (size_t)27 * p.Cout, m->f16);
+        std::vector<unsigned short> packed((size_t)p.Cout * 64);
+        pack_weights_cin3_mfma_host(kernel, has_bn ? scale.data() : nullptr, p.Cout, p.Cout, m->f16, wshift, packed.data());
+        op.out_scale = ldexpf(1.0f, -wshift);
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(unsigned short),
+                                hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
+                                hipMemcpyHostToDevice));
     } else if (op.cin3) {
         std::vector<float> w((size_t)27 * p.Cout);
         for (int k = 0; k < 27; ++k)
@@ -580,6 +592,10 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             skip_next = false;                      // the pool already ran inside the previous conv
         } else if (op.kind == OP_TOSPLIT) {
             e = launch_f32_to_split(x, (long long)B * op.H * op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
+        } else if (op.kind == OP_CONV && op.cin3_mfma) {
+            e = launch_conv_cin3_mfma(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs),
+                                      B, op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
+                                      op.out_scale, m->tensors[op.out].split_fmt ? 1 : 0, m->f16, s);
         } else if (op.kind == OP_CONV && op.cin3) {
             e = launch_conv_cin3(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs), B,
                                  op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
@@ -655,7 +671,7 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_CONV && op.cin3) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 27.0;
         by = in_b + out_b;
-        k = "conv_cin3_direct";
+        k = op.cin3_mfma ? "conv_cin3_mfma" : "conv_cin3_direct";
     } else if (op.kind == OP_CONV && op.split) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
         by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
