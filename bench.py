@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--serial-nms", action="store_true",
                     help="run decode+NMS on the conv stream (default: NMS of step k overlaps the convs of step k+1 on a "
                          "second HIP stream; every step's work still completes inside the timed region)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise a world-size-1 RCCL group and run the N > 1 code path (record packing + all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
@@ -144,8 +146,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
@@ -159,7 +162,7 @@ def main():
     else:
         hp = dict(train_utils.get_hyper_params(args.backbone))
     weights = synthetic_weights(args.backbone, hp, seed=1)
-    overlap = not args.serial_nms and world == 1     # with N > 1 the all-gather consumes the proposals every step
+    overlap = not args.serial_nms                     # 2-stage pipeline across steps (see Proposer.overlap_nms)
     prop = Proposer(args.backbone, hyper_params=hp, weights=weights, precision=args.precision,
                     max_batch=args.batch, iou_threshold=args.iou_threshold, overlap_nms=overlap)
     B = args.batch
@@ -168,8 +171,12 @@ def main():
     imgs = torch.rand((B, hp["img_size"], hp["img_size"], 3), generator=gen, device="cuda", dtype=torch.float32)
     M = prop.topn
     gathered = torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") if world > 1 else None
+    gather_bufs = [torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") for _ in range(2)]
+    use_dist = world > 1 or args.force_dist
 
     def step():
+        if overlap and use_dist:
+            return prop.propose_distributed_pipelined(imgs, gather_bufs)
         return prop.propose_distributed(imgs, gather_out=gathered)
 
     def fence():
@@ -180,6 +187,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if overlap and use_dist:
+        prop.flush_distributed(gather_bufs)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
     model = prop.rpn_model
     model.set_profiling(args.steps)               # HIP events on the launch stream around every launch of the K steps
@@ -189,6 +198,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if overlap and use_dist:                  # + all-gather of step k-1 behind the convs of step k
+            prop.propose_distributed_pipelined(imgs, gather_bufs)
+            continue
         if overlap:
             prop.propose(imgs)                    # convs on this stream, decode+NMS on the side stream
             continue
@@ -204,7 +216,9 @@ def main():
         if world > 1:
             rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3])
             dist.all_gather_into_tensor(gathered, rec)
-    if overlap:
+    if overlap and use_dist:
+        prop.flush_distributed(gather_bufs)       # the last step's NMS + all-gather finish inside the timed region
+    elif overlap:
         prop.wait()                               # the last step's NMS must finish inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
@@ -270,7 +284,8 @@ def main():
                        "anchors_per_image": prop.total_anchors, "nms_topn": M, "iou_threshold": args.iou_threshold,
                        "weights": "random-init (seeded He-normal)",
                        "parallelism": "image-sharded dp%d, one RCCL all-gather of proposals" % world,
-                       "nms_overlap": "decode+NMS of step k on a second HIP stream, overlapping the convs of step k+1"
+                       "nms_overlap": ("decode+NMS of step k on a second HIP stream, overlapping the convs of step k+1"
+                                       + ("; all-gather of step k-1 issued behind the convs of step k" if use_dist else ""))
                                       if overlap else "serial on the conv stream"},
             "nms_boxes_per_sec": round(B * prop.total_anchors / (nms_ms * 1e-3), 1),
             "roofline": roofline,
@@ -287,7 +302,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -127,3 +127,43 @@ def test_propose_is_graph_capturable():
         torch.cuda.synchronize()
         for o, w in zip(outs, want):
             assert torch.equal(o, w)
+
+
+def test_pipelined_distributed_path_world1():
+    """The N > 1 code path (record packing + all-gather one step behind the convs) on a world-size-1 RCCL group:
+    gathered records must equal the serial proposals, in order, including the flushed last batch."""
+    import socket
+    import torch.distributed as dist
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        hp = dict(bo.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+        weights = synthetic_weights("vgg16", hp, seed=3)
+        serial = Proposer("vgg16", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+        piped = Proposer("vgg16", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3", overlap_nms=True)
+        M = piped.topn
+        gen = torch.Generator().manual_seed(8)
+        batches = [torch.rand((2, 160, 160, 3), generator=gen).cuda() for _ in range(4)]
+        want = []
+        for x in batches:
+            b, s, v, _ = serial.propose(x)
+            want.append(serial.pack_records(b, s, v).clone())
+        bufs = [torch.empty((2, M * 5 + 1), device="cuda") for _ in range(2)]
+        got = []
+        for x in batches:
+            out = piped.propose_distributed_pipelined(x, bufs)
+            if out is not None:
+                got.append(out.clone())
+        got.append(piped.flush_distributed(bufs).clone())
+        torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+        rec = serial.propose_distributed(batches[0])                      # unpipelined helper, world size 1
+        assert torch.equal(rec, want[0])
+    finally:
+        dist.destroy_process_group()

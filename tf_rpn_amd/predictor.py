@@ -114,6 +114,7 @@ class Proposer(object):
             buf["nms_done"].record(self._nms_stream)
         buf["used"] = True
         self._last = buf
+        self._last_batch = B
         return ob, osc, ov, oi
 
     def wait(self):
@@ -155,6 +156,42 @@ class Proposer(object):
     def unpack_records(rec, M):
         B = int(rec.shape[0])
         return (rec[:, :M * 4].reshape(B, M, 4), rec[:, M * 4:M * 5], rec[:, M * 5].to(torch.int32))
+
+    def propose_distributed_pipelined(self, local_imgs, gather_bufs):
+        """Pipelined form for throughput runs (needs ``overlap_nms=True``): this call enqueues the convs of batch k
+        on the current stream and its decode+NMS on the side stream, then -- behind those convs -- packs and
+        all-gathers the records of batch k-1, whose NMS ran concurrently with them.  Returns the gathered records of
+        batch k-1 (None on the first call); ``flush_distributed`` gathers the last batch.  ``gather_bufs``: two
+        (world * B, M*5+1) float32 tensors used alternately.  Every rank must make the same sequence of calls."""
+        import torch.distributed as dist
+        prev = getattr(self, "_last", None) if getattr(self, "_dist_pending", False) else None
+        self.propose(local_imgs)
+        out = self._gather_records(prev, gather_bufs, dist) if prev is not None else None
+        self._dist_pending = True
+        return out
+
+    def flush_distributed(self, gather_bufs):
+        """Gather the records of the last ``propose_distributed_pipelined`` call."""
+        import torch.distributed as dist
+        if not getattr(self, "_dist_pending", False):
+            return None
+        self._dist_pending = False
+        return self._gather_records(self._last, gather_bufs, dist)
+
+    def _gather_records(self, buf, gather_bufs, dist):
+        main = torch.cuda.current_stream()
+        main.wait_event(buf["nms_done"])                                 # that batch's NMS (side stream) is complete
+        B = int(self._last_batch)
+        rec = self.pack_records(buf["boxes"][:B], buf["scores"][:B], buf["valid"][:B])
+        self._gather_slot = getattr(self, "_gather_slot", 0) ^ 1
+        out = gather_bufs[self._gather_slot]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_gather_into_tensor(out, rec)
+        elif dist.is_available() and dist.is_initialized():
+            dist.all_gather_into_tensor(out[:rec.shape[0]], rec)         # world size 1: still exercises RCCL
+        else:
+            out[:rec.shape[0]].copy_(rec)
+        return out
 
     def propose_distributed(self, local_imgs, gather_out=None):
         """Each rank proposes for its slice; one all-gather (RCCL over xGMI when the backend is
