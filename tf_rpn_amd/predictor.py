@@ -158,40 +158,41 @@ class Proposer(object):
         return (rec[:, :M * 4].reshape(B, M, 4), rec[:, M * 4:M * 5], rec[:, M * 5].to(torch.int32))
 
     def propose_distributed_pipelined(self, local_imgs, gather_bufs):
-        """Pipelined form for throughput runs (needs ``overlap_nms=True``): this call enqueues the convs of batch k
-        on the current stream and its decode+NMS on the side stream, then -- behind those convs -- packs and
-        all-gathers the records of batch k-1, whose NMS ran concurrently with them.  Returns the gathered records of
-        batch k-1 (None on the first call); ``flush_distributed`` gathers the last batch.  ``gather_bufs``: two
-        (world * B, M*5+1) float32 tensors used alternately.  Every rank must make the same sequence of calls."""
+        """Pipelined form for throughput runs (needs ``overlap_nms=True``): the convs of batch k run on the current
+        stream; its decode+NMS, the record packing and the all-gather run on the side stream (RCCL orders itself
+        behind that stream), concurrently with the convs of batch k+1.  Returns the gathered records of batch k-1
+        (None on the first call) after making the current stream wait for them; ``flush_distributed`` returns the
+        last batch.  ``gather_bufs``: two (world * B, M*5+1) float32 tensors used alternately.  Every rank must make
+        the same sequence of calls."""
         import torch.distributed as dist
-        prev = getattr(self, "_last", None) if getattr(self, "_dist_pending", False) else None
+        prev = getattr(self, "_dist_last", None)
         self.propose(local_imgs)
-        out = self._gather_records(prev, gather_bufs, dist) if prev is not None else None
-        self._dist_pending = True
-        return out
-
-    def flush_distributed(self, gather_bufs):
-        """Gather the records of the last ``propose_distributed_pipelined`` call."""
-        import torch.distributed as dist
-        if not getattr(self, "_dist_pending", False):
+        buf, B = self._last, int(self._last_batch)
+        slot = getattr(self, "_gather_slot", 0) ^ 1
+        self._gather_slot = slot
+        out = gather_bufs[slot]
+        with torch.cuda.stream(self._nms_stream):                        # behind this batch's NMS
+            rec = self.pack_records(buf["boxes"][:B], buf["scores"][:B], buf["valid"][:B])
+            if dist.is_available() and dist.is_initialized():
+                dist.all_gather_into_tensor(out[:rec.shape[0] * dist.get_world_size()], rec)
+            else:
+                out[:rec.shape[0]].copy_(rec)
+            done = torch.cuda.Event()
+            done.record(self._nms_stream)
+        self._dist_last = (out, done)
+        if prev is None:
             return None
-        self._dist_pending = False
-        return self._gather_records(self._last, gather_bufs, dist)
+        torch.cuda.current_stream().wait_event(prev[1])
+        return prev[0]
 
-    def _gather_records(self, buf, gather_bufs, dist):
-        main = torch.cuda.current_stream()
-        main.wait_event(buf["nms_done"])                                 # that batch's NMS (side stream) is complete
-        B = int(self._last_batch)
-        rec = self.pack_records(buf["boxes"][:B], buf["scores"][:B], buf["valid"][:B])
-        self._gather_slot = getattr(self, "_gather_slot", 0) ^ 1
-        out = gather_bufs[self._gather_slot]
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_gather_into_tensor(out, rec)
-        elif dist.is_available() and dist.is_initialized():
-            dist.all_gather_into_tensor(out[:rec.shape[0]], rec)         # world size 1: still exercises RCCL
-        else:
-            out[:rec.shape[0]].copy_(rec)
-        return out
+    def flush_distributed(self, gather_bufs=None):
+        """Gathered records of the last ``propose_distributed_pipelined`` call (current stream waits for them)."""
+        prev = getattr(self, "_dist_last", None)
+        self._dist_last = None
+        if prev is None:
+            return None
+        torch.cuda.current_stream().wait_event(prev[1])
+        return prev[0]
 
     def propose_distributed(self, local_imgs, gather_out=None):
         """Each rank proposes for its slice; one all-gather (RCCL over xGMI when the backend is
