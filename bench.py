@@ -146,12 +146,6 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
-
     if args.backbone is None:
         args.backbone = "mobilenet_v2" if args.config == "c5" else "vgg16"
     if args.batch is None:
@@ -169,6 +163,17 @@ def main():
     gen = torch.Generator(device="cuda")
     gen.manual_seed(rank)
     imgs = torch.rand((B, hp["img_size"], hp["img_size"], 3), generator=gen, device="cuda", dtype=torch.float32)
+    if world > 1 or args.force_dist:
+        # The communicator is created AFTER the proposer's streams have run once: created first (eagerly, with
+        # device_id), RCCL's internal streams take the hardware queues and the NMS side stream ends up sharing a
+        # queue with the conv stream -- measured: the NMS/conv overlap disappears (3.25 vs 3.05 ms/step).
+        prop.propose(imgs)
+        prop.wait()
+        torch.cuda.synchronize()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
     M = prop.topn
     gathered = torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") if world > 1 else None
     gather_bufs = [torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") for _ in range(2)]
