@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librpn_hip.so")
+# RPN_HIP_LIB: another build of the same library (kernel A/B runs); still no fallback of any kind.
+LIB_PATH = os.environ.get("RPN_HIP_LIB") or os.path.join(_HERE, "csrc", "librpn_hip.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

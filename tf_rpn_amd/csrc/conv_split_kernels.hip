@@ -31,7 +31,50 @@
 #include <cstdlib>
 #include <cstring>
 
+// The next slice's global loads are issued at the TOP of a barrier interval so that a whole interval of MFMAs hides
+// their latency.  Left alone the scheduler sinks them to the end of the interval, right in front of the barrier whose
+// far side stores them to LDS (measured in the ISA), exposing the full memory latency every interval: pin them.
+#ifndef RPN_PIN
+#define RPN_PIN 1
+#endif
+#if RPN_PIN
+#define RPN_PIN_LOADS() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RPN_PIN_LOADS() ((void)0)
+#endif
+
+// Debug build only (-DRPN_STAMP, scripts/stamp_probe.py): in-kernel cycle stamps of the 16x16x32 kernel's phases.
+#ifdef RPN_STAMP
+__device__ unsigned long long g_rpn_stamps[8192 * 32];
+#define RPN_STAMP_AT(k)                                                                                    \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 8192 && (k) < 32)                                             \
+            g_rpn_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter();                            \
+    } while (0)
+#define RPN_STAMP_VAL(k, v)                                                                                \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_rpn_stamps[blockIdx.x * 32 + (k)] = (v);             \
+    } while (0)
+extern "C" int rpn_debug_read_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rpn_stamps), (size_t)n * 8);
+}
+#else
+#define RPN_STAMP_AT(k) ((void)0)
+#define RPN_STAMP_VAL(k, v) ((void)0)
+#endif
+
 namespace rpn {
+
+// The epilogue's staging area is private to a wave: lanes exchange data through it, other waves never touch it, and
+// a wave's LDS instructions execute in order -- so the exchange needs a wave-level fence, not a workgroup barrier
+// (which would make every wave wait for the slowest one twice per output row).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -249,6 +292,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
             RPN_LOAD_B(step + 1 < steps ? step + 1 : step);
 #pragma unroll
             for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN_LOAD_A(next_chunk, row * A_RPS + q);
+            if constexpr (NW == 4) RPN_PIN_LOADS();          // (the 8-wave variant has 128 VGPRs: pinned, it spills)
 
             const u32x4 *arow = As + (abuf * ABUF + (wm * MI + row) * HW * 4);
 #pragma unroll
@@ -354,9 +398,9 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     const int m2 = (e2 & 1) + 4 * (e2 >> 1) + 2 * kh;             // pooled column 0..15
                     stage[m2 * STAGE_LD + j * 32 + lm] = fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
-            __syncthreads();
+            wave_sync();
             store_stage(4, (oy0 + wm * MI + 2 * ip) >> 1, ox0 >> 1, OHo, OWo);
-            __syncthreads();
+            wave_sync();
         }
     } else {
 #pragma unroll
@@ -368,9 +412,9 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
                     stage[m * STAGE_LD + j * 32 + lm] = fminf(fmaxf(acc[i][j][e] * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
-            __syncthreads();
+            wave_sync();
             store_stage(5, oy0 + wm * MI + i, ox0, a.H, a.W);
-            __syncthreads();
+            wave_sync();
         }
     }
 }
@@ -394,177 +438,18 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// TH: tile rows (8 | 4); WN: waves along N (2 -> 128 channels, 1 -> 64); NW: waves (8 | 4).  Each wave owns
-// RW = TH / (NW / WN) rows of 32 pixels x 64 channels.  <8,2,8>: one 136 KB workgroup per CU (large layers);
-// <4,1,4>: 77 KB, two workgroups per CU (small feature maps).
-template <int TH, int WN, int NW, bool F16, bool POOL>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 2)
-conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+// Epilogue shared by the 16x16x32 kernels: scale + bias + activation (+ fused 2x2 max-pool), transposed through a
+// wave-private LDS staging area, 16-byte stores (C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg).
+// The caller guarantees that no wave still reads (and no DMA still writes) the pipeline buffers the area overlays.
+template <bool F16, bool POOL, int RW, int NW>
+__device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][4], float *lds_f, const SplitConvArgs &a, int img,
+                                                 int oy0, int ox0, int n0, int wave, int wm, int wn, int lane)
 {
-    constexpr int NT = 64 * NW, BN = 64 * WN;
-    constexpr int WM = NW / WN, RW = TH / WM;          // rows of 32 pixels per wave
-    constexpr int MT = RW * 2;                         // 16-pixel MFMA tiles per wave along M
-    constexpr int HP = (TH + 2) * HW;                 // halo pixels
-    constexpr int PPP = 8;                            // 16-byte pieces per 32-channel row
-    constexpr int ABUF = HP * PPP + 8;                // + dummy slot for idle lanes
-    constexpr int A_PIECES = HP * PPP;
-    constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT;
-    constexpr int A_RPS = (A_ROUNDS + 2) / 3, A_SLOTS = 3 * A_RPS;
-    constexpr int B_PIECES = 3 * BN * PPP;            // one filter row of 32-channel weight rows
-    constexpr int B_ROUNDS = B_PIECES / NT;
+    constexpr int MT = RW * 2;
     constexpr int STAGE_LD = 64 + kStagePad;
-    constexpr int LDS_PIPE = 2 * ABUF + B_PIECES;
-    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;
-    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
-    static_assert(RW * WM == TH && RW >= 1 && B_PIECES % NT == 0 && (!POOL || RW == 2), "tile shape");
-
-    __shared__ uint4 lds[LDS_UINT4];
-    u32x4 *As = reinterpret_cast<u32x4 *>(lds);
-    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;         // rows [RW*wm, +RW), channels [64wn, +64)
-    const int lr = lane & 15, kg = lane >> 4;         // fragment row / k-group (8 channels) of this lane
-
-    int nt, mt;
-    {
-        const int m_tiles = tiles_x * tiles_y * a.B;
-        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
-        const int NTl = (n_tiles + XN - 1) / XN;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        nt = (slot % NTl) * XN + (xcd % XN);
-        mt = (slot / NTl) * XM + (xcd / XN);
-        if (nt >= n_tiles || mt >= m_tiles) return;
-    }
-    const int tx = mt % tiles_x;
-    mt /= tiles_x;
-    const int ty = mt % tiles_y;
-    const int img = mt / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
-
-    const int chunks = a.Cin >> 5;                    // 32-channel slices
-    const int steps = chunks * 3;
-    const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
-    const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
-
-    constexpr unsigned kOob = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
-    unsigned a_goff[A_SLOTS];
-    int a_loff[A_SLOTS];
-#pragma unroll
-    for (int R = 0; R < A_SLOTS; ++R) {
-        const int e = R * NT + tid;
-        const int pix = e >> 3, q = e & 7;            // q: piece of the pixel's 128-byte (2 x SPLIT16 record) slice
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool piece = e < A_PIECES;
-        const bool inimg = piece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const int kgq = (q >> 2) * 2 + ((q >> 1) & 1), lo = q & 1;     // SPLIT16 record order -> (k-group, lo)
-        a_loff[R] = piece ? (pix * PPP + ((lo * 4 + kgq) ^ ((hx >> 1) & 7))) : HP * PPP;
-        a_goff[R] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + q) * 16) : kOob;
-    }
-    u32x4 b_reg[B_ROUNDS];
-    u32x4 a_reg[A_RPS];
-#define RPN16_LOAD_B(STEP)                                                                                   \
-    {                                                                                                        \
-        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(a.w) + ((size_t)(STEP) * 3 * a.cout_pad + n0) * PPP; \
-        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
-            const int e_ = tid + i_ * NT;                                                                    \
-            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
-            b_reg[i_] = src_[(size_t)t_ * a.cout_pad * PPP + rem_];                                          \
-        }                                                                                                    \
-    }
-#define RPN16_STORE_B()                                                                                      \
-    {                                                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
-            const int e_ = tid + i_ * NT;                                                                    \
-            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
-            const int n_ = rem_ >> 3, pc_ = rem_ & 7;                                                        \
-            Bs[(t_ * BN + n_) * PPP + (pc_ ^ ((n_ >> 1) & 7))] = b_reg[i_];                                  \
-        }                                                                                                    \
-    }
-#define RPN16_LOAD_A(CHUNK, R) \
-    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 128, 0))
-
-    f32x4 acc[MT][4];                                 // [M-tile = row i * 2 + half][N-tile j]
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int a_off[3][2];                                  // [tap column s][16-px half]: lane-constant
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int hx = 16 * hf + lr + s3;
-            a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
-        }
-    int b_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wn * 64 + j * 16 + lr;
-        b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
-    }
-
-#pragma unroll
-    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN16_LOAD_A(0, R);
-    RPN16_LOAD_B(0);
-    RPN16_STORE_B();
-    __syncthreads();
-
-    int abuf = 0;
-#pragma unroll 1
-    for (int chunk = 0; chunk < chunks; ++chunk) {
-        const int next_chunk = chunk + 1 < chunks ? chunk + 1 : chunk;
-#pragma unroll
-        for (int row = 0; row < 3; ++row) {
-            const int step = chunk * 3 + row;
-            RPN16_LOAD_B(step + 1 < steps ? step + 1 : step);
-#pragma unroll
-            for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN16_LOAD_A(next_chunk, row * A_RPS + q);
-
-            const u32x4 *arow = As + (abuf * ABUF + (RW * wm + row) * HW * PPP);
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                u32x4 ahi[MT], alo[MT], bhi[4], blo[4];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {            // m = i * 2 + half
-                    const int idx = (m >> 1) * HW * PPP + a_off[s][m & 1];
-                    ahi[m] = arow[idx];
-                    alo[m] = arow[idx ^ 4];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bhi[j] = Bs[s * BN * PPP + b_off[j]];
-                    blo[j] = Bs[s * BN * PPP + (b_off[j] ^ 4)];
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[m][j] = mfma16<F16>(alo[m], bhi[j], acc[m][j]);
-                        acc[m][j] = mfma16<F16>(ahi[m], blo[j], acc[m][j]);
-                        acc[m][j] = mfma16<F16>(ahi[m], bhi[j], acc[m][j]);
-                    }
-            }
-            __syncthreads();                              // every wave is done reading the weight buffer
-            RPN16_STORE_B();
-#pragma unroll
-            for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
-            __syncthreads();
-        }
-        abuf ^= 1;
-    }
-#undef RPN16_LOAD_B
-#undef RPN16_STORE_B
-#undef RPN16_LOAD_A
-
+    const int lr = lane & 15, kg = lane >> 4;
     // ---- epilogue (as in the 32x32 kernel; C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg) --
-    float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
+    float *stage = lds_f + wave * (32 * STAGE_LD);
     float bias_v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -624,7 +509,7 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     const int px2 = 8 * hf + 2 * kg + r2;                                          // pooled column 0..15
                     stage[px2 * STAGE_LD + j * 16 + lr] = fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + bias_v[j], act_lo), act_hi);
                 }
-        __syncthreads();
+        wave_sync();
         store_stage(4, (oy0 + 2 * wm) >> 1, ox0 >> 1, OHo, OWo);
     } else {
 #pragma unroll
@@ -639,11 +524,419 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                         stage[px * STAGE_LD + j * 16 + lr] =
                             fminf(fmaxf(acc[i * 2 + hf][j][r] * a.out_scale + bias_v[j], act_lo), act_hi);
                     }
-            __syncthreads();
+            wave_sync();
             store_stage(5, oy0 + RW * wm + i, ox0, a.H, a.W);
-            __syncthreads();
+            wave_sync();
         }
     }
+}
+
+// TH: tile rows (8 | 4); WN: waves along N (2 -> 128 channels, 1 -> 64); NW: waves (8 | 4).  Each wave owns
+// RW = TH / (NW / WN) rows of 32 pixels x 64 channels.  <8,2,8>: one 136 KB workgroup per CU (large layers);
+// <4,1,4>: 77 KB, two workgroups per CU (small feature maps).
+template <int TH, int WN, int NW, bool F16, bool POOL>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 2)
+conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int NT = 64 * NW, BN = 64 * WN;
+    constexpr int WM = NW / WN, RW = TH / WM;          // rows of 32 pixels per wave
+    constexpr int MT = RW * 2;                         // 16-pixel MFMA tiles per wave along M
+    constexpr int HP = (TH + 2) * HW;                 // halo pixels
+    constexpr int PPP = 8;                            // 16-byte pieces per 32-channel row
+    constexpr int ABUF = HP * PPP + 8;                // + dummy slot for idle lanes
+    constexpr int A_PIECES = HP * PPP;
+    constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT;
+    constexpr int A_RPS = (A_ROUNDS + 2) / 3, A_SLOTS = 3 * A_RPS;
+    constexpr int B_PIECES = 3 * BN * PPP;            // one filter row of 32-channel weight rows
+    constexpr int B_ROUNDS = B_PIECES / NT;
+    constexpr int STAGE_LD = 64 + kStagePad;
+    constexpr int LDS_PIPE = 2 * ABUF + B_PIECES;
+    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;
+    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
+    static_assert(RW * WM == TH && RW >= 1 && B_PIECES % NT == 0 && (!POOL || RW == 2), "tile shape");
+
+    __shared__ uint4 lds[LDS_UINT4];
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;         // rows [RW*wm, +RW), channels [64wn, +64)
+    const int lr = lane & 15, kg = lane >> 4;         // fragment row / k-group (8 channels) of this lane
+
+    int nt, mt;
+    {
+        const int m_tiles = tiles_x * tiles_y * a.B;
+        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+        const int NTl = (n_tiles + XN - 1) / XN;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nt = (slot % NTl) * XN + (xcd % XN);
+        mt = (slot / NTl) * XM + (xcd / XN);
+        if (nt >= n_tiles || mt >= m_tiles) return;
+    }
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
+    RPN_STAMP_AT(0);
+    RPN_STAMP_VAL(1, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                         (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));       // XCC_ID, HW_ID
+
+    const int chunks = a.Cin >> 5;                    // 32-channel slices
+    const int steps = chunks * 3;
+    const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
+    const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
+    unsigned a_goff[A_SLOTS];
+    int a_loff[A_SLOTS];
+#pragma unroll
+    for (int R = 0; R < A_SLOTS; ++R) {
+        const int e = R * NT + tid;
+        const int pix = e >> 3, q = e & 7;            // q: piece of the pixel's 128-byte (2 x SPLIT16 record) slice
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool piece = e < A_PIECES;
+        const bool inimg = piece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int kgq = (q >> 2) * 2 + ((q >> 1) & 1), lo = q & 1;     // SPLIT16 record order -> (k-group, lo)
+        a_loff[R] = piece ? (pix * PPP + ((lo * 4 + kgq) ^ ((hx >> 1) & 7))) : HP * PPP;
+        a_goff[R] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + q) * 16) : kOob;
+    }
+    u32x4 b_reg[B_ROUNDS];
+    u32x4 a_reg[A_RPS];
+#define RPN16_LOAD_B(STEP)                                                                                   \
+    {                                                                                                        \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(a.w) + ((size_t)(STEP) * 3 * a.cout_pad + n0) * PPP; \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
+            const int e_ = tid + i_ * NT;                                                                    \
+            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
+            b_reg[i_] = src_[(size_t)t_ * a.cout_pad * PPP + rem_];                                          \
+        }                                                                                                    \
+    }
+#define RPN16_STORE_B()                                                                                      \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_ROUNDS; ++i_) {                                            \
+            const int e_ = tid + i_ * NT;                                                                    \
+            const int t_ = e_ / (BN * PPP), rem_ = e_ - t_ * (BN * PPP);                                     \
+            Bs[t_ * BN * PPP + rem_] = b_reg[i_];       /* the packed weights already are the swizzled image */ \
+        }                                                                                                    \
+    }
+#define RPN16_LOAD_A(CHUNK, R) \
+    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 128, 0))
+
+    f32x4 acc[MT][4];                                 // [M-tile = row i * 2 + half][N-tile j]
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int a_off[3][2];                                  // [tap column s][16-px half]: lane-constant
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = 16 * hf + lr + s3;
+            a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
+        }
+    int b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + lr;
+        b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
+    }
+
+#pragma unroll
+    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN16_LOAD_A(0, R);
+    RPN16_LOAD_B(0);
+    RPN16_STORE_B();
+    __syncthreads();
+    RPN_STAMP_AT(2);
+
+    int abuf = 0;
+#pragma unroll 1
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const int next_chunk = chunk + 1 < chunks ? chunk + 1 : chunk;
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            const int step = chunk * 3 + row;
+            RPN16_LOAD_B(step + 1 < steps ? step + 1 : step);
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN16_LOAD_A(next_chunk, row * A_RPS + q);
+            RPN_PIN_LOADS();
+
+            const u32x4 *arow = As + (abuf * ABUF + (RW * wm + row) * HW * PPP);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                u32x4 ahi[MT], alo[MT], bhi[4], blo[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {            // m = i * 2 + half
+                    const int idx = (m >> 1) * HW * PPP + a_off[s][m & 1];
+                    ahi[m] = arow[idx];
+                    alo[m] = arow[idx ^ 4];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bhi[j] = Bs[s * BN * PPP + b_off[j]];
+                    blo[j] = Bs[s * BN * PPP + (b_off[j] ^ 4)];
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[m][j] = mfma16<F16>(alo[m], bhi[j], acc[m][j]);
+                        acc[m][j] = mfma16<F16>(ahi[m], blo[j], acc[m][j]);
+                        acc[m][j] = mfma16<F16>(ahi[m], bhi[j], acc[m][j]);
+                    }
+            }
+            __syncthreads();                              // every wave is done reading the weight buffer
+            RPN16_STORE_B();
+#pragma unroll
+            for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
+            __syncthreads();
+        }
+        abuf ^= 1;
+        RPN_STAMP_AT(4 + chunk);
+    }
+#undef RPN16_LOAD_B
+#undef RPN16_STORE_B
+#undef RPN16_LOAD_A
+
+    split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+    RPN_STAMP_AT(3);
+}
+
+// ---- 16x16x32-MFMA variant, LDS-DMA pipeline ---------------------------------------------------------------------
+// Same tile (8 x 32 px x 128 ch, 8 waves), same LDS images and the same arithmetic in the same order as
+// conv3x3_split16_kernel<8, 2, 8> (bit-identical results), but the staging pipeline is rebuilt around
+// `buffer_load ... lds` (global -> LDS without passing through registers):
+//   * one barrier per TAP (not two per filter row) and no exposed store phase: in-kernel stamps of the register-staged
+//     kernel show 18.7k cycles per 32-channel slice against 13.8k of MFMA issue -- 62 KB of ds_write_b128 between the two
+//     barriers of every row interval (~79 B/clk/CU), plus the fragment-read latency behind the second barrier;
+//   * the weights of tap t+3 are DMA'd into a 3-slot ring while tap t computes; the halo tile of the next slice in
+//     6 pieces per wave during taps 0..5 of the current slice (other halo buffer);
+//   * the MFMA fragments of tap t+1 are read into a second register set during tap t, so the matrix pipe does not
+//     wait for LDS behind a barrier.
+// Hazards, by the rule "read a DMA'd buffer one interval after the wait that retires it":
+//   RAW  weights(t+2) (issued in interval t-1) are retired by the counted vmcnt at the end of interval t (which leaves
+//        only interval t's own DMAs in flight), then the barrier; read in interval t+1.  Halo pieces likewise (issued in
+//        intervals 0..5, first read in interval 8).
+//   WAR  the ring slot of tap t+3 is the slot of tap t, whose fragments were read in interval t-1 and retired by the
+//        lgkmcnt(0) in front of that interval's barrier.  The other halo buffer was last read in interval 7 of the
+//        previous slice.
+// The weights in HBM are already the swizzled LDS image ("split32" packing), so their DMA is a linear copy; the halo
+// tile's swizzle is applied on the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  Out-of-image halo
+// pixels are out-of-range buffer offsets: the DMA writes zeros for them (checked: scripts/micro/dma_oob.hip).
+// Needs an even number of 32-channel slices (the body is unrolled over two slices = 18 taps so that register sets,
+// halo buffers and ring slots are all compile-time).
+#ifndef RPN_DMA_SCHED
+#define RPN_DMA_SCHED 1
+#endif
+#define RPN_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+template <bool F16, bool POOL>
+__global__ void __launch_bounds__(512, 2)
+conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int TH = 8, NW = 8, WN = 2, BN = 128, RW = 2, MT = 4, PPP = 8;
+    constexpr int HP = (TH + 2) * HW;                  // 340 halo pixels
+    constexpr int A_INSTR = (HP * PPP + 63) / 64;      // 43 wave-instructions (1 KB each) per halo tile
+    constexpr int ABUF = A_INSTR * 64;                 // pieces per halo buffer (the tail of the last KB is padding)
+    constexpr int A_PER_WAVE = (A_INSTR + NW - 1) / NW;   // 6 (the 5 surplus ones go to a dump area)
+    constexpr int BSLOT = BN * PPP;                    // pieces per ring slot (one tap: 16 KB)
+    constexpr int DUMP = 2 * ABUF + 3 * BSLOT;
+    constexpr int LDS_PIPE = DUMP + 64;
+    constexpr int STAGE_LD = 64 + kStagePad;
+    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;
+    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
+    static_assert(A_PER_WAVE <= 9, "halo pieces are issued one per tap");
+
+    __shared__ uint4 lds[LDS_UINT4];
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, kg = lane >> 4;
+
+    int nt, mt;
+    {
+        const int m_tiles = tiles_x * tiles_y * a.B;
+        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+        const int NTl = (n_tiles + XN - 1) / XN;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nt = (slot % NTl) * XN + (xcd % XN);
+        mt = (slot / NTl) * XM + (xcd / XN);
+        if (nt >= n_tiles || mt >= m_tiles) return;
+    }
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
+
+    const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
+    const int total_taps = chunks * 9;
+    const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
+    const uint4 *xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
+    const int w_tap_bytes = a.cout_pad * 128;
+
+    // halo DMA: wave-instruction k = j * 8 + wave fills LDS pieces [64k, 64k + 64); piece e = pixel * 8 + physical slot
+    unsigned a_goff[A_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+        const int k = j * NW + wave;
+        const int e = k * 64 + lane;
+        const int pix = e >> 3, ps = e & 7;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool inimg = k < A_INSTR && e < HP * PPP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int lg = ps ^ ((hx >> 1) & 7);              // logical piece: lo * 4 + k-group
+        const int lo = lg >> 2, kgq = lg & 3;
+        const int q = ((kgq >> 1) << 2) | ((kgq & 1) << 1) | lo;   // its place in the two SPLIT16 records of the slice
+        a_goff[j] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + q) * 16) : kOob;
+    }
+    const unsigned b_voff = (unsigned)(((n0 * PPP) + (2 * wave) * 64 + lane) * 16);   // this wave's 2 KB of a tap's 16 KB
+
+#define RPN_DMA_A(J, CHUNK, BUF)                                                                                  \
+    {                                                                                                             \
+        const int k_ = (J) * NW + wave;                                                                           \
+        u32x4 *dst_ = k_ < A_INSTR ? As + (BUF) * ABUF + k_ * 64 : reinterpret_cast<u32x4 *>(lds) + DUMP;         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, RPN_LDS_PTR(dst_), 16, a_goff[J], (CHUNK) * 128, 0, 0);   \
+    }
+#define RPN_DMA_B(GT, SLOT)                                                                                       \
+    {                                                                                                             \
+        const int soff_ = (GT) * w_tap_bytes;                                                                     \
+        u32x4 *dst_ = Bs + (SLOT) * BSLOT + (2 * wave) * 64;                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, soff_, 0, 0);              \
+        /* the instruction offset advances BOTH the global and the LDS address */                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, soff_, 1024, 0);           \
+    }
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int a_off[3][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = 16 * hf + lr + s3;
+            a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
+        }
+    int b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + lr;
+        b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
+    }
+
+    u32x4 fa[2][MT * 2], fb[2][8];                    // [register set][tile * 2 + (0 hi | 1 lo)]
+#define RPN_READ_FRAGS(SET, BUF, ROW, S)                                                                          \
+    {                                                                                                             \
+        const u32x4 *arow_ = As + ((BUF) * ABUF + (RW * wm + (ROW)) * HW * PPP);                                  \
+        _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                       \
+            const int idx_ = (m_ >> 1) * HW * PPP + a_off[S][m_ & 1];                                             \
+            fa[SET][2 * m_] = arow_[idx_];                                                                        \
+            fa[SET][2 * m_ + 1] = arow_[idx_ ^ 4];                                                                \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                        \
+            fb[SET][2 * j_] = Bs[(S) * BSLOT + b_off[j_]];                                                        \
+            fb[SET][2 * j_ + 1] = Bs[(S) * BSLOT + (b_off[j_] ^ 4)];                                              \
+        }                                                                                                         \
+    }
+
+    // ---- prologue: halo tile of slice 0, weights of taps 0..2, fragments of tap 0 -------------------------------
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) RPN_DMA_A(j, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) RPN_DMA_B(t, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    RPN_STAMP_AT(2);
+    RPN_READ_FRAGS(0, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // ring slot 0 may now be overwritten (tap 3)
+
+    int gt = 3;                                        // next tap to DMA
+#pragma unroll 1
+    for (int pair = 0; pair < (chunks >> 1); ++pair) {
+#pragma unroll
+        for (int T = 0; T < 18; ++T) {                // tap T of this pair of slices; everything below is static in T
+            const int c2 = T / 9, s9 = T % 9;
+            RPN_DMA_B(gt < total_taps ? gt : total_taps - 1, s9 % 3);
+            ++gt;
+            if (s9 < A_PER_WAVE) {
+                const int nc = 2 * pair + c2 + 1;
+                RPN_DMA_A(s9, nc < chunks ? nc : chunks - 1, (c2 + 1) & 1);
+            }
+            // program order = intended issue order: one fragment read of tap t+1 behind each of the 16 chain-head MFMAs
+            // (the reads have long returned when the interval ends), then the other 32 MFMAs
+            {
+                const int NS = (T + 1) & 1, NB = ((T + 1) / 9) & 1, NR = ((T + 1) % 9) / 3, NC = ((T + 1) % 9) % 3;
+                const u32x4 *arow_ = As + (NB * ABUF + (RW * wm + NR) * HW * PPP);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i < 8) {
+                        const int idx_ = (i >> 2) * HW * PPP + a_off[NC][(i >> 1) & 1];
+                        fa[NS][i] = arow_[(i & 1) ? (idx_ ^ 4) : idx_];
+                    } else {
+                        const int o_ = b_off[(i - 8) >> 1];
+                        fb[NS][i - 8] = Bs[NC * BSLOT + ((i & 1) ? (o_ ^ 4) : o_)];
+                    }
+                    acc[i >> 2][i & 3] = mfma16<F16>(fa[T & 1][2 * (i >> 2) + 1], fb[T & 1][2 * (i & 3)], acc[i >> 2][i & 3]);   // lo * hi
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[m][j] = mfma16<F16>(fa[T & 1][2 * m], fb[T & 1][2 * j + 1], acc[m][j]);       // hi * lo
+                    acc[m][j] = mfma16<F16>(fa[T & 1][2 * m], fb[T & 1][2 * j], acc[m][j]);           // hi * hi
+                }
+#if RPN_DMA_SCHED
+            if (s9 < A_PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs would otherwise sink below the barrier)
+#endif
+            if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#if RPN_DMA_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (s9 == 8) RPN_STAMP_AT(4 + 2 * pair + c2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the staging area is reused
+    __builtin_amdgcn_s_barrier();
+#undef RPN_DMA_A
+#undef RPN_DMA_B
+#undef RPN_READ_FRAGS
+
+    split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+    RPN_STAMP_AT(3);
 }
 
 static inline unsigned short f32_to_bf16_rne(float f);
@@ -1150,8 +1443,9 @@ void pack_weights_split32_host(const float *hwio, const float *scale, int Cin, i
                 }
                 const int chunk = c >> 5, kgq = (c >> 3) & 3, k = c & 7;
                 unsigned short *rec = dst + (((size_t)chunk * 9 + t) * cout_pad + n) * 64;
-                rec[kgq * 8 + k] = hi;
-                rec[(4 + kgq) * 8 + k] = lo;
+                const int swz = (n >> 1) & 7;                 // the kernels' LDS image: piece p of channel n at p ^ swz
+                rec[(kgq ^ swz) * 8 + k] = hi;
+                rec[((4 + kgq) ^ swz) * 8 + k] = lo;
             }
 }
 
@@ -1282,14 +1576,22 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
 #define RPN_L16(TH_, WN_, NW_, F16_, POOL_)                                                                          \
     hipLaunchKernelGGL((conv3x3_split16_kernel<TH_, WN_, NW_, F16_, POOL_>), dim3((unsigned)nblocks), dim3(64 * NW_), 0, s, \
                        a, tiles_x, tiles_y, n_tiles)
+    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+#define RPN_L16D(F16_, POOL_)                                                                                        \
+    hipLaunchKernelGGL((conv3x3_split16_dma_kernel<F16_, POOL_>), dim3((unsigned)nblocks), dim3(512), 0, s, a, tiles_x, \
+                       tiles_y, n_tiles)
     if (small) {
         if (f16) RPN_L16(4, 1, 4, true, false); else RPN_L16(4, 1, 4, false, false);
+    } else if (dma_mode && Cin % 64 == 0) {            // LDS-DMA pipeline (same results bit for bit)
+        if (f16) { if (pool) RPN_L16D(true, true); else RPN_L16D(true, false); }
+        else { if (pool) RPN_L16D(false, true); else RPN_L16D(false, false); }
     } else if (f16) {
         if (pool) RPN_L16(8, 2, 8, true, true); else RPN_L16(8, 2, 8, true, false);
     } else {
         if (pool) RPN_L16(8, 2, 8, false, true); else RPN_L16(8, 2, 8, false, false);
     }
 #undef RPN_L16
+#undef RPN_L16D
     return hipGetLastError();
 }
 
