@@ -709,17 +709,24 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     RPN_STAMP_AT(3);
 }
 
-// ---- 16x16x32-MFMA variant, LDS-DMA pipeline ---------------------------------------------------------------------
-// Same tile (8 x 32 px x 128 ch, 8 waves), same LDS images and the same arithmetic in the same order as
-// conv3x3_split16_kernel<8, 2, 8> (bit-identical results), but the staging pipeline is rebuilt around
-// `buffer_load ... lds` (global -> LDS without passing through registers):
-//   * one barrier per TAP (not two per filter row) and no exposed store phase: in-kernel stamps of the register-staged
-//     kernel show 18.7k cycles per 32-channel slice against 13.8k of MFMA issue -- 62 KB of ds_write_b128 between the two
-//     barriers of every row interval (~79 B/clk/CU), plus the fragment-read latency behind the second barrier;
-//   * the weights of tap t+3 are DMA'd into a 3-slot ring while tap t computes; the halo tile of the next slice in
-//     6 pieces per wave during taps 0..5 of the current slice (other halo buffer);
-//   * the MFMA fragments of tap t+1 are read into a second register set during tap t, so the matrix pipe does not
-//     wait for LDS behind a barrier.
+// ---- 16x16x32-MFMA variant: persistent workgroups, LDS-DMA pipeline ----------------------------------------------
+// Same tile (8 x 32 px x 128 ch, 8 waves), same LDS images and the same products accumulated in the same order as
+// conv3x3_split16_kernel<8, 2, 8>, with the staging pipeline and the tile loop rebuilt from in-kernel cycle stamps
+// (scripts/stamp_probe.py) of that kernel: 18.7k cycles per 32-channel slice against 13.8k of MFMA issue, and 13k
+// cycles per tile of prologue + epilogue + dispatch gap that nothing overlapped (one workgroup per CU).
+//   * `buffer_load ... lds` (global -> LDS, no registers, no ds_write): one barrier per TAP and no exposed store phase
+//     (before: 62 KB of ds_write_b128 at ~79 B/clk/CU between the two barriers of every filter row).  The weights of
+//     tap t+3 are DMA'd into a 3-slot ring while tap t computes; the halo tile of the next slice in 6 pieces per wave
+//     during taps 0..5 of the current slice (other halo buffer).
+//   * the MFMA fragments of tap t+1 are read into a second register set during tap t (one read behind each of the 16
+//     chain-head MFMAs), so the matrix pipe does not wait for LDS behind a barrier.
+//   * persistent workgroups (one per CU) walk the tiles of their XCD: the tap stream simply continues into the next
+//     tile (its halo tile and first weights are DMA'd during the last slice of the current one), so there is no
+//     prologue and no dispatch gap between tiles.
+//   * the MFMA operands are swapped (weights as A, pixels as B): a lane's 4 accumulator registers are then 4 consecutive
+//     CHANNELS of one pixel and the epilogue stores straight from registers (8-byte hi / lo halves of a SPLIT16 piece,
+//     or float4), no LDS staging -- the LDS stays free for the next tile's DMAs, and a wave that finishes its epilogue
+//     early already computes the next tile's first tap beside its SIMD partner's epilogue.
 // Hazards, by the rule "read a DMA'd buffer one interval after the wait that retires it":
 //   RAW  weights(t+2) (issued in interval t-1) are retired by the counted vmcnt at the end of interval t (which leaves
 //        only interval t's own DMAs in flight), then the barrier; read in interval t+1.  Halo pieces likewise (issued in
@@ -731,11 +738,136 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 // tile's swizzle is applied on the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  Out-of-image halo
 // pixels are out-of-range buffer offsets: the DMA writes zeros for them (checked: scripts/micro/dma_oob.hip).
 // Needs an even number of 32-channel slices (the body is unrolled over two slices = 18 taps so that register sets,
-// halo buffers and ring slots are all compile-time).
+// halo buffers and ring slots are all compile-time) and an input tensor below 2 GiB (32-bit buffer offsets).
 #ifndef RPN_DMA_SCHED
 #define RPN_DMA_SCHED 1
 #endif
 #define RPN_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+// Tile schedule of a persistent workgroup: blockIdx & 7 labels the XCD; an XCD owns n-tiles (xcd % XN) + XN * k and
+// walks its slots.  next(): first real tile at or after `slot` (slots past the edge of the XN x XM ownership grid are
+// skipped); -1: none.  Tiles are 8 rows x 32 pixels x 128 channels.
+struct TileWalk {
+    int n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, n_slots, xcd, slot_stride;
+    __device__ __forceinline__ int next(int slot, int &img, int &oy0, int &ox0, int &n0) const
+    {
+        for (; slot < n_slots; slot += slot_stride) {
+            const int nt = (slot % NTl) * XN + (xcd % XN);
+            int mt = (slot / NTl) * XM + (xcd / XN);
+            if (nt >= n_tiles || mt >= m_tiles) continue;
+            const int tx = mt % tiles_x;
+            mt /= tiles_x;
+            const int ty = mt % tiles_y;
+            img = mt / tiles_y;
+            oy0 = ty * 8; ox0 = tx * TWS; n0 = nt * 128;
+            return slot;
+        }
+        return -1;
+    }
+};
+
+// Byte offset (inside the SPLIT16 input tensor) of the 16-byte piece that lane `lane` of halo wave-instruction
+// k = j * NW + wave DMAs: LDS piece e = 64 k + lane = halo pixel * 8 + physical slot; the LDS image's XOR swizzle is applied
+// here, on the source side.  Out-of-image pixels and the padding lanes get an out-of-range offset (the DMA writes zeros).
+template <int NW, int A_INSTR, int A_PIECES>
+__device__ __forceinline__ unsigned halo_source_offset(int j, int wave, int lane, int im, int y0, int x0, int H, int W,
+                                                       int in_pix_stride)
+{
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                      // opaque: keeps the lane-constant parts from being hoisted
+    const int k = j * NW + wave;                      // out of the tap loop into long-lived registers
+    const int e = k * 64 + ln;
+    const int pix = e >> 3, ps = e & 7;
+    const int hy = pix / HW, hx = pix - hy * HW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool in = k < A_INSTR && e < A_PIECES && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int lg = ps ^ ((hx >> 1) & 7);              // logical piece: lo * 4 + k-group
+    const int q = (((lg & 3) >> 1) << 2) | ((lg & 1) << 1) | (lg >> 2);   // its place in the slice's SPLIT16 records
+    return in ? (unsigned)((((im * H + iy) * W + ix) * in_pix_stride + q) * 16) : 0x80000000u;
+}
+
+// 4 floats -> the 8-byte hi half and the 8-byte lo half of their SPLIT16 piece
+template <bool F16>
+__device__ __forceinline__ void split4(const float (&x)[4], uint2 &hi, uint2 &lo)
+{
+    using E = typename Half<F16>::elem;
+    using E4 = __attribute__((ext_vector_type(4))) E;
+    E4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = (E)x[k];
+        l[k] = (E)(x[k] - (float)h[k]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+// Epilogue of the operand-swapped kernel.  acc[m][j][r]: pixel (row RW*wm + (m >> 1), column 16 * (m & 1) + (lane & 15)),
+// channel n0 + 64 wn + 16 j + 4 (lane >> 4) + r.
+template <bool F16, bool POOL>
+__device__ __forceinline__ void split16_store_direct(f32x4 (&acc)[4][4], const SplitConvArgs &a, int img, int oy0, int ox0,
+                                                     int n0, int wm, int wn, int lane)
+{
+    const int lr = lane & 15, kg = lane >> 4;
+    const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
+    const int cout_chunks = a.Cout >> 4;
+    const int c0 = n0 + wn * 64 + 4 * kg;                 // + 16 j
+    float bias_v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = c0 + 16 * j;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && n < a.Cout) b = *reinterpret_cast<const float4 *>(a.bias + n);
+        bias_v[j][0] = b.x; bias_v[j][1] = b.y; bias_v[j][2] = b.z; bias_v[j][3] = b.w;
+    }
+    // one pixel's 4 channels: float4, or the two 8-byte halves of the piece (record = [hi0-7 | lo0-7 | hi8-15 | lo8-15])
+    auto store4 = [&](const float (&v)[4], int oy, int ox, int OHo, int OWo, int n, bool want_hi, bool want_lo) {
+        if (oy >= OHo || ox >= OWo || n >= a.Cout) return;
+        const size_t pix = ((size_t)img * OHo + oy) * OWo + ox;
+        if (a.out_f32) {
+            if (want_hi) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.out) + pix * a.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+            return;
+        }
+        uint2 hi, lo;
+        split4<F16>(v, hi, lo);
+        uint2 *rec = reinterpret_cast<uint2 *>(a.out) + (pix * cout_chunks + (n >> 4)) * 8 + ((n >> 3) & 1) * 4 + ((n >> 2) & 1);
+        if (want_hi) rec[0] = hi;
+        if (want_lo) rec[2] = lo;
+    };
+    if constexpr (POOL) {
+        // MaxPooling2D(2,2) 'valid' fused: rows (2 wm, 2 wm + 1) are tiles m and m + 2 of this wave, the column pair is
+        // lanes (lr, lr ^ 1); max commutes with the monotone scale + bias + activation applied afterwards.  Both lanes of
+        // a pair end up with the pooled pixel: the even one stores its hi half, the odd one its lo half.
+        const int OHo = a.H >> 1, OWo = a.W >> 1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = fmaxf(acc[hf][j][r], acc[2 + hf][j][r]);
+                    t = fmaxf(t, __shfl_xor(t, 1));
+                    v[r] = fminf(fmaxf(t * a.out_scale + bias_v[j][r], act_lo), act_hi);
+                }
+                const bool even = (lr & 1) == 0;
+                store4(v, (oy0 + 2 * wm) >> 1, (ox0 >> 1) + 8 * hf + (lr >> 1), OHo, OWo, c0 + 16 * j,
+                       a.out_f32 ? even : even, a.out_f32 ? false : !even);
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = fminf(fmaxf(acc[m][j][r] * a.out_scale + bias_v[j][r], act_lo), act_hi);
+                store4(v, oy0 + 2 * wm + (m >> 1), ox0 + 16 * (m & 1) + lr, a.H, a.W, c0 + 16 * j, true, true);
+            }
+    }
+}
 
 template <bool F16, bool POOL>
 __global__ void __launch_bounds__(512, 2)
@@ -747,16 +879,17 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     constexpr int ABUF = A_INSTR * 64;                 // pieces per halo buffer (the tail of the last KB is padding)
     constexpr int A_PER_WAVE = (A_INSTR + NW - 1) / NW;   // 6 (the 5 surplus ones go to a dump area)
     constexpr int BSLOT = BN * PPP;                    // pieces per ring slot (one tap: 16 KB)
-    constexpr int DUMP = 2 * ABUF + 3 * BSLOT;
-    constexpr int LDS_PIPE = DUMP + 64;
-    constexpr int STAGE_LD = 64 + kStagePad;
-    constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;
-    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
-    static_assert(A_PER_WAVE <= 9, "halo pieces are issued one per tap");
+    // LDS map (16-byte pieces): halo buffer 0 | weight ring | dump | halo buffer 1 | spare.  At the end of a tile halo
+    // buffer 1 is dead (an even number of slices), so buffer 1 + spare is the epilogue's staging area: 8 waves x 32 px x
+    // 68 floats = 69632 bytes = exactly what is left of the CU's 160 KB.
+    constexpr int B_AT = ABUF, DUMP = B_AT + 3 * BSLOT, A1_AT = DUMP + 64;
+    constexpr int STAGE_PIECES = NW * 32 * (64 + kStagePad) * 4 / 16;
+    constexpr int LDS_UINT4 = A1_AT + (ABUF > STAGE_PIECES ? ABUF : STAGE_PIECES);
+    static_assert(A_PER_WAVE <= 9 && RW * (NW / WN) == TH && MT == 2 * RW && LDS_UINT4 * 16 <= 160 * 1024, "tile shape");
 
     __shared__ uint4 lds[LDS_UINT4];
-    u32x4 *As = reinterpret_cast<u32x4 *>(lds);
-    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + 2 * ABUF;
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);       // halo buffer b at As + b * A1_AT
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + B_AT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -764,71 +897,43 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, kg = lane >> 4;
 
-    int nt, mt;
-    {
-        const int m_tiles = tiles_x * tiles_y * a.B;
-        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
-        const int NTl = (n_tiles + XN - 1) / XN;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        nt = (slot % NTl) * XN + (xcd % XN);
-        mt = (slot / NTl) * XM + (xcd / XN);
-        if (nt >= n_tiles || mt >= m_tiles) return;
-    }
-    const int tx = mt % tiles_x;
-    mt /= tiles_x;
-    const int ty = mt % tiles_y;
-    const int img = mt / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TWS, n0 = nt * BN;
+    // tile schedule: blockIdx & 7 labels the XCD; an XCD owns n-tiles (xcd % XN) + XN * k and walks its slots
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+    const int NTl = (n_tiles + XN - 1) / XN, MTl = (m_tiles + XM - 1) / XM;
+    const int xcd = blockIdx.x & 7;
+    const int slot_stride = gridDim.x >> 3;
+    const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride};
+#define next_tile(SLOT, IMG, OY0, OX0, N0) walk.next((SLOT), (IMG), (OY0), (OX0), (N0))
 
     const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
     const int total_taps = chunks * 9;
-    const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
-    const uint4 *xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
-
-    constexpr unsigned kOob = 0x80000000u;
+    const int in_pix_stride = (a.Cin >> 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(xin), (short)0, (int)((size_t)a.H * a.W * in_pix_stride * 16), 0x00020000);
+        const_cast<uint4 *>(a.x), (short)0, (int)((size_t)a.B * a.H * a.W * in_pix_stride * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
     const int w_tap_bytes = a.cout_pad * 128;
 
-    // halo DMA: wave-instruction k = j * 8 + wave fills LDS pieces [64k, 64k + 64); piece e = pixel * 8 + physical slot
-    unsigned a_goff[A_PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-        const int k = j * NW + wave;
-        const int e = k * 64 + lane;
-        const int pix = e >> 3, ps = e & 7;
-        const int hy = pix / HW, hx = pix - hy * HW;
-        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool inimg = k < A_INSTR && e < HP * PPP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const int lg = ps ^ ((hx >> 1) & 7);              // logical piece: lo * 4 + k-group
-        const int lo = lg >> 2, kgq = lg & 3;
-        const int q = ((kgq >> 1) << 2) | ((kgq & 1) << 1) | lo;   // its place in the two SPLIT16 records of the slice
-        a_goff[j] = inimg ? (unsigned)((((size_t)iy * a.W + ix) * in_pix_stride + q) * 16) : kOob;
-    }
-    const unsigned b_voff = (unsigned)(((n0 * PPP) + (2 * wave) * 64 + lane) * 16);   // this wave's 2 KB of a tap's 16 KB
+    // halo DMA: wave-instruction k = j * 8 + wave fills LDS pieces [64k, 64k + 64); piece e = pixel * 8 + physical slot.
+    // The source offset is recomputed at each use (top of an interval, where register pressure is lowest; ~25 VALU
+    // operations against the interval's 48 MFMAs) instead of living in 6 registers through the whole kernel.
+#define halo_goff(J, IM, Y0, X0) halo_source_offset<NW, A_INSTR, HP * PPP>((J), wave, lane, (IM), (Y0), (X0), a.H, a.W, in_pix_stride)
+    const unsigned b_voff = (unsigned)(((2 * wave) * 64 + lane) * 16);   // this wave's 2 KB of a tap's 16 KB
 
-#define RPN_DMA_A(J, CHUNK, BUF)                                                                                  \
+#define RPN_DMA_A(J, GOFF, SOFF, BUF)                                                                             \
     {                                                                                                             \
         const int k_ = (J) * NW + wave;                                                                           \
-        u32x4 *dst_ = k_ < A_INSTR ? As + (BUF) * ABUF + k_ * 64 : reinterpret_cast<u32x4 *>(lds) + DUMP;         \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, RPN_LDS_PTR(dst_), 16, a_goff[J], (CHUNK) * 128, 0, 0);   \
+        u32x4 *dst_ = k_ < A_INSTR ? As + (BUF) * A1_AT + k_ * 64 : reinterpret_cast<u32x4 *>(lds) + DUMP;        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, RPN_LDS_PTR(dst_), 16, (GOFF), (SOFF), 0, 0);             \
     }
-#define RPN_DMA_B(GT, SLOT)                                                                                       \
+#define RPN_DMA_B(SOFF, SLOT)                                                                                     \
     {                                                                                                             \
-        const int soff_ = (GT) * w_tap_bytes;                                                                     \
         u32x4 *dst_ = Bs + (SLOT) * BSLOT + (2 * wave) * 64;                                                      \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, soff_, 0, 0);              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 0, 0);             \
         /* the instruction offset advances BOTH the global and the LDS address */                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, soff_, 1024, 0);           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 1024, 0);          \
     }
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int a_off[3][2];
 #pragma unroll
@@ -845,98 +950,152 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
         b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
     }
 
-    u32x4 fa[2][MT * 2], fb[2][8];                    // [register set][tile * 2 + (0 hi | 1 lo)]
-#define RPN_READ_FRAGS(SET, BUF, ROW, S)                                                                          \
-    {                                                                                                             \
-        const u32x4 *arow_ = As + ((BUF) * ABUF + (RW * wm + (ROW)) * HW * PPP);                                  \
-        _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                       \
-            const int idx_ = (m_ >> 1) * HW * PPP + a_off[S][m_ & 1];                                             \
-            fa[SET][2 * m_] = arow_[idx_];                                                                        \
-            fa[SET][2 * m_ + 1] = arow_[idx_ ^ 4];                                                                \
-        }                                                                                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                        \
-            fb[SET][2 * j_] = Bs[(S) * BSLOT + b_off[j_]];                                                        \
-            fb[SET][2 * j_ + 1] = Bs[(S) * BSLOT + (b_off[j_] ^ 4)];                                              \
-        }                                                                                                         \
-    }
+    int img = 0, oy0 = 0, ox0 = 0, n0 = 0;
+    int cur = next_tile(blockIdx.x >> 3, img, oy0, ox0, n0);
+    if (cur < 0) return;
+    RPN_STAMP_AT(0);
+    RPN_STAMP_VAL(1, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                         (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));       // XCC_ID, HW_ID
 
-    // ---- prologue: halo tile of slice 0, weights of taps 0..2, fragments of tap 0 -------------------------------
+    // Fragment registers.  The interval of a tap is worked in two halves (the wave's first / second pixel row) so that
+    // only the weight fragments are double-buffered: fx0 / fx1 hold [hi, lo] of the two 16-pixel tiles of row 0 / 1.
+    //   half 0: MFMAs of row 0 (fx0, fw[cur]); reads: fx1 of THIS tap
+    //   half 1: MFMAs of row 1 (fx1, fw[cur]); reads: fw[next] and fx0 of the NEXT tap
+    u32x4 fx0[4], fx1[4], fw[2][8];                   // fx: [16-px half * 2 + (0 hi | 1 lo)];  fw: [set][j * 2 + (0 hi | 1 lo)]
+#define RPN_X_ADDR(BUF, ROW, S, I, II)   /* row I of the wave, element II = half * 2 + lohi */                       \
+    (As[(BUF) * A1_AT + (RW * wm + (ROW) + (I)) * HW * PPP + (a_off[S][(II) >> 1] ^ (((II) & 1) ? 4 : 0))])
+#define RPN_W_ADDR(S, II)                /* element II = j * 2 + lohi */                                           \
+    (Bs[(S) * BSLOT + (b_off[(II) >> 1] ^ (((II) & 1) ? 4 : 0))])
+
+    // ---- prologue (first tile only): halo tile of slice 0, weights of taps 0..2, first fragments of tap 0 -------
+    unsigned a_goff[A_PER_WAVE];                       // halo source offsets of the tile whose halo is being fetched
 #pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) RPN_DMA_A(j, 0, 0);
+    for (int j = 0; j < A_PER_WAVE; ++j) a_goff[j] = halo_goff(j, img, oy0, ox0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) RPN_DMA_B(t, t);
+    for (int j = 0; j < A_PER_WAVE; ++j) RPN_DMA_A(j, a_goff[j], 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) RPN_DMA_B(t * w_tap_bytes + n0 * (PPP * 16), t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     RPN_STAMP_AT(2);
-    RPN_READ_FRAGS(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fw[0][i] = RPN_W_ADDR(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fx0[i] = RPN_X_ADDR(0, 0, 0, 0, i);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // ring slot 0 may now be overwritten (tap 3)
 
-    int gt = 3;                                        // next tap to DMA
+    int gt = 3;                                        // next tap to DMA, counted from the current tile's tap 0
+    int tile_no = 0;
+    for (;;) {
+        int nimg = 0, noy0 = 0, nox0 = 0, nn0 = 0;
+        const int nxt = next_tile(cur + slot_stride, nimg, noy0, nox0, nn0);
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll 1
-    for (int pair = 0; pair < (chunks >> 1); ++pair) {
+        for (int pair = 0; pair < (chunks >> 1); ++pair) {
 #pragma unroll
-        for (int T = 0; T < 18; ++T) {                // tap T of this pair of slices; everything below is static in T
-            const int c2 = T / 9, s9 = T % 9;
-            RPN_DMA_B(gt < total_taps ? gt : total_taps - 1, s9 % 3);
-            ++gt;
-            if (s9 < A_PER_WAVE) {
-                const int nc = 2 * pair + c2 + 1;
-                RPN_DMA_A(s9, nc < chunks ? nc : chunks - 1, (c2 + 1) & 1);
-            }
-            // program order = intended issue order: one fragment read of tap t+1 behind each of the 16 chain-head MFMAs
-            // (the reads have long returned when the interval ends), then the other 32 MFMAs
-            {
-                const int NS = (T + 1) & 1, NB = ((T + 1) / 9) & 1, NR = ((T + 1) % 9) / 3, NC = ((T + 1) % 9) % 3;
-                const u32x4 *arow_ = As + (NB * ABUF + (RW * wm + NR) * HW * PPP);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (i < 8) {
-                        const int idx_ = (i >> 2) * HW * PPP + a_off[NC][(i >> 1) & 1];
-                        fa[NS][i] = arow_[(i & 1) ? (idx_ ^ 4) : idx_];
-                    } else {
-                        const int o_ = b_off[(i - 8) >> 1];
-                        fb[NS][i - 8] = Bs[NC * BSLOT + ((i & 1) ? (o_ ^ 4) : o_)];
+            for (int T = 0; T < 18; ++T) {            // tap T of this pair of slices; everything below is static in T
+                const int c2 = T / 9, s9 = T % 9;
+                const int CS = T & 1, CB = c2 & 1, CR = s9 / 3, CC = s9 % 3;                       // this tap
+                const int NS = (T + 1) & 1, NB = ((T + 1) / 9) & 1, NR = ((T + 1) % 9) / 3, NC = ((T + 1) % 9) % 3;   // next
+                {   // weights of tap t+3: this tile's, or the first taps of the next tile (or a harmless re-load)
+                    int tap = gt, nb = n0;
+                    if (gt >= total_taps) {
+                        if (nxt >= 0) { tap = gt - total_taps; nb = nn0; }
+                        else tap = total_taps - 1;
                     }
-                    acc[i >> 2][i & 3] = mfma16<F16>(fa[T & 1][2 * (i >> 2) + 1], fb[T & 1][2 * (i & 3)], acc[i >> 2][i & 3]);   // lo * hi
+                    RPN_DMA_B(tap * w_tap_bytes + nb * (PPP * 16), s9 % 3);
+                    ++gt;
                 }
-            }
+                if (T == 9 && nxt >= 0 && pair == (chunks >> 1) - 1) {    // last slice of the tile: from here on the halo
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                    for (int j = 0; j < A_PER_WAVE; ++j) a_goff[j] = halo_goff(j, nimg, noy0, nox0);   // of the NEXT tile
+                }
+                if (s9 < A_PER_WAVE) {      // halo piece s9 of the next slice: this tile's, or slice 0 of the next tile
+                    const int nc = 2 * pair + c2 + 1;
+                    RPN_DMA_A(s9, a_goff[s9], nc < chunks ? nc * 128 : (nxt >= 0 ? 0 : (chunks - 1) * 128), (c2 + 1) & 1);
+                }
+                // ---- half 0: row 0.  Program order = intended issue order: a fragment read behind each of the first MFMAs
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[m][j] = mfma16<F16>(fa[T & 1][2 * m], fb[T & 1][2 * j + 1], acc[m][j]);       // hi * lo
-                    acc[m][j] = mfma16<F16>(fa[T & 1][2 * m], fb[T & 1][2 * j], acc[m][j]);           // hi * hi
+                for (int i = 0; i < 8; ++i) {         // chain heads (x lo * w hi) of tiles (m = i >> 2, j = i & 3)
+                    if (i < 4) fx1[i] = RPN_X_ADDR(CB, CR, CC, 1, i);
+                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2) + 1], fw[CS][2 * (i & 3)], acc[i >> 2][i & 3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2)], fw[CS][2 * (i & 3) + 1], acc[i >> 2][i & 3]);   // x hi * w lo
+                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2)], fw[CS][2 * (i & 3)], acc[i >> 2][i & 3]);       // x hi * w hi
                 }
 #if RPN_DMA_SCHED
-            if (s9 < A_PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (s9 < A_PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
-            __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs would otherwise sink below the barrier)
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+                // ---- half 1: row 1; the next tap's weights and row-0 pixels arrive meanwhile
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    fw[NS][i] = RPN_W_ADDR(NC, i);
+                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2) + 1], fw[CS][2 * (i & 3)], acc[2 + (i >> 2)][i & 3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < 4) fx0[i] = RPN_X_ADDR(NB, NR, NC, 0, i);
+                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2)], fw[CS][2 * (i & 3) + 1], acc[2 + (i >> 2)][i & 3]);
+                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2)], fw[CS][2 * (i & 3)], acc[2 + (i >> 2)][i & 3]);
+                }
 #if RPN_DMA_SCHED
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_barrier(0);     // (register-only MFMAs would otherwise sink below the barrier)
 #endif
-            if (s9 == 8) RPN_STAMP_AT(4 + 2 * pair + c2);
+                if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#if RPN_DMA_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (s9 == 8 && tile_no == 0) RPN_STAMP_AT(4 + 2 * pair + c2);
+            }
         }
+        // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
+        // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
+        // first interval starts to refill buffer 1 -- hence one workgroup barrier per tile.
+        split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+        if (tile_no == 0) RPN_STAMP_AT(3);
+        if (nxt < 0) break;
+        __builtin_amdgcn_s_barrier();
+        cur = nxt; img = nimg; oy0 = noy0; ox0 = nox0; n0 = nn0;
+        gt -= total_taps;
+        ++tile_no;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the staging area is reused
-    __builtin_amdgcn_s_barrier();
+#undef RPN_X_ADDR
+#undef RPN_W_ADDR
+#undef next_tile
+#undef halo_goff
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs still target this workgroup's LDS
 #undef RPN_DMA_A
 #undef RPN_DMA_B
-#undef RPN_READ_FRAGS
-
-    split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), a, img, oy0, ox0, n0, wave, wm, wn, lane);
-    RPN_STAMP_AT(3);
 }
 
 static inline unsigned short f32_to_bf16_rne(float f);
@@ -1577,12 +1736,21 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
     hipLaunchKernelGGL((conv3x3_split16_kernel<TH_, WN_, NW_, F16_, POOL_>), dim3((unsigned)nblocks), dim3(64 * NW_), 0, s, \
                        a, tiles_x, tiles_y, n_tiles)
     static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+    // persistent workgroups: one per CU (8 per XCD label at least), each walks the slots of its XCD label
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n;
+    }();
+    const long long slots = nblocks / 8;
+    const unsigned pgrid = 8u * (unsigned)(slots < n_cus / 8 ? slots : n_cus / 8);
+    const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
+                        (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
 #define RPN_L16D(F16_, POOL_)                                                                                        \
-    hipLaunchKernelGGL((conv3x3_split16_dma_kernel<F16_, POOL_>), dim3((unsigned)nblocks), dim3(512), 0, s, a, tiles_x, \
-                       tiles_y, n_tiles)
+    hipLaunchKernelGGL((conv3x3_split16_dma_kernel<F16_, POOL_>), dim3(pgrid), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles)
     if (small) {
         if (f16) RPN_L16(4, 1, 4, true, false); else RPN_L16(4, 1, 4, false, false);
-    } else if (dma_mode && Cin % 64 == 0) {            // LDS-DMA pipeline (same results bit for bit)
+    } else if (dma_ok) {                               // persistent LDS-DMA pipeline
         if (f16) { if (pool) RPN_L16D(true, true); else RPN_L16D(true, false); }
         else { if (pool) RPN_L16D(false, true); else RPN_L16D(false, false); }
     } else if (f16) {
