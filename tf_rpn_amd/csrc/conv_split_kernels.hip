@@ -441,33 +441,35 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
 // Epilogue shared by the 16x16x32 kernels: scale + bias + activation (+ fused 2x2 max-pool), transposed through a
 // wave-private LDS staging area, 16-byte stores (C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg).
 // The caller guarantees that no wave still reads (and no DMA still writes) the pipeline buffers the area overlays.
-template <bool F16, bool POOL, int RW, int NW>
-__device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][4], float *lds_f, const SplitConvArgs &a, int img,
+template <bool F16, bool POOL, int RW, int NW, int NJ = 4>
+__device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float *lds_f, const SplitConvArgs &a, int img,
                                                  int oy0, int ox0, int n0, int wave, int wm, int wn, int lane)
 {
     constexpr int MT = RW * 2;
-    constexpr int STAGE_LD = 64 + kStagePad;
+    constexpr int CW = 16 * NJ;                        // channels per wave
+    constexpr int STAGE_LD = CW + kStagePad;
+    constexpr int PP = CW / 4;                         // 16-byte pieces (or float4s) per pixel
     const int lr = lane & 15, kg = lane >> 4;
     // ---- epilogue (as in the 32x32 kernel; C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg) --
     float *stage = lds_f + wave * (32 * STAGE_LD);
-    float bias_v[4];
+    float bias_v[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + lr;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * CW + j * 16 + lr;
         bias_v[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     }
     const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
     const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
     const int cout_chunks = a.Cout >> 4;
-    const int nbase = n0 + wn * 64;
+    const int nbase = n0 + wn * CW;
     auto store_stage = [&](int npx_log2, int oy, int oxb, int OHo, int OWo) {
         if (oy >= OHo) return;
-        const int rounds = (16 << npx_log2) >> 6;
+        const int rounds = (PP << npx_log2) >> 6;
         if (a.out_f32) {
             float *out = reinterpret_cast<float *>(a.out);
             for (int rd = 0; rd < rounds; ++rd) {
                 const int e = rd * 64 + lane;
-                const int px = e >> 4, q = e & 15;
+                const int px = e / PP, q = e % PP;
                 const int ox = oxb + px, n = nbase + 4 * q;
                 if (ox < OWo && n < a.Cout) {
                     const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
@@ -478,7 +480,7 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][4], float 
             uint4 *out = reinterpret_cast<uint4 *>(a.out);
             for (int rd = 0; rd < rounds; ++rd) {
                 const int e = rd * 64 + lane;
-                const int px = e >> 4, q = e & 15;
+                const int px = e / PP, q = e % PP;
                 const int ox = oxb + px;
                 const int cl = q >> 2, pc = q & 3;
                 const int n = nbase + cl * 16;
@@ -501,7 +503,7 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][4], float 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
                     const float v0 = fmaxf(acc[hf][j][2 * r2], acc[hf][j][2 * r2 + 1]);            // row i = 0
@@ -517,7 +519,7 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][4], float 
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int px = 16 * hf + 4 * kg + r;
@@ -746,9 +748,9 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 
 // Tile schedule of a persistent workgroup: blockIdx & 7 labels the XCD; an XCD owns n-tiles (xcd % XN) + XN * k and
 // walks its slots.  next(): first real tile at or after `slot` (slots past the edge of the XN x XM ownership grid are
-// skipped); -1: none.  Tiles are 8 rows x 32 pixels x 128 channels.
+// skipped); -1: none.  Tiles are 8 rows x 32 pixels x bn channels.
 struct TileWalk {
-    int n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, n_slots, xcd, slot_stride;
+    int n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, n_slots, xcd, slot_stride, bn;
     __device__ __forceinline__ int next(int slot, int &img, int &oy0, int &ox0, int &n0) const
     {
         for (; slot < n_slots; slot += slot_stride) {
@@ -759,7 +761,7 @@ struct TileWalk {
             mt /= tiles_x;
             const int ty = mt % tiles_y;
             img = mt / tiles_y;
-            oy0 = ty * 8; ox0 = tx * TWS; n0 = nt * 128;
+            oy0 = ty * 8; ox0 = tx * TWS; n0 = nt * bn;
             return slot;
         }
         return -1;
@@ -869,11 +871,13 @@ __device__ __forceinline__ void split16_store_direct(f32x4 (&acc)[4][4], const S
     }
 }
 
-template <bool F16, bool POOL>
+template <bool F16, bool POOL, int BN>
 __global__ void __launch_bounds__(512, 2)
 conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    constexpr int TH = 8, NW = 8, WN = 2, BN = 128, RW = 2, MT = 4, PPP = 8;
+    constexpr int TH = 8, NW = 8, WN = 2, RW = 2, MT = 4, PPP = 8;
+    constexpr int NJ = BN / (16 * WN);                 // 16-channel MFMA tiles per wave: 4 (BN = 128) or 2 (BN = 64)
+    constexpr int B_PER_WAVE = BN * PPP / 64 / NW;     // weight DMA instructions per wave and tap: 2 or 1
     constexpr int HP = (TH + 2) * HW;                  // 340 halo pixels
     constexpr int A_INSTR = (HP * PPP + 63) / 64;      // 43 wave-instructions (1 KB each) per halo tile
     constexpr int ABUF = A_INSTR * 64;                 // pieces per halo buffer (the tail of the last KB is padding)
@@ -883,9 +887,10 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     // buffer 1 is dead (an even number of slices), so buffer 1 + spare is the epilogue's staging area: 8 waves x 32 px x
     // 68 floats = 69632 bytes = exactly what is left of the CU's 160 KB.
     constexpr int B_AT = ABUF, DUMP = B_AT + 3 * BSLOT, A1_AT = DUMP + 64;
-    constexpr int STAGE_PIECES = NW * 32 * (64 + kStagePad) * 4 / 16;
+    constexpr int STAGE_PIECES = NW * 32 * (16 * NJ + kStagePad) * 4 / 16;
     constexpr int LDS_UINT4 = A1_AT + (ABUF > STAGE_PIECES ? ABUF : STAGE_PIECES);
-    static_assert(A_PER_WAVE <= 9 && RW * (NW / WN) == TH && MT == 2 * RW && LDS_UINT4 * 16 <= 160 * 1024, "tile shape");
+    static_assert(A_PER_WAVE <= 9 && RW * (NW / WN) == TH && MT == 2 * RW && LDS_UINT4 * 16 <= 160 * 1024 &&
+                      (BN == 128 || BN == 64), "tile shape");
 
     __shared__ uint4 lds[LDS_UINT4];
     u32x4 *As = reinterpret_cast<u32x4 *>(lds);       // halo buffer b at As + b * A1_AT
@@ -903,7 +908,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     const int NTl = (n_tiles + XN - 1) / XN, MTl = (m_tiles + XM - 1) / XM;
     const int xcd = blockIdx.x & 7;
     const int slot_stride = gridDim.x >> 3;
-    const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride};
+    const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride, BN};
 #define next_tile(SLOT, IMG, OY0, OX0, N0) walk.next((SLOT), (IMG), (OY0), (OX0), (N0))
 
     const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
@@ -919,7 +924,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     // The source offset is recomputed at each use (top of an interval, where register pressure is lowest; ~25 VALU
     // operations against the interval's 48 MFMAs) instead of living in 6 registers through the whole kernel.
 #define halo_goff(J, IM, Y0, X0) halo_source_offset<NW, A_INSTR, HP * PPP>((J), wave, lane, (IM), (Y0), (X0), a.H, a.W, in_pix_stride)
-    const unsigned b_voff = (unsigned)(((2 * wave) * 64 + lane) * 16);   // this wave's 2 KB of a tap's 16 KB
+    const unsigned b_voff = (unsigned)(((B_PER_WAVE * wave) * 64 + lane) * 16);   // this wave's share of a tap's weights
 
 #define RPN_DMA_A(J, GOFF, SOFF, BUF)                                                                             \
     {                                                                                                             \
@@ -929,10 +934,11 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     }
 #define RPN_DMA_B(SOFF, SLOT)                                                                                     \
     {                                                                                                             \
-        u32x4 *dst_ = Bs + (SLOT) * BSLOT + (2 * wave) * 64;                                                      \
+        u32x4 *dst_ = Bs + (SLOT) * BSLOT + (B_PER_WAVE * wave) * 64;                                             \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 0, 0);             \
         /* the instruction offset advances BOTH the global and the LDS address */                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 1024, 0);          \
+        if constexpr (B_PER_WAVE == 2)                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 1024, 0);      \
     }
 
     int a_off[3][2];
@@ -943,10 +949,10 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
             const int hx = 16 * hf + lr + s3;
             a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
         }
-    int b_off[4];
+    int b_off[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wn * 64 + j * 16 + lr;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = wn * (16 * NJ) + j * 16 + lr;
         b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
     }
 
@@ -961,7 +967,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     // only the weight fragments are double-buffered: fx0 / fx1 hold [hi, lo] of the two 16-pixel tiles of row 0 / 1.
     //   half 0: MFMAs of row 0 (fx0, fw[cur]); reads: fx1 of THIS tap
     //   half 1: MFMAs of row 1 (fx1, fw[cur]); reads: fw[next] and fx0 of the NEXT tap
-    u32x4 fx0[4], fx1[4], fw[2][8];                   // fx: [16-px half * 2 + (0 hi | 1 lo)];  fw: [set][j * 2 + (0 hi | 1 lo)]
+    u32x4 fx0[4], fx1[4], fw[2][2 * NJ];                   // fx: [16-px half * 2 + (0 hi | 1 lo)];  fw: [set][j * 2 + (0 hi | 1 lo)]
 #define RPN_X_ADDR(BUF, ROW, S, I, II)   /* row I of the wave, element II = half * 2 + lohi */                       \
     (As[(BUF) * A1_AT + (RW * wm + (ROW) + (I)) * HW * PPP + (a_off[S][(II) >> 1] ^ (((II) & 1) ? 4 : 0))])
 #define RPN_W_ADDR(S, II)                /* element II = j * 2 + lohi */                                           \
@@ -979,7 +985,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     __builtin_amdgcn_s_barrier();
     RPN_STAMP_AT(2);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fw[0][i] = RPN_W_ADDR(0, i);
+    for (int i = 0; i < 2 * NJ; ++i) fw[0][i] = RPN_W_ADDR(0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) fx0[i] = RPN_X_ADDR(0, 0, 0, 0, i);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -990,11 +996,11 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     for (;;) {
         int nimg = 0, noy0 = 0, nox0 = 0, nn0 = 0;
         const int nxt = next_tile(cur + slot_stride, nimg, noy0, nox0, nn0);
-        f32x4 acc[MT][4];
+        f32x4 acc[MT][NJ];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
         for (int pair = 0; pair < (chunks >> 1); ++pair) {
@@ -1022,41 +1028,41 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 }
                 // ---- half 0: row 0.  Program order = intended issue order: a fragment read behind each of the first MFMAs
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {         // chain heads (x lo * w hi) of tiles (m = i >> 2, j = i & 3)
+                for (int i = 0; i < 2 * NJ; ++i) {    // chain heads (x lo * w hi) of tiles (m = i / NJ, j = i % NJ)
                     if (i < 4) fx1[i] = RPN_X_ADDR(CB, CR, CC, 1, i);
-                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2) + 1], fw[CS][2 * (i & 3)], acc[i >> 2][i & 3]);
+                    acc[i / NJ][i % NJ] = mfma16<F16>(fx0[2 * (i / NJ) + 1], fw[CS][2 * (i % NJ)], acc[i / NJ][i % NJ]);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2)], fw[CS][2 * (i & 3) + 1], acc[i >> 2][i & 3]);   // x hi * w lo
-                    acc[i >> 2][i & 3] = mfma16<F16>(fx0[2 * (i >> 2)], fw[CS][2 * (i & 3)], acc[i >> 2][i & 3]);       // x hi * w hi
+                for (int i = 0; i < 2 * NJ; ++i) {
+                    acc[i / NJ][i % NJ] = mfma16<F16>(fx0[2 * (i / NJ)], fw[CS][2 * (i % NJ) + 1], acc[i / NJ][i % NJ]);   // x hi * w lo
+                    acc[i / NJ][i % NJ] = mfma16<F16>(fx0[2 * (i / NJ)], fw[CS][2 * (i % NJ)], acc[i / NJ][i % NJ]);       // x hi * w hi
                 }
 #if RPN_DMA_SCHED
-                if (s9 < A_PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (s9 < A_PER_WAVE) __builtin_amdgcn_sched_group_barrier(0x020, B_PER_WAVE + 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, B_PER_WAVE, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * NJ - 4, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 // ---- half 1: row 1; the next tap's weights and row-0 pixels arrive meanwhile
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 2 * NJ; ++i) {
                     fw[NS][i] = RPN_W_ADDR(NC, i);
-                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2) + 1], fw[CS][2 * (i & 3)], acc[2 + (i >> 2)][i & 3]);
+                    acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ) + 1], fw[CS][2 * (i % NJ)], acc[2 + i / NJ][i % NJ]);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 2 * NJ; ++i) {
                     if (i < 4) fx0[i] = RPN_X_ADDR(NB, NR, NC, 0, i);
-                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2)], fw[CS][2 * (i & 3) + 1], acc[2 + (i >> 2)][i & 3]);
-                    acc[2 + (i >> 2)][i & 3] = mfma16<F16>(fx1[2 * (i >> 2)], fw[CS][2 * (i & 3)], acc[2 + (i >> 2)][i & 3]);
+                    acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ)], fw[CS][2 * (i % NJ) + 1], acc[2 + i / NJ][i % NJ]);
+                    acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ)], fw[CS][2 * (i % NJ)], acc[2 + i / NJ][i % NJ]);
                 }
 #if RPN_DMA_SCHED
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 2 * NJ; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
@@ -1065,11 +1071,17 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                if constexpr (4 * NJ - 8 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 8, 0);
                 __builtin_amdgcn_sched_barrier(0);     // (register-only MFMAs would otherwise sink below the barrier)
 #endif
-                if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                // leave exactly this interval's own DMAs in flight
+                if constexpr (B_PER_WAVE == 2) {
+                    if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else {
+                    if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
 #if RPN_DMA_SCHED
@@ -1081,7 +1093,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
         // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
         // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
         // first interval starts to refill buffer 1 -- hence one workgroup barrier per tile.
-        split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+        split16_epilogue<F16, POOL, RW, NW, NJ>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane);
         if (tile_no == 0) RPN_STAMP_AT(3);
         if (nxt < 0) break;
         __builtin_amdgcn_s_barrier();
@@ -1716,14 +1728,49 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
                                   int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
                                   bool pool, hipStream_t s)
 {
-    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 128 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
+    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
-    // large grids: 8 x 32 px x 128 ch tiles, one 8-wave workgroup per CU; small feature maps (no pooling there):
-    // 4 x 32 px x 64 ch tiles, 4 waves, two workgroups per CU
     const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
+    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+    const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
+                        (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
+    if (dma_ok) {
+        // Persistent LDS-DMA kernel: 8 x 32 px tiles, 128 channels wide -- or 64 wide where that is all there is
+        // (Cout <= 64) or where 128-wide tiles would leave CUs without a tile (the 31 x 31 layers).  One workgroup per
+        // CU (8 per XCD label at least), each walks the slots of its XCD label.
+        const int BN = (cout_pad % 128 != 0 || big_blocks < 256) ? 64 : 128;
+        const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8;
+        const int n_tiles = (Cout + BN - 1) / BN;
+        const long long m_tiles = (long long)tiles_x * tiles_y * B;
+        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+        const long long slots = (long long)((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
+        if (m_tiles <= 0 || slots > 0x0fffffffll) return hipErrorInvalidValue;
+        static const int n_cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+                n = 256;
+            return n;
+        }();
+        const unsigned pgrid = 8u * (unsigned)(slots < n_cus / 8 ? slots : n_cus / 8);
+#define RPN_L16D(F16_, POOL_, BN_)                                                                                   \
+    hipLaunchKernelGGL((conv3x3_split16_dma_kernel<F16_, POOL_, BN_>), dim3(pgrid), dim3(512), 0, s, a, tiles_x, tiles_y, \
+                       n_tiles)
+#define RPN_L16D_BN(F16_, POOL_)                                                                                     \
+    if (BN == 128) RPN_L16D(F16_, POOL_, 128); else RPN_L16D(F16_, POOL_, 64)
+        if (f16) { if (pool) { RPN_L16D_BN(true, true); } else { RPN_L16D_BN(true, false); } }
+        else { if (pool) { RPN_L16D_BN(false, true); } else { RPN_L16D_BN(false, false); } }
+#undef RPN_L16D_BN
+#undef RPN_L16D
+        return hipGetLastError();
+    }
+    // Register-staged kernels (an odd number of 32-channel slices, or RPN_S16_DMA=0).  Large grids: 8 x 32 px x 128 ch
+    // tiles, one 8-wave workgroup per CU; small feature maps (no pooling there): 4 x 32 px x 64 ch tiles, 4 waves, two
+    // workgroups per CU.
+    if (cout_pad % 128 != 0) return hipErrorInvalidValue;
     const bool small = big_blocks < 256 && !pool;
     const int TH = small ? 4 : 8, BN = small ? 64 : 128;
     const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + TH - 1) / TH;
@@ -1735,31 +1782,14 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
 #define RPN_L16(TH_, WN_, NW_, F16_, POOL_)                                                                          \
     hipLaunchKernelGGL((conv3x3_split16_kernel<TH_, WN_, NW_, F16_, POOL_>), dim3((unsigned)nblocks), dim3(64 * NW_), 0, s, \
                        a, tiles_x, tiles_y, n_tiles)
-    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
-    // persistent workgroups: one per CU (8 per XCD label at least), each walks the slots of its XCD label
-    static const int n_cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n;
-    }();
-    const long long slots = nblocks / 8;
-    const unsigned pgrid = 8u * (unsigned)(slots < n_cus / 8 ? slots : n_cus / 8);
-    const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
-                        (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
-#define RPN_L16D(F16_, POOL_)                                                                                        \
-    hipLaunchKernelGGL((conv3x3_split16_dma_kernel<F16_, POOL_>), dim3(pgrid), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles)
     if (small) {
         if (f16) RPN_L16(4, 1, 4, true, false); else RPN_L16(4, 1, 4, false, false);
-    } else if (dma_ok) {                               // persistent LDS-DMA pipeline
-        if (f16) { if (pool) RPN_L16D(true, true); else RPN_L16D(true, false); }
-        else { if (pool) RPN_L16D(false, true); else RPN_L16D(false, false); }
     } else if (f16) {
         if (pool) RPN_L16(8, 2, 8, true, true); else RPN_L16(8, 2, 8, true, false);
     } else {
         if (pool) RPN_L16(8, 2, 8, false, true); else RPN_L16(8, 2, 8, false, false);
     }
 #undef RPN_L16
-#undef RPN_L16D
     return hipGetLastError();
 }
 

@@ -85,14 +85,19 @@ struct rpn_model {
 
 namespace rpn {
 
-// The 16x16x32-MFMA split kernel is used for every eligible layer with Cin >= 128 (RPN_SPLIT_MFMA16=0 switches it
-// off).  Measured on VGG16, batch 8 (A/B in one process, same box): +4 % at Cin = 128, +8-12 % at Cin >= 256 on the
-// 8 x 32 px x 128 ch tiles, +20 % on the 31 x 31 layers (4 x 32 px x 64 ch tiles), -3 % at Cin = 64 (2 slices only).
+// The 16x16x32-MFMA split kernels ("split32" weight packing) take every 3x3 layer whose channel count gives an even
+// number of 32-channel slices (the persistent LDS-DMA kernel: Cin = 64, 128, 256, 512 in VGG16) and, register-staged,
+// the other Cin >= 128 layers with 128-wide output tiles.  RPN_SPLIT_MFMA16=0 switches them off (32x32x16 kernels).
 static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
 {
     static const int mode = getenv("RPN_SPLIT_MFMA16") ? atoi(getenv("RPN_SPLIT_MFMA16")) : 1;
+    static const int dma = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
     (void)H; (void)W; (void)B;
-    return mode != 0 && Cin % 32 == 0 && Cin >= 128 && Cout > 64;
+    if (mode == 0 || Cin % 32 != 0) return false;
+    if (Cout <= 64) return false;       // block1_conv2 (64 -> 64, fused pool): measured 0.43 ms on the 64-wide persistent
+                                        // tiles against 0.39 ms on the 32x32x16 kernel (each tile re-reads all the weights)
+    if (dma && Cin % 64 == 0) return true;
+    return Cin >= 128;
 }
 
 static int add_tensor(rpn_model *m, const std::string &name, int H, int W, int C, bool external = false)
