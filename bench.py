@@ -112,16 +112,16 @@ def cpu_baseline(backbone, hyper_params, weights, iou_threshold, target_seconds)
 
 def measured_traffic(kernel, precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same
-    command); null when no profile matches the precision being run."""
+    (profiles/*_traffic.json, written by scripts/make_traffic.py under the same kernel names as this file's
+    per-op table: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command);
+    null when no profile matches the kernel and precision being run."""
     import glob
-    fam = "conv3x3_split" if "split" in kernel else ("conv_igemm_f32" if "igemm" in kernel else None)
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % precision)))
-    if not fam or not paths:
+    if not paths:
         return None
     try:
         with open(paths[-1]) as f:
-            return round(json.load(f)["kernels"][fam]["hbm_bytes_per_launch"])
+            return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 

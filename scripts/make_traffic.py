@@ -3,8 +3,19 @@ FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide coalesced 
 WRITE_SIZE as is; both are reported by rocprofv3 in KiB."""
 import csv, glob, json, os, sys, collections
 root, out = sys.argv[1], sys.argv[2]
-fam = lambda k: ("conv3x3_split" if "conv3x3_split_kernel" in k else "conv_igemm_f32" if "conv_igemm_f32" in k else
-                 "nms_kernel" if "nms_kernel" in k else "conv_cin3" if "conv_cin3" in k else None)
+import re
+def fam(k):
+    """rocprofv3 kernel name -> the kernel name bench.py prints for the op (both POOL instantiations together)."""
+    prec = lambda f16: "f16x3" if f16 == "true" else "bf16x3"
+    m = re.search(r"conv3x3_split16_dma_kernel<(true|false), (true|false), (\d+)>", k)
+    if m: return "conv3x3_split16_dma<%s,%s>" % (prec(m.group(1)), m.group(3))
+    m = re.search(r"conv3x3_split16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", k)
+    if m: return "conv3x3_split16<%s,%d>" % (prec(m.group(4)), 64 * int(m.group(2)))
+    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", k)
+    if m: return "conv3x3_split<%s>" % prec(m.group(5))
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
+    return "nms_kernel" if "nms_kernel" in k else "conv_cin3" if "conv_cin3" in k else None
 acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_fetch": 0, "n_write": 0})
 for name in ("fetch", "write"):
     for path in glob.glob(os.path.join(root, name, "**", "*counter_collection.csv"), recursive=True):

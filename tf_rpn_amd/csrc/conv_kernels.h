@@ -68,6 +68,9 @@ void pack_weights_split32_host(const float *hwio, const float *scale, int Cin, i
 hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                   int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
                                   bool pool, hipStream_t s);
+// which 16x16x32 kernel launch_conv3x3_split16 picks for a layer: "dma,128" | "dma,64" (persistent LDS-DMA kernel,
+// tile width in channels) or "reg,128" | "reg,64" (register-staged kernels); nullptr: not launchable
+const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int cout_pad, bool pool);
 hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, void *out, hipStream_t s);
 hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, float *out, hipStream_t s);
 hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);

@@ -736,6 +736,9 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 //   WAR  the ring slot of tap t+3 is the slot of tap t, whose fragments were read in interval t-1 and retired by the
 //        lgkmcnt(0) in front of that interval's barrier.  The other halo buffer was last read in interval 7 of the
 //        previous slice.
+// (Tried: a 6-slot ring at 64 channels per tile -- weights four intervals ahead -- and the halo pieces two per tap behind
+// the weights of taps 0..2 so that the in-order counter gives them two intervals to land: no gain on any layer, the DMA
+// latency is already covered.)
 // The weights in HBM are already the swizzled LDS image ("split32" packing), so their DMA is a linear copy; the halo
 // tile's swizzle is applied on the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  Out-of-image halo
 // pixels are out-of-range buffer offsets: the DMA writes zeros for them (checked: scripts/micro/dma_oob.hip).
@@ -1724,6 +1727,18 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
 }
 
 // 16x16x32-MFMA kernel (weights in "split32" packing).  Needs Cin % 32 == 0 and cout_pad % 128 == 0.
+const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int cout_pad, bool pool)
+{
+    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || cout_pad < Cout) return nullptr;
+    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+    const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
+    const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
+                        (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
+    if (dma_ok) return (cout_pad % 128 != 0 || big_blocks < 256) ? "dma,64" : "dma,128";
+    if (cout_pad % 128 != 0) return nullptr;
+    return (big_blocks < 256 && !pool) ? "reg,64" : "reg,128";
+}
+
 hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                   int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
                                   bool pool, hipStream_t s)
@@ -1733,15 +1748,14 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
+    const char *variant = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, pool);
+    if (!variant) return hipErrorInvalidValue;
     const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
-    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
-    const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
-                        (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
-    if (dma_ok) {
+    if (variant[0] == 'd') {
         // Persistent LDS-DMA kernel: 8 x 32 px tiles, 128 channels wide -- or 64 wide where that is all there is
         // (Cout <= 64) or where 128-wide tiles would leave CUs without a tile (the 31 x 31 layers).  One workgroup per
         // CU (8 per XCD label at least), each walks the slots of its XCD label.
-        const int BN = (cout_pad % 128 != 0 || big_blocks < 256) ? 64 : 128;
+        const int BN = variant[4] == '6' ? 64 : 128;
         const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8;
         const int n_tiles = (Cout + BN - 1) / BN;
         const long long m_tiles = (long long)tiles_x * tiles_y * B;
@@ -1770,7 +1784,6 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
     // Register-staged kernels (an odd number of 32-channel slices, or RPN_S16_DMA=0).  Large grids: 8 x 32 px x 128 ch
     // tiles, one 8-wave workgroup per CU; small feature maps (no pooling there): 4 x 32 px x 64 ch tiles, 4 waves, two
     // workgroups per CU.
-    if (cout_pad % 128 != 0) return hipErrorInvalidValue;
     const bool small = big_blocks < 256 && !pool;
     const int TH = small ? 4 : 8, BN = small ? 64 : 128;
     const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + TH - 1) / TH;

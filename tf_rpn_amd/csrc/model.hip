@@ -682,7 +682,18 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_CONV && op.split) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
         by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
-        k = m->f16 ? "conv3x3_split<f16x3>" : "conv3x3_split<bf16x3>";     // (16x16x32- and 32x32x16-MFMA variants)
+        // the kernel template that runs this layer (both POOL instantiations under one name)
+        static thread_local char kname[64];
+        const char *prec = m->f16 ? "f16x3" : "bf16x3";
+        if (op.k16) {
+            const bool fused_pool = i + 1 < (int)m->ops.size() && m->ops[i + 1].kind == OP_POOL && m->ops[i + 1].split;
+            const char *v = conv3x3_split16_variant(m->max_batch, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout), fused_pool);
+            if (v && v[0] == 'd') snprintf(kname, sizeof kname, "conv3x3_split16_dma<%s,%s>", prec, v + 4);
+            else snprintf(kname, sizeof kname, "conv3x3_split16<%s,%s>", prec, v ? v + 4 : "?");
+        } else {
+            snprintf(kname, sizeof kname, "conv3x3_split<%s>", prec);
+        }
+        k = kname;
     } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
         fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
         by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
