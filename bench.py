@@ -10,8 +10,9 @@ all-gather of the proposal records.  Inputs are resident in HBM before the timed
 At N = 1 the workload is BASELINE.json configs[1] (batch 8, VGG16 backbone + RPN head).
 Images shard over ranks (weak scaling: the per-GPU batch is fixed), no other data-path collective.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128x128 f32-MFMA implicit-GEMM
-conv), timed live with HIP events recorded on the launch stream around every launch of the timed steps;
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (f16x3 / bf16x3: the persistent LDS-DMA
+16x16x32-MFMA conv; f32: the 128x128 f32-MFMA implicit-GEMM conv), found by an untimed pre-pass and then timed
+live with HIP events recorded on the launch stream around each of its launches in the K timed steps;
 `cpu_baseline` is the CPU oracle (torch-CPU conv stack + plain-C decode/NMS restatement: a "port", the
 TF2 reference cannot run here) timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
@@ -196,9 +197,25 @@ def main():
         prop.flush_distributed(gather_bufs)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
     model = prop.rpn_model
-    model.set_profiling(args.steps)               # HIP events on the launch stream around every launch of the K steps
     ops = model.ops()
-    op_ms = [0.0] * len(ops)
+
+    def dominant_kernel(ms_per_op):               # the conv kernel template with the largest total time
+        tot = {}
+        for op, ms in zip(ops, ms_per_op):
+            tot[op["kernel"]] = tot.get(op["kernel"], 0.0) + ms
+        return max(tot, key=tot.get)
+
+    # untimed pre-pass: every op timed, to find the dominant kernel.  The timed region then carries HIP events only
+    # around ITS launches (2 events per launch on the launch stream; events around all 20 ops cost ~2.5 % of a step).
+    model.set_profiling(2)
+    for _ in range(2):
+        step()
+    if overlap and use_dist:
+        prop.flush_distributed(gather_bufs)
+    torch.cuda.synchronize()
+    dom = dominant_kernel(model.profile_ms()[0])
+    model.set_profiling_mask([op["kernel"] == dom for op in ops])
+    model.set_profiling(args.steps)
     nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
@@ -227,8 +244,18 @@ def main():
         prop.wait()                               # the last step's NMS must finish inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
-    # mean per-op durations over the K timed steps (events were recorded on the launch stream, read here)
-    last_ms, _kept = model.profile_ms()
+    # mean durations of the dominant kernel's launches over the K timed steps (events were recorded on the launch
+    # stream, read here); the other ops' durations come from an untimed post-pass with every op timed
+    dom_ms, _kept = model.profile_ms()
+    model.set_profiling_mask(None)
+    model.set_profiling(3)
+    for _ in range(3):
+        step()
+    if overlap and use_dist:
+        prop.flush_distributed(gather_bufs)
+    torch.cuda.synchronize()
+    all_ms, _ = model.profile_ms()
+    last_ms = [d if op["kernel"] == dom else a for op, d, a in zip(ops, dom_ms, all_ms)]
     model.set_profiling(0)
     if overlap:                                   # time decode+NMS alone, after the region, for the report
         torch.cuda.synchronize()
@@ -262,7 +289,6 @@ def main():
             d["ms"] += ms
             d["flops"] += op["flops_per_image"] * B
             d["launches"] += 1
-        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
         d = by_kernel[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
@@ -271,6 +297,7 @@ def main():
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flops_per_launch": d["flops"] / d["launches"],
+                    "timing": "HIP events on the launch stream around this kernel's launches in the K timed steps",
                     "conv_stack_ms": round(sum(last_ms), 3), "decode_nms_ms": round(nms_ms, 4)}
         out = {
             "metric": "proposal images/sec at 500x500x3 VOC batch; NMS boxes/sec",

@@ -80,6 +80,7 @@ struct rpn_model {
     // optional per-op timing: one hipEvent before the first op and one after every op
     int profiling = 0;                 // number of forwards whose events are kept (ring)
     std::vector<hipEvent_t> events;    // profiling x (ops + 1)
+    std::vector<unsigned char> prof_mask;   // empty: time every op; else only the ops marked non-zero
     long long profiled_forwards = 0;
 };
 
@@ -581,9 +582,14 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             m->profiled_forwards = 0;
         }
         evs = m->events.data() + per * (size_t)(m->profiled_forwards % m->profiling);
-        RPN_HIP_CHECK(hipEventRecord(evs[0], s));
+        if (m->prof_mask.empty() || m->prof_mask[0]) RPN_HIP_CHECK(hipEventRecord(evs[0], s));
         ++m->profiled_forwards;
     }
+    // event i+1 closes op i and opens op i+1: with a mask only the boundaries of marked ops are recorded
+    auto want_event = [&](size_t boundary) {
+        if (m->prof_mask.empty()) return true;
+        return (boundary > 0 && m->prof_mask[boundary - 1]) || (boundary < m->ops.size() && m->prof_mask[boundary]);
+    };
     int op_index = 0;
     bool skip_next = false;
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
@@ -642,7 +648,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             return fail(RPN_ERR_NO_DEVICE, "rpn_model_forward: layer '%s' failed to launch: %s", op.name.c_str(),
                         hipGetErrorString(e));
         ++op_index;
-        if (evs) RPN_HIP_CHECK(hipEventRecord(evs[op_index], s));
+        if (evs && want_event((size_t)op_index)) RPN_HIP_CHECK(hipEventRecord(evs[op_index], s));
     }
     return RPN_OK;
 }
@@ -652,6 +658,18 @@ extern "C" int rpn_model_set_profiling(rpn_model *m, int n_forwards)
 {
     RPN_REQUIRE(m && n_forwards >= 0 && n_forwards <= 4096, "rpn_model_set_profiling: bad argument");
     m->profiling = n_forwards;
+    m->profiled_forwards = 0;
+    return RPN_OK;
+}
+
+// Restrict the per-op events to the ops with mask[i] != 0 (NULL: every op).  A throughput run that only needs the
+// dominant kernel's durations then records 2 events per marked launch instead of one per op.
+extern "C" int rpn_model_set_profiling_mask(rpn_model *m, const unsigned char *mask, int n)
+{
+    RPN_REQUIRE(m, "rpn_model_set_profiling_mask: null model");
+    if (!mask) { m->prof_mask.clear(); return RPN_OK; }
+    RPN_REQUIRE(n == (int)m->ops.size(), "rpn_model_set_profiling_mask: mask has %d entries, the model %d ops", n, (int)m->ops.size());
+    m->prof_mask.assign(mask, mask + n);
     m->profiled_forwards = 0;
     return RPN_OK;
 }
@@ -725,8 +743,9 @@ extern "C" int rpn_model_get_profile(rpn_model *m, float *ms, int n, int *n_forw
     for (size_t i = 0; i < m->ops.size(); ++i) ms[i] = 0.0f;
     for (int f = 0; f < kept; ++f) {
         hipEvent_t *evs = m->events.data() + per * (size_t)f;
-        RPN_HIP_CHECK(hipEventSynchronize(evs[per - 1]));
         for (size_t i = 0; i < m->ops.size(); ++i) {
+            if (!m->prof_mask.empty() && !m->prof_mask[i]) continue;          // not timed: stays 0
+            RPN_HIP_CHECK(hipEventSynchronize(evs[i + 1]));
             float t = 0.0f;
             RPN_HIP_CHECK(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
             ms[i] += t / (float)kept;

@@ -138,6 +138,14 @@ class RPNModel(object):
         """Keep HIP-event timings of the last ``n_forwards`` forwards (0 switches profiling off)."""
         L.check(L.lib().rpn_model_set_profiling(self._h, int(n_forwards)), "rpn_model_set_profiling")
 
+    def set_profiling_mask(self, mask=None):
+        """Time only the ops with a true entry in ``mask`` (one per op; None: every op)."""
+        if mask is None:
+            L.check(L.lib().rpn_model_set_profiling_mask(self._h, None, 0), "rpn_model_set_profiling_mask")
+            return
+        buf = (ctypes.c_ubyte * len(mask))(*[1 if v else 0 for v in mask])
+        L.check(L.lib().rpn_model_set_profiling_mask(self._h, buf, len(mask)), "rpn_model_set_profiling_mask")
+
     def ops(self):
         """[{name, kernel, flops_per_image, bytes_per_image}] in launch order."""
         lib = L.lib()
