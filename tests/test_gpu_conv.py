@@ -184,6 +184,12 @@ SPLIT_CASES = [
     (8, 62, 62, 256, 512, "relu"),         # block4_conv1: tall tiles, 512 blocks
     (1, 13, 9, 32, 48, "linear"),          # Cout = 48 (cout_pad 64), signed outputs
     (1, 40, 33, 128, 256, "relu6"),
+    # persistent LDS-DMA kernel (even number of 32-channel slices)
+    (8, 125, 125, 128, 128, "relu"),       # 512 tiles: every workgroup walks two tiles (tap stream crosses a tile boundary)
+    (3, 50, 45, 128, 384, "relu"),         # 3 n-tiles on a 2 x 4 XCD ownership grid: padding slots are skipped
+    (1, 9, 40, 64, 192, "linear"),         # Cin = 64 (two slices per tile), ragged rows / columns, signed outputs
+    (2, 31, 31, 256, 320, "relu"),         # 64-wide tiles (small map), Cout not a multiple of 128
+    (1, 16, 64, 192, 128, "relu"),         # exact tiles, 6 slices
 ]
 
 

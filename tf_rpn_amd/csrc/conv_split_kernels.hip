@@ -438,6 +438,14 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Timing experiment only (-DRPN_NOSTORE): every epilogue store of a lane goes to one 16-byte slot per lane, so the
+// instruction stream is unchanged but no output traffic reaches HBM.
+#ifdef RPN_NOSTORE
+#define RPN_STORE_INDEX(i) ((i) & 63)
+#else
+#define RPN_STORE_INDEX(i) (i)
+#endif
+
 // Epilogue shared by the 16x16x32 kernels: scale + bias + activation (+ fused 2x2 max-pool), transposed through a
 // wave-private LDS staging area, 16-byte stores (C/D of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg).
 // The caller guarantees that no wave still reads (and no DMA still writes) the pipeline buffers the area overlays.
@@ -491,7 +499,7 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float
                     const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
                     xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
                     xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-                    out[((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
+                    out[RPN_STORE_INDEX(((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc)] =
                         split_piece<F16>(xs, (pc & 1) != 0);
                 }
             }
@@ -986,7 +994,6 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     for (int t = 0; t < 3; ++t) RPN_DMA_B(t * w_tap_bytes + n0 * (PPP * 16), t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    RPN_STAMP_AT(2);
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) fw[0][i] = RPN_W_ADDR(0, i);
 #pragma unroll
@@ -1077,8 +1084,13 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 if constexpr (4 * NJ - 8 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 8, 0);
                 __builtin_amdgcn_sched_barrier(0);     // (register-only MFMAs would otherwise sink below the barrier)
 #endif
-                // leave exactly this interval's own DMAs in flight
-                if constexpr (B_PER_WAVE == 2) {
+                // Leave exactly this interval's own DMAs in flight.  Not in a tile's first interval: what it needs (tap 2) was
+                // retired by the vmcnt(0) in front of the previous tile's epilogue (or by the prologue), and the in-order
+                // counter would otherwise make the wave wait for that epilogue's global stores -- all 256 workgroups
+                // finish their tiles together, so those stores are a burst (stamps: 12.9k cycles of epilogue in steady
+                // state against 6.5k on a workgroup's first tile).  The stores now have two intervals to drain.
+                if (T == 0 && pair == 0) {
+                } else if constexpr (B_PER_WAVE == 2) {
                     if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else {
@@ -1090,16 +1102,18 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
 #if RPN_DMA_SCHED
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                if (s9 == 8 && tile_no == 0) RPN_STAMP_AT(4 + 2 * pair + c2);
+                if (s9 == 8 && tile_no == 1) RPN_STAMP_AT(4 + 2 * pair + c2);   // (second tile: steady state)
             }
         }
         // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
         // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
         // first interval starts to refill buffer 1 -- hence one workgroup barrier per tile.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last interval's weight DMAs (issued a whole interval ago)
         split16_epilogue<F16, POOL, RW, NW, NJ>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane);
-        if (tile_no == 0) RPN_STAMP_AT(3);
+        if (tile_no == 1) RPN_STAMP_AT(3);
         if (nxt < 0) break;
         __builtin_amdgcn_s_barrier();
+        if (tile_no == 0) RPN_STAMP_AT(2);
         cur = nxt; img = nimg; oy0 = noy0; ox0 = nox0; n0 = nn0;
         gt -= total_taps;
         ++tile_no;
