@@ -25,6 +25,12 @@
 //
 // Roofline: MFMA-bound; 3 MFMAs per algorithmic product, so the algorithmic peak is
 // (dense 16-bit MFMA peak, 2.5 PFLOP/s) / 3.
+//
+// Three kernel families share that design (DESIGN.md 4.1 has the measurements that chose between them):
+//   conv3x3_split_kernel        32x32x16 MFMA, 16-channel slices, register-staged          (Cin = 64 -> 64: block1_conv2)
+//   conv3x3_split16_kernel      16x16x32 MFMA, 32-channel slices, register-staged          (odd slice counts)
+//   conv3x3_split16_dma_kernel  16x16x32 MFMA, LDS-DMA staging, one barrier per tap, persistent workgroups whose tap
+//                               stream runs on across tiles                                 (11 of VGG16's 13 3x3 layers)
 #include "conv_kernels.h"
 
 #include <cmath>
@@ -797,89 +803,6 @@ __device__ __forceinline__ unsigned halo_source_offset(int j, int wave, int lane
     const int lg = ps ^ ((hx >> 1) & 7);              // logical piece: lo * 4 + k-group
     const int q = (((lg & 3) >> 1) << 2) | ((lg & 1) << 1) | (lg >> 2);   // its place in the slice's SPLIT16 records
     return in ? (unsigned)((((im * H + iy) * W + ix) * in_pix_stride + q) * 16) : 0x80000000u;
-}
-
-// 4 floats -> the 8-byte hi half and the 8-byte lo half of their SPLIT16 piece
-template <bool F16>
-__device__ __forceinline__ void split4(const float (&x)[4], uint2 &hi, uint2 &lo)
-{
-    using E = typename Half<F16>::elem;
-    using E4 = __attribute__((ext_vector_type(4))) E;
-    E4 h, l;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        h[k] = (E)x[k];
-        l[k] = (E)(x[k] - (float)h[k]);
-    }
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
-}
-
-// Epilogue of the operand-swapped kernel.  acc[m][j][r]: pixel (row RW*wm + (m >> 1), column 16 * (m & 1) + (lane & 15)),
-// channel n0 + 64 wn + 16 j + 4 (lane >> 4) + r.
-template <bool F16, bool POOL>
-__device__ __forceinline__ void split16_store_direct(f32x4 (&acc)[4][4], const SplitConvArgs &a, int img, int oy0, int ox0,
-                                                     int n0, int wm, int wn, int lane)
-{
-    const int lr = lane & 15, kg = lane >> 4;
-    const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
-    const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
-    const int cout_chunks = a.Cout >> 4;
-    const int c0 = n0 + wn * 64 + 4 * kg;                 // + 16 j
-    float bias_v[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = c0 + 16 * j;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias && n < a.Cout) b = *reinterpret_cast<const float4 *>(a.bias + n);
-        bias_v[j][0] = b.x; bias_v[j][1] = b.y; bias_v[j][2] = b.z; bias_v[j][3] = b.w;
-    }
-    // one pixel's 4 channels: float4, or the two 8-byte halves of the piece (record = [hi0-7 | lo0-7 | hi8-15 | lo8-15])
-    auto store4 = [&](const float (&v)[4], int oy, int ox, int OHo, int OWo, int n, bool want_hi, bool want_lo) {
-        if (oy >= OHo || ox >= OWo || n >= a.Cout) return;
-        const size_t pix = ((size_t)img * OHo + oy) * OWo + ox;
-        if (a.out_f32) {
-            if (want_hi) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.out) + pix * a.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
-            return;
-        }
-        uint2 hi, lo;
-        split4<F16>(v, hi, lo);
-        uint2 *rec = reinterpret_cast<uint2 *>(a.out) + (pix * cout_chunks + (n >> 4)) * 8 + ((n >> 3) & 1) * 4 + ((n >> 2) & 1);
-        if (want_hi) rec[0] = hi;
-        if (want_lo) rec[2] = lo;
-    };
-    if constexpr (POOL) {
-        // MaxPooling2D(2,2) 'valid' fused: rows (2 wm, 2 wm + 1) are tiles m and m + 2 of this wave, the column pair is
-        // lanes (lr, lr ^ 1); max commutes with the monotone scale + bias + activation applied afterwards.  Both lanes of
-        // a pair end up with the pooled pixel: the even one stores its hi half, the odd one its lo half.
-        const int OHo = a.H >> 1, OWo = a.W >> 1;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = fmaxf(acc[hf][j][r], acc[2 + hf][j][r]);
-                    t = fmaxf(t, __shfl_xor(t, 1));
-                    v[r] = fminf(fmaxf(t * a.out_scale + bias_v[j][r], act_lo), act_hi);
-                }
-                const bool even = (lr & 1) == 0;
-                store4(v, (oy0 + 2 * wm) >> 1, (ox0 >> 1) + 8 * hf + (lr >> 1), OHo, OWo, c0 + 16 * j,
-                       a.out_f32 ? even : even, a.out_f32 ? false : !even);
-            }
-    } else {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = fminf(fmaxf(acc[m][j][r] * a.out_scale + bias_v[j][r], act_lo), act_hi);
-                store4(v, oy0 + 2 * wm + (m >> 1), ox0 + 16 * (m & 1) + lr, a.H, a.W, c0 + 16 * j, true, true);
-            }
-    }
 }
 
 template <bool F16, bool POOL, int BN>
