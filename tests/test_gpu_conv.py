@@ -283,3 +283,35 @@ def test_split_round_trip_and_pool():
         c2 = model.get_activation("block1_conv2", batch=1).cpu().numpy()
         p = model.get_activation("block1_pool", batch=1).cpu().numpy()
         assert np.array_equal(p, co.maxpool2x2(c2))
+
+
+@pytest.mark.gpu
+def test_split_conv_dynamic_tile_schedule_subprocess():
+    """RPN_S16_DYN=1 (tile queue of the persistent kernel) and RPN_S16_C64=1 (64 -> 64 layers on it) are read once per
+    process: run the persistent-kernel cases in a child process with both set.  Same results required (the schedule
+    only changes which workgroup computes which tile); two launches per case check that a launch re-arms the queue."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from oracle import conv_oracle as cv
+        from tests.test_gpu_conv import _conv_gpu
+        worst = 0.0
+        for (B, H, W, Cin, Cout, act) in [(8, 125, 125, 128, 128, "relu"), (3, 50, 45, 128, 384, "relu"),
+                                          (2, 31, 31, 256, 320, "relu"), (2, 21, 45, 64, 64, "relu"), (1, 9, 40, 64, 192, "linear")]:
+            rng = np.random.RandomState(B * 1000 + H)
+            x = rng.uniform(-1, 1, size=(B, H, W, Cin)).astype(np.float32)
+            w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+            b = rng.uniform(-0.5, 0.5, size=(Cout,)).astype(np.float32)
+            ref = cv.conv2d_nhwc(x, w, b, pad=(1, 1, 1, 1), act=act, dtype=torch.float64)
+            for rep in range(2):
+                got = _conv_gpu(x, w, b, 1, 1, 1, H, W, act, precision="f16x3")
+                assert not np.isnan(got).any(), "some outputs were never written"
+                worst = max(worst, float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
+        assert worst <= 1e-5, worst
+        print("dynamic schedule ok, worst scaled error %%.2e" %% worst)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, RPN_S16_DYN="1", RPN_S16_C64="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "dynamic schedule ok" in r.stdout
