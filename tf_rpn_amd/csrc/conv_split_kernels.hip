@@ -460,8 +460,10 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
 // The caller guarantees that no wave still reads (and no DMA still writes) the pipeline buffers the area overlays.
 template <bool F16, bool POOL, int RW, int NW, int NJ = 4>
 __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float *lds_f, const SplitConvArgs &a, int img,
-                                                 int oy0, int ox0, int n0, int wave, int wm, int wn, int lane)
+                                                 int oy0, int ox0, int n0, int wave, int wm, int wn, int lane,
+                                                 int stamp_base = -1 /* -DRPN_STAMP builds: first of 4 stamp slots */)
 {
+    (void)stamp_base;
     constexpr int MT = RW * 2;
     constexpr int CW = 16 * NJ;                        // channels per wave
     constexpr int STAGE_LD = CW + kStagePad;
@@ -544,8 +546,10 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float
                             fminf(fmaxf(acc[i * 2 + hf][j][r] * a.out_scale + bias_v[j], act_lo), act_hi);
                     }
             wave_sync();
+            if (stamp_base >= 0) RPN_STAMP_AT(stamp_base + 2 * i);
             store_stage(5, oy0 + RW * wm + i, ox0, a.H, a.W);
             wave_sync();
+            if (stamp_base >= 0) RPN_STAMP_AT(stamp_base + 2 * i + 1);
         }
     }
 }
@@ -1095,8 +1099,15 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
         // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
         // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
         // first interval starts to refill buffer 1 -- hence one workgroup barrier per tile.
+        if (tile_no < 2) RPN_STAMP_AT(20 + 6 * tile_no);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last interval's weight DMAs (issued a whole interval ago)
+        if (tile_no < 2) RPN_STAMP_AT(21 + 6 * tile_no);
+#ifdef RPN_STAMP
+        split16_epilogue<F16, POOL, RW, NW, NJ>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane,
+                                                tile_no < 2 ? 22 + 6 * tile_no : -1);
+#else
         split16_epilogue<F16, POOL, RW, NW, NJ>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+#endif
         if (tile_no == 1) RPN_STAMP_AT(3);
         if (nxt < 0) break;
         __builtin_amdgcn_s_barrier();
