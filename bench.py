@@ -274,6 +274,19 @@ def main():
     else:
         nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / args.steps
 
+    gather_ms = None
+    if use_dist:                                  # the all-gather alone, after the region, for the report
+        src = prop._bufs[0] if overlap else {"boxes": prop._boxes, "scores": prop._scores, "valid": prop._valid}
+        rec = prop.pack_records(src["boxes"][:B], src["scores"][:B], src["valid"][:B])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_gather_into_tensor(gather_bufs[0], rec)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_ms = e0.elapsed_time(e1) / 10
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +333,7 @@ def main():
                                        + ("; all-gather of step k-1 issued behind the convs of step k" if use_dist else ""))
                                       if overlap else "serial on the conv stream"},
             "nms_boxes_per_sec": round(B * prop.total_anchors / (nms_ms * 1e-3), 1),
+            "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
             "roofline": roofline,
         }
         if args.layers:
