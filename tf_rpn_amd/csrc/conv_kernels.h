@@ -43,6 +43,7 @@ struct ConvArgs {
 };
 
 // dense convolution as an implicit GEMM on the f32 MFMA; returns hipGetLastError()
+int conv_f32_tile_n(int B, int OH, int OW, int Cout);   // N tile (128 | 64 | 32) launch_conv_f32 picks for a layer
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream);
 
 // MaxPooling2D(2,2) 'valid' (floors odd sizes), NHWC, C % 4 == 0

@@ -301,10 +301,30 @@ static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Output channels per workgroup tile (128 | 64 | 32) of the f32 implicit-GEMM conv for a layer: the widest tile that
+// fits Cout -- unless that leaves CUs without a workgroup (single images, small feature maps: MobileNetV2's 1x1 layers
+// at batch 1 give 32 workgroups of 128 x 128), then the narrowest tile that fills them, or failing that the one with
+// the most workgroups.  Every variant handles every Cout (cout_pad is a multiple of 32).
+int conv_f32_tile_n(int B, int OH, int OW, int Cout)
+{
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            n = 256;
+        return n;
+    }();
+    const long long m_tiles = (long long)((OW + TW - 1) / TW) * ((OH + TH - 1) / TH) * B;
+    int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    while (bn > 32 && m_tiles * ((Cout + bn - 1) / bn) < n_cus) bn >>= 1;
+    return bn;
+}
+
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream)
 {
-    if (a.Cout > 64) return launch_variant<2, 2, 2, 2>(a, stream);     // 128 x 128
-    if (a.Cout > 32) return launch_variant<4, 1, 1, 2>(a, stream);     // 128 x 64
+    const int bn = conv_f32_tile_n(a.B, a.OH, a.OW, a.Cout);
+    if (bn == 128) return launch_variant<2, 2, 2, 2>(a, stream);       // 128 x 128
+    if (bn == 64) return launch_variant<4, 1, 1, 2>(a, stream);        // 128 x 64
     return launch_variant<4, 1, 1, 1>(a, stream);                      // 128 x 32
 }
 

@@ -719,8 +719,10 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
         fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
         by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
-        if (op.ps.generic) k = op.Cout > 64 ? "conv_igemm_f32<128x128,generic>" : (op.Cout > 32 ? "conv_igemm_f32<128x64,generic>" : "conv_igemm_f32<128x32,generic>");
-        else k = op.Cout > 64 ? "conv_igemm_f32<128x128>" : (op.Cout > 32 ? "conv_igemm_f32<128x64>" : "conv_igemm_f32<128x32>");
+        static thread_local char kname32[64];
+        snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
+                 op.ps.generic ? ",generic" : "");
+        k = kname32;
     } else if (op.kind == OP_DWCONV) {
         fl = 2.0 * op.OH * op.OW * op.Cin * 9;
         by = in_b + out_b;
