@@ -190,6 +190,10 @@ SPLIT_CASES = [
     (1, 9, 40, 64, 192, "linear"),         # Cin = 64 (two slices per tile), ragged rows / columns, signed outputs
     (2, 31, 31, 256, 320, "relu"),         # 64-wide tiles (small map), Cout not a multiple of 128
     (1, 16, 64, 192, 128, "relu"),         # exact tiles, 6 slices
+    # register-staged 16x16x32 kernels (an odd number of 32-channel slices)
+    (2, 20, 40, 160, 128, "relu"),         # 5 slices, 4 x 32 px x 64 ch tiles (small grid)
+    (8, 70, 70, 160, 256, "relu"),         # 5 slices, 8 x 32 px x 128 ch tiles (>= 256 workgroups)
+    (1, 31, 31, 288, 192, "linear"),       # 9 slices, signed outputs
 ]
 
 
