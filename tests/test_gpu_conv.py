@@ -319,3 +319,32 @@ def test_split_conv_dynamic_tile_schedule_subprocess():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "dynamic schedule ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_persistent_conv_repeats_bit_identically():
+    """Race screen of the LDS-DMA pipeline (scripts/race_screen.py is the long version): a DMA that lands after its
+    reader shows up as a rarely different tile, so the same launch repeated -- beside a second stream that perturbs the
+    timing -- must give bit-identical outputs."""
+    side = torch.cuda.Stream()
+    junk = torch.rand((16, 1024, 1024), device="cuda")
+    for (B, H, Cin, Cout, prec) in [(8, 125, 128, 128, "f16x3"), (2, 31, 512, 512, "bf16x3")]:
+        torch.manual_seed(H)
+        x = (torch.rand((B, H, H, Cin), device="cuda") - 0.5).contiguous()
+        w = (torch.randn((3, 3, Cin, Cout), device="cuda") * (2.0 / (9 * Cin)) ** 0.5).contiguous()
+        b = torch.rand((Cout,), device="cuda") - 0.5
+        out = torch.empty((B, H, H, Cout), device="cuda")
+        ref = None
+        for i in range(60):
+            if i % 3 == 1:
+                with torch.cuda.stream(side):
+                    junk.mul_(1.0001)
+            out.fill_(float("nan"))
+            L.check(L.lib().rpn_conv2d(L.ptr(x), B, H, H, Cin, L.ptr(w), L.ptr(b), 3, 3, Cout, 1, 1, 1, H, H, L.ACTS["relu"],
+                                       L.PRECISIONS[prec], L.ptr(out), L.stream_ptr()), "rpn_conv2d")
+            if ref is None:
+                ref = out.clone()
+                assert not torch.isnan(ref).any()
+            else:
+                assert torch.equal(out, ref), "run %d differs from run 0" % i
+    torch.cuda.synchronize()
