@@ -348,3 +348,42 @@ def test_persistent_conv_repeats_bit_identically():
             else:
                 assert torch.equal(out, ref), "run %d differs from run 0" % i
     torch.cuda.synchronize()
+
+
+H5PY_PYTHON = "/opt/conda/bin/python3.9"          # the image's interpreter that has the real h5py
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backbone,strings", [("vgg16", "fixed"), ("mobilenet_v2", "vlen")])
+def test_load_weights_from_keras_h5(tmp_path, backbone, strings):
+    """The reference's ``rpn_model.load_weights(path, by_name=True)`` (predictor.py:43-44) on a Keras-layout .h5 file
+    written by the real h5py (full-size VGG16 / MobileNetV2 + RPN weight set, BatchNorm and depthwise layers included):
+    the model loaded from the file must produce bit-identical outputs to the model given the same arrays directly."""
+    import os, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        ok = subprocess.run([H5PY_PYTHON, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except OSError:
+        ok = False
+    if not ok:
+        pytest.skip("no interpreter with h5py on this machine to write the file")
+    hp, weights, model, imgs = _model_case(backbone, 64, 2)
+    npz, h5 = str(tmp_path / "w.npz"), str(tmp_path / "w.h5")
+    RPNModel.save_weights(weights, npz)
+    r = subprocess.run([H5PY_PYTHON, os.path.join(here, "golden", "npz_to_keras_h5.py"), npz, h5, strings],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref_reg, ref_cls = model.predict_on_batch(imgs)
+    loaded = RPNModel(backbone, hp, max_batch=2)
+    done = loaded.load_weights(h5, by_name=True)
+    assert sorted(done) == sorted(l["name"] for l in loaded.layers)
+    reg, cls = loaded.predict_on_batch(imgs)
+    np.testing.assert_array_equal(reg, ref_reg)
+    np.testing.assert_array_equal(cls, ref_cls)
+    # by_name: a file with only some of the layers sets just those
+    part = {k: v for k, v in weights.items() if k.startswith("rpn_")}
+    RPNModel.save_weights(part, npz)
+    assert subprocess.run([H5PY_PYTHON, os.path.join(here, "golden", "npz_to_keras_h5.py"), npz, h5, strings],
+                          capture_output=True, timeout=600).returncode == 0
+    fresh = RPNModel(backbone, hp, max_batch=2)
+    assert sorted(fresh.load_weights(h5)) == ["rpn_cls", "rpn_conv", "rpn_reg"]

@@ -72,14 +72,19 @@ class RPNModel(object):
         return int(w.value), int(a.value)
 
     # ---- weights ------------------------------------------------------------------------
-    def set_weights(self, weights):
+    def set_weights(self, weights, partial=False):
         """weights: {layer_name: {"kernel": HWIO, "bias": (Cout,)}} and, for layers followed by
-        BatchNorm, {bn_name: {"gamma", "beta", "mean", "var"}} -- Keras layer names."""
+        BatchNorm, {bn_name: {"gamma", "beta", "mean", "var"}} -- Keras layer names.  ``partial``: layers absent
+        from ``weights`` are left as they are (Keras ``by_name`` loading); forward still refuses to run until every
+        layer has been set once.  Returns the names of the layers set."""
         lib = L.lib()
         fp = lambda a: (np.ascontiguousarray(a, dtype=np.float32))
+        done = []
         for layer in self.layers:
             name, bn = layer["name"], layer["bn_name"]
             if name not in weights:
+                if partial:
+                    continue
                 raise KeyError("weights for layer %r are missing" % name)
             kernel = fp(weights[name]["kernel"])
             if tuple(kernel.shape) != layer["shape"]:
@@ -98,15 +103,29 @@ class RPNModel(object):
             else:
                 args += [None, None, None, None]
             L.check(lib.rpn_model_set_layer(self._h, name.encode(), *args), "rpn_model_set_layer(%s)" % name)
+            done.append(name)
+        return done
 
     def load_weights(self, path, by_name=True):
-        """Load a flat ``.npz`` written by ``save_weights`` (keys ``<layer>/<param>``)."""
-        data = np.load(path)
-        weights = {}
-        for key in data.files:
-            layer, param = key.rsplit("/", 1)
-            weights.setdefault(layer, {})[param] = data[key]
-        self.set_weights(weights)
+        """``model.load_weights(path, by_name=True)`` of the reference (predictor.py:43-44).
+
+        ``path``: a Keras ``.h5`` / ``.hdf5`` weights file (what the reference's trainer checkpoints, or the
+        ``model_weights`` of a full-model file; read by ``utils/h5_weights.py``, no h5py needed), or a flat ``.npz``
+        written by ``save_weights`` (keys ``<layer>/<param>``).  Layers are matched by their Keras names; BatchNorm is
+        folded into the preceding conv at load time.  ``by_name=True``: layers of this model that the file does not
+        contain are left untouched, layers of the file that this model lacks are ignored.  Returns the layers set."""
+        with open(path, "rb") as f:
+            is_h5 = f.read(8) == b"\x89HDF\r\n\x1a\n"
+        if is_h5:
+            from ..utils import h5_weights
+            weights = h5_weights.to_layer_arrays(h5_weights.read_keras_weights(path)[0])
+        else:
+            data = np.load(path)
+            weights = {}
+            for key in data.files:
+                layer, param = key.rsplit("/", 1)
+                weights.setdefault(layer, {})[param] = data[key]
+        return self.set_weights(weights, partial=bool(by_name))
 
     @staticmethod
     def save_weights(weights, path):

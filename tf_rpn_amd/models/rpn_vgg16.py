@@ -14,7 +14,8 @@ BACKBONE = "vgg16"
 def get_model(hyper_params, weights="synthetic", precision="f32", max_batch=8, keep_activations=False, seed=1):
     """weights: "synthetic" (seeded He-normal; the reference would download ImageNet weights,
     which needs network access), None (set them later with ``set_weights`` / ``load_weights``),
-    a ``{layer: {...}}`` dict, or a path to a ``.npz`` written by ``RPNModel.save_weights``."""
+    a ``{layer: {...}}`` dict, or a path: a Keras ``.h5`` weights file (the reference's checkpoint; loaded ``by_name``
+    like predictor.py:43-44) or a ``.npz`` written by ``RPNModel.save_weights``."""
     rpn_model = RPNModel(BACKBONE, hyper_params, precision=precision, max_batch=max_batch,
                          keep_activations=keep_activations)
     if isinstance(weights, str) and weights == "synthetic":
