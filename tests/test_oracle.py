@@ -244,3 +244,15 @@ def test_randomly_select_ties_and_short_masks():
     assert got.tolist() == [[True, False, True, True, False, False, False]]      # 7, then the two lowest-index 5s
     assert np.array_equal(bo.randomly_select_xyz_mask(mask, np.array([10]), rnd), mask)          # fewer than asked
     assert not bo.randomly_select_xyz_mask(mask, np.array([0]), rnd).any()
+
+
+def test_resize_restatement_matches_scikit_image():
+    """Independent pin of the bilinear-resize restatement (data_utils.py:26): scikit-image's order-1 resize without
+    anti-aliasing samples the same half-pixel-centre grid as TF 2.x (tests/golden/make_resize_golden.py, generated with
+    the image's scikit-image 0.18.3; up- and down-scaling, identity, non-square)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize_skimage.npz"))
+    for i in range(5):
+        src, ref = d["in%d" % i], d["out%d" % i]
+        got = bo.preprocess_image(src, ref.shape[0], ref.shape[1])
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-5          # float32 rounding of a [0,1] image (observed 7e-6)
