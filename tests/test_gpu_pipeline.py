@@ -167,3 +167,39 @@ def test_pipelined_distributed_path_world1():
         assert torch.equal(rec, want[0])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_predictor_cli_on_a_folder_of_images(tmp_path):
+    """``python -m tf_rpn_amd.predictor`` = the reference script's custom-image branch (predictor.py:8-60) minus the
+    drawing: folder -> PIL/Lanczos -> model -> decode -> top-k (or NMS) -> pixel boxes, ragged last batch included."""
+    import json
+    from PIL import Image
+    from tf_rpn_amd import predictor
+    rng = np.random.RandomState(1)
+    for i, (h, w) in enumerate(((60, 80), (90, 70), (50, 50))):
+        Image.fromarray(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(tmp_path / ("img%d.png" % i))
+    imgdir = tmp_path
+    outdir = tmp_path.parent / (tmp_path.name + "_out")
+    outdir.mkdir()
+    out = outdir / "p.json"                       # (like the reference, every file of the folder is opened as an image)
+    res = predictor.main(["--backbone", "mobilenet_v2", "--images", str(imgdir), "--synthetic-weights", "--batch-size", "2",
+                          "--top-k", "7", "--out", str(out)])
+    assert len(res) == 3 and json.load(open(out)) == res
+    for r in res:
+        assert len(r["boxes_y1x1y2x2"]) == 7 and len(r["scores"]) == 7 and r["img_size"] == 500
+        assert all(r["scores"][i] >= r["scores"][i + 1] for i in range(6))          # top_k: descending
+    nms = predictor.main(["--backbone", "mobilenet_v2", "--images", str(tmp_path), "--synthetic-weights", "--nms",
+                          "--out", str(out)])
+    assert len(nms) == 3 and all(0 < len(r["boxes_y1x1y2x2"]) <= 300 for r in nms)
+    # same images through the library calls the script is made of
+    from tf_rpn_amd.utils import data_utils, train_utils
+    hp = train_utils.get_hyper_params("mobilenet_v2")
+    paths = sorted(data_utils.get_custom_imgs(str(tmp_path)))
+    paths = [p for p in paths if p.endswith(".png")]
+    imgs = np.stack([im for im, _, _ in data_utils.custom_data_generator(paths, 500, 500)])
+    prop = predictor.Proposer("mobilenet_v2", hyper_params=hp, precision="f16x3", max_batch=3)
+    boxes, _idx, scores = prop.top_k(torch.from_numpy(imgs).cuda(), 7, return_scores=True)
+    for i, r in enumerate(res):
+        np.testing.assert_allclose(r["scores"], scores[i].cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(np.array(r["boxes_y1x1y2x2"]), np.round(boxes[i].cpu().numpy() * np.float32(500)).astype(int))

@@ -146,3 +146,40 @@ def test_record_pack_unpack_round_trip():
     assert rec.shape == (B, M * 5 + 1)
     b2, s2, v2 = Proposer.unpack_records(rec, M)
     assert torch.equal(b2, boxes) and torch.equal(s2, scores) and torch.equal(v2, valid)
+
+
+def test_io_utils_mirror(tmp_path, monkeypatch):
+    """io_utils.py:17-50 of the reference: model path (creates ./trained), the two CLI flags, backbone check."""
+    from tf_rpn_amd.utils import io_utils
+    monkeypatch.chdir(tmp_path)
+    assert io_utils.get_model_path("rpn", "vgg16") == os.path.join("trained", "rpn_vgg16_model_weights.h5")
+    assert os.path.isdir(tmp_path / "trained")
+    assert io_utils.get_model_path("faster_rcnn", "mobilenet_v2").endswith("faster_rcnn_mobilenet_v2_model_weights.h5")
+    a = io_utils.handle_args([])
+    assert a.backbone == "mobilenet_v2" and a.handle_gpu is False
+    a = io_utils.handle_args(["-handle-gpu", "--backbone", "vgg16"])
+    assert a.backbone == "vgg16" and a.handle_gpu is True
+    io_utils.is_valid_backbone("vgg16")
+    with pytest.raises(AssertionError):
+        io_utils.is_valid_backbone("resnet50")
+    assert io_utils.handle_gpu_compatibility() is None
+
+
+def test_custom_image_generator(tmp_path):
+    """data_utils.py:106-136: files of the folder (not recursive), PIL Lanczos resize, float32 [0,1], empty gt."""
+    from PIL import Image
+    from tf_rpn_amd.utils import data_utils
+    rng = np.random.RandomState(0)
+    (tmp_path / "sub").mkdir()
+    for name, (h, w) in (("a.png", (30, 50)), ("b.png", (64, 40))):
+        Image.fromarray(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(tmp_path / name)
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(tmp_path / "sub" / "nested.png")
+    paths = sorted(data_utils.get_custom_imgs(str(tmp_path)))
+    assert [os.path.basename(p) for p in paths] == ["a.png", "b.png"]
+    out = list(data_utils.custom_data_generator(paths, 20, 24))
+    assert len(out) == 2
+    for (img, boxes, labels), path in zip(out, paths):
+        assert img.shape == (20, 24, 3) and img.dtype == np.float32 and 0.0 <= img.min() and img.max() <= 1.0
+        ref = np.asarray(Image.open(path).resize((24, 20), Image.LANCZOS), dtype=np.uint8)
+        np.testing.assert_array_equal(img, ref.astype(np.float32) * np.float32(1.0 / 255.0))
+        assert boxes.shape == (1, 0) and boxes.dtype == np.float32 and labels.shape == (0,) and labels.dtype == np.int32

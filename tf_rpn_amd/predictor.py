@@ -134,13 +134,15 @@ class Proposer(object):
             return_indices=True)
         return nb, ns, nv, ni
 
-    def top_k(self, imgs, k=10):
-        """The reference's own selector: tf.nn.top_k + gather (predictor.py:58-60)."""
+    def top_k(self, imgs, k=10, return_scores=False):
+        """The reference's own selector: tf.nn.top_k + gather (predictor.py:58-60) -> (boxes (B,k,4), indices (B,k))
+        [+ scores (B,k)]."""
         B = int(imgs.shape[0])
         deltas, scores = self.forward(imgs)
         boxes = bbox_utils.get_bboxes_from_deltas(self.anchors, deltas, variances=self.variances)
         order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]    # ties -> lower index
-        return torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, k, 4)), order
+        top = torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, k, 4))
+        return (top, order, torch.gather(scores, 1, order)) if return_scores else (top, order)
 
     # -- multi-GPU collection ---------------------------------------------------------------
     def pack_records(self, boxes, scores, valid):
@@ -215,3 +217,85 @@ def shard_bounds(total, world, rank):
     base, rem = divmod(int(total), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def main(argv=None):
+    """The reference's ``predictor.py`` script for its custom-image branch (predictor.py:8-9, 32-36, 41-60), without
+    the drawing: ``python -m tf_rpn_amd.predictor --backbone vgg16 --images data/images/`` loads
+    ``trained/rpn_<backbone>_model_weights.h5`` (Keras checkpoint, ``by_name``), batches the images of the folder
+    (PIL, Lanczos resize to img_size), and prints / writes the top-k proposals per image in pixels of the resized image
+    (``denormalize_bboxes``).  ``--nms`` returns the NMS(300) proposals instead of the reference's plain top-k."""
+    import argparse
+    import json
+    import os
+
+    import numpy as np
+
+    from .utils import data_utils, io_utils
+    ap = argparse.ArgumentParser(description="RPN proposals on MI355X")
+    ap.add_argument("-handle-gpu", action="store_true", help="accepted for compatibility; no effect")
+    ap.add_argument("--backbone", default="mobilenet_v2", metavar=str(list(io_utils.BACKBONES)))
+    ap.add_argument("--images", default="data/images/", help="folder of images (the reference's custom_image_path)")
+    ap.add_argument("--weights", default=None, help="Keras .h5 / .npz weights (default: trained/rpn_<backbone>_model_weights.h5)")
+    ap.add_argument("--synthetic-weights", action="store_true", help="seeded random weights instead of a checkpoint")
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--nms", action="store_true", help="NMS(test_nms_topn) proposals instead of the plain top-k")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
+    ap.add_argument("--out", default=None, help="write the proposals as JSON here (default: stdout)")
+    args = ap.parse_args(argv)
+    io_utils.is_valid_backbone(args.backbone)
+    hyper_params = train_utils.get_hyper_params(args.backbone)
+    img_size = int(hyper_params["img_size"])
+    img_paths = sorted(data_utils.get_custom_imgs(args.images))
+    if not img_paths:
+        raise SystemExit("no images in %r" % args.images)
+    if args.synthetic_weights:
+        weights = "synthetic"
+    else:
+        weights = args.weights or io_utils.get_model_path("rpn", args.backbone)
+        if not os.path.exists(weights):
+            raise SystemExit("weights file %r not found (train the reference, or pass --weights / --synthetic-weights)" % weights)
+    B = max(1, int(args.batch_size))
+    prop = Proposer(args.backbone, hyper_params=hyper_params, weights=weights, precision=args.precision, max_batch=B)
+    results = []
+    gen = data_utils.custom_data_generator(img_paths, img_size, img_size)
+    batch, names = [], []
+
+    def flush():
+        if not batch:
+            return
+        imgs = torch.from_numpy(np.stack(batch)).cuda()
+        n = len(batch)
+        if args.nms:
+            boxes, scores, valid, _ = prop.propose(imgs)
+            boxes, scores, valid = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy(), valid[:n].cpu().numpy()
+        else:
+            boxes, _order, scores = prop.top_k(imgs, args.top_k, return_scores=True)
+            boxes, scores = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy()
+            valid = np.full((n,), boxes.shape[1])
+        for i in range(n):
+            k = int(valid[i])
+            px = np.round(boxes[i, :k] * np.float32(img_size)).astype(int)          # denormalize_bboxes (bbox_utils.py:152-166)
+            results.append({"image": names[i], "img_size": img_size, "boxes_y1x1y2x2": px.tolist(),
+                            "scores": [float(v) for v in scores[i, :k]]})
+        batch.clear()
+        names.clear()
+
+    for path, (img, _gt_boxes, _gt_labels) in zip(img_paths, gen):
+        batch.append(img)
+        names.append(path)
+        if len(batch) == B:
+            flush()
+    flush()
+    text = json.dumps(results, indent=1)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(text)
+    else:
+        print(text)
+    return results
+
+
+if __name__ == "__main__":
+    main()

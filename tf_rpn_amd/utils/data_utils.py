@@ -1,7 +1,11 @@
 """Input preprocessing of the RPN path on MI355X -- counterpart of the part of the reference's
 ``utils/data_utils.py`` that sits immediately in front of the model (``preprocessing``, :7-29, and
-``flip_horizontally``, :54-68).  Dataset loading (tensorflow_datasets, PIL) is out of scope.
+``flip_horizontally``, :54-68) and of its custom-image branch (``get_custom_imgs`` :106-118,
+``custom_data_generator`` :120-136).  Dataset loading through tensorflow_datasets is out of scope.
 """
+import os
+
+import numpy as np
 import torch
 
 from .. import _lib as L
@@ -39,3 +43,24 @@ def flip_boxes_horizontally(gt_boxes):
     """(…, [y1, x1, y2, x2]) -> [y1, 1 - x2, y2, 1 - x1] (data_utils.py:64-67); plain tensor arithmetic."""
     g = gt_boxes if isinstance(gt_boxes, torch.Tensor) else torch.as_tensor(gt_boxes, dtype=torch.float32)
     return torch.stack([g[..., 0], 1.0 - g[..., 3], g[..., 2], 1.0 - g[..., 1]], dim=-1)
+
+
+def get_custom_imgs(custom_image_path):
+    """Paths of the files directly inside ``custom_image_path`` (not recursive; data_utils.py:113-118)."""
+    for path, _dirs, filenames in os.walk(custom_image_path):
+        return [os.path.join(path, name) for name in filenames]
+    return []
+
+
+def custom_data_generator(img_paths, final_height, final_width):
+    """Yield ``(img, gt_boxes, gt_labels)`` per file like the reference's generator for its own images
+    (data_utils.py:131-136): the image is opened with PIL, resized to (final_width, final_height) with **Lanczos**
+    (not the bilinear resize of the dataset branch), converted to float32 in [0,1] (non-RGB files are converted to RGB
+    first; the reference assumes RGB); boxes / labels are empty
+    placeholders of shapes (1,0) float32 and (0,) int32.  Host arrays: batching moves them to the device."""
+    from PIL import Image
+    for img_path in img_paths:
+        image = Image.open(img_path).convert("RGB")
+        resized = image.resize((int(final_width), int(final_height)), Image.LANCZOS)
+        img = np.asarray(resized, dtype=np.uint8).astype(np.float32) * np.float32(1.0 / 255.0)   # convert_image_dtype
+        yield img, np.zeros((1, 0), np.float32), np.zeros((0,), np.int32)
