@@ -173,8 +173,24 @@ def main():
         torch.cuda.synchronize()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        # RCCL prints a version banner through C stdio when the communicator is created (flushed at exit when stdout
+        # is a pipe, i.e. AFTER the JSON line): send it to stderr so that stdout carries the one JSON line only.
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     M = prop.topn
     gathered = torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") if world > 1 else None
     gather_bufs = [torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") for _ in range(2)]
