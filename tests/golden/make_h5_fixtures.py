@@ -84,6 +84,20 @@ if __name__ == "__main__":
     write(os.path.join(HERE, "keras_weights_many_layers.h5"), mnv2_like(), strings="fixed")
     write(os.path.join(HERE, "keras_weights_latest_libver.h5"), VGG_TINY, strings="vlen", libver="latest")
     write(os.path.join(HERE, "keras_weights_chunked_gzip.h5"), VGG_TINY[:2], strings="fixed", chunked=True)
+    # Keras splits attributes above 64512 bytes into <name>0, <name>1, ... (save_attributes_to_hdf5_group): same naming,
+    # small contents
+    path = os.path.join(HERE, "keras_weights_chunked_attrs.h5")
+    write(path, VGG_TINY, strings="fixed")
+    with h5py.File(path, "r+") as f:
+        names = f.attrs["layer_names"]
+        del f.attrs["layer_names"]
+        f.attrs["layer_names0"] = names[:4]
+        f.attrs["layer_names1"] = names[4:]
+        g = f["rpn_reg"]
+        wn = g.attrs["weight_names"]
+        del g.attrs["weight_names"]
+        g.attrs["weight_names0"] = wn[:1]
+        g.attrs["weight_names1"] = wn[1:]
     for n in sorted(os.listdir(HERE)):
         if n.endswith(".h5"):
             print(n, os.path.getsize(os.path.join(HERE, n)))

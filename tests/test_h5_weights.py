@@ -22,7 +22,8 @@ VGG_TINY_SHAPES = {"block1_conv1": {"kernel": (3, 3, 3, 4), "bias": (4,)}, "rpn_
 
 
 @pytest.mark.parametrize("name,full", [("keras_weights_fixed_strings", False), ("keras_weights_vlen_strings", False),
-                                       ("keras_full_model", True), ("keras_weights_latest_libver", False)])
+                                       ("keras_full_model", True), ("keras_weights_latest_libver", False),
+                                       ("keras_weights_chunked_attrs", False)])
 def test_reads_keras_layout_written_by_h5py(name, full):
     w, info = hw.read_keras_weights(os.path.join(GOLD, name + ".h5"))
     assert info["layer_names"] == ["input_1", "block1_conv1", "block1_pool", "rpn_conv", "rpn_cls", "rpn_reg"]
