@@ -186,6 +186,9 @@ double rpn_model_flops_per_image(const rpn_model *m);
 int rpn_model_set_profiling(rpn_model *m, int n_forwards);
 /* time only the ops with mask[i] != 0 (n = rpn_model_num_ops; NULL: every op); untimed ops read back as 0 ms */
 int rpn_model_set_profiling_mask(rpn_model *m, const unsigned char *mask, int n);
+/* with a mask: time ONE marked op per forward, round robin (2 events per forward); rpn_model_get_profile then averages
+   each op over the forwards in which it was the one timed */
+int rpn_model_set_profiling_rotate(rpn_model *m, int on);
 int rpn_model_num_ops(const rpn_model *m);
 int rpn_model_op_info(const rpn_model *m, int i, char *name, int name_len, char *kernel, int kernel_len,
                       double *flops_per_image, double *bytes_per_image);

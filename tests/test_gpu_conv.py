@@ -387,3 +387,35 @@ def test_load_weights_from_keras_h5(tmp_path, backbone, strings):
                           capture_output=True, timeout=600).returncode == 0
     fresh = RPNModel(backbone, hp, max_batch=2)
     assert sorted(fresh.load_weights(h5)) == ["rpn_cls", "rpn_conv", "rpn_reg"]
+
+
+@pytest.mark.gpu
+def test_profiling_mask_and_rotation():
+    """Per-op HIP-event timing: a mask restricts it to some ops; with rotation each forward times one marked op (round
+    robin) and every marked op still gets a duration close to the one measured with all of them timed."""
+    hp, weights, model, imgs = _model_case("vgg16", 160, 2)
+    x = torch.from_numpy(imgs).cuda()
+    ops = model.ops()
+    marked = [i for i, op in enumerate(ops) if "conv3x3" in op["kernel"]][:4]
+    mask = [i in marked for i in range(len(ops))]
+    model.set_profiling_mask(mask)
+    model.set_profiling(12)
+    for _ in range(12):
+        model.predict_on_batch(x)
+    full, kept = model.profile_ms()
+    assert kept == 12
+    assert all((full[i] > 0) == mask[i] for i in range(len(ops)))
+    model.set_profiling_rotate(True)
+    model.set_profiling(12)
+    for _ in range(12):
+        model.predict_on_batch(x)
+    rot, kept = model.profile_ms()
+    assert kept == 12
+    for i in range(len(ops)):
+        if mask[i]:
+            assert rot[i] > 0 and abs(rot[i] - full[i]) <= 0.5 * full[i] + 0.01, (ops[i]["name"], rot[i], full[i])
+        else:
+            assert rot[i] == 0
+    model.set_profiling_rotate(False)
+    model.set_profiling_mask(None)
+    model.set_profiling(0)

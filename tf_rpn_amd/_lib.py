@@ -60,6 +60,7 @@ _SIGNATURES = {
     "rpn_model_flops_per_image": (ctypes.c_double, [vp]),
     "rpn_model_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_model_set_profiling_mask": (ctypes.c_int, [vp, vp, ctypes.c_int]),
+    "rpn_model_set_profiling_rotate": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_model_num_ops": (ctypes.c_int, [vp]),
     "rpn_model_op_info": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),

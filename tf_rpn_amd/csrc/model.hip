@@ -81,6 +81,8 @@ struct rpn_model {
     int profiling = 0;                 // number of forwards whose events are kept (ring)
     std::vector<hipEvent_t> events;    // profiling x (ops + 1)
     std::vector<unsigned char> prof_mask;   // empty: time every op; else only the ops marked non-zero
+    int prof_rotate = 0;                    // with a mask: each forward times ONE of the marked ops, round robin
+    std::vector<int> prof_timed;            // per kept forward: the op timed in it (-1: every marked op)
     long long profiled_forwards = 0;
 };
 
@@ -577,6 +579,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     hipStream_t s = as_stream(stream);
     m->last_input = d_imgs;
     hipEvent_t *evs = nullptr;
+    int sel_op = -1;
     if (m->profiling > 0) {
         const size_t per = m->ops.size() + 1;
         if (m->events.size() != per * (size_t)m->profiling) {
@@ -585,15 +588,27 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             for (auto &ev : m->events) RPN_HIP_CHECK(hipEventCreate(&ev));
             m->profiled_forwards = 0;
         }
-        evs = m->events.data() + per * (size_t)(m->profiled_forwards % m->profiling);
-        if (m->prof_mask.empty() || m->prof_mask[0]) RPN_HIP_CHECK(hipEventRecord(evs[0], s));
+        const size_t slot = (size_t)(m->profiled_forwards % m->profiling);
+        evs = m->events.data() + per * slot;
+        m->prof_timed.resize((size_t)m->profiling, -1);
+        m->prof_timed[slot] = -1;
+        if (m->prof_rotate && !m->prof_mask.empty()) {
+            std::vector<int> marked;
+            for (size_t i = 0; i < m->ops.size(); ++i)
+                if (m->prof_mask[i]) marked.push_back((int)i);
+            if (!marked.empty()) m->prof_timed[slot] = marked[(size_t)(m->profiled_forwards % (long long)marked.size())];
+        }
+        sel_op = m->prof_timed[slot];
         ++m->profiled_forwards;
     }
     // event i+1 closes op i and opens op i+1: with a mask only the boundaries of marked ops are recorded
+    // (with rotation: of the one op selected for this forward)
     auto want_event = [&](size_t boundary) {
         if (m->prof_mask.empty()) return true;
-        return (boundary > 0 && m->prof_mask[boundary - 1]) || (boundary < m->ops.size() && m->prof_mask[boundary]);
+        auto marked = [&](size_t i) { return sel_op >= 0 ? (int)i == sel_op : m->prof_mask[i] != 0; };
+        return (boundary > 0 && marked(boundary - 1)) || (boundary < m->ops.size() && marked(boundary));
     };
+    if (evs && want_event(0)) RPN_HIP_CHECK(hipEventRecord(evs[0], s));
     int op_index = 0;
     bool skip_next = false;
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
@@ -678,6 +693,16 @@ extern "C" int rpn_model_set_profiling_mask(rpn_model *m, const unsigned char *m
     return RPN_OK;
 }
 
+// With a mask: time only ONE of the marked ops per forward, round robin over the forwards (2 events per forward
+// instead of 2 per marked launch; every marked op is still timed live, in every (number of marked ops)-th forward).
+extern "C" int rpn_model_set_profiling_rotate(rpn_model *m, int on)
+{
+    RPN_REQUIRE(m, "rpn_model_set_profiling_rotate: null model");
+    m->prof_rotate = on ? 1 : 0;
+    m->profiled_forwards = 0;
+    return RPN_OK;
+}
+
 extern "C" int rpn_model_num_ops(const rpn_model *m) { return m ? (int)m->ops.size() : 0; }
 
 // name, kernel family ("conv128x128", "conv128x64", "conv128x32", "conv_generic*", "dwconv", "maxpool") and
@@ -746,17 +771,22 @@ extern "C" int rpn_model_get_profile(rpn_model *m, float *ms, int n, int *n_forw
     RPN_REQUIRE(n >= (int)m->ops.size(), "rpn_model_get_profile: need room for %d ops", (int)m->ops.size());
     const size_t per = m->ops.size() + 1;
     const int kept = (int)(m->profiled_forwards < m->profiling ? m->profiled_forwards : m->profiling);
-    for (size_t i = 0; i < m->ops.size(); ++i) ms[i] = 0.0f;
+    std::vector<double> sum(m->ops.size(), 0.0);
+    std::vector<int> cnt(m->ops.size(), 0);
     for (int f = 0; f < kept; ++f) {
         hipEvent_t *evs = m->events.data() + per * (size_t)f;
+        const int sel = (size_t)f < m->prof_timed.size() ? m->prof_timed[(size_t)f] : -1;
         for (size_t i = 0; i < m->ops.size(); ++i) {
             if (!m->prof_mask.empty() && !m->prof_mask[i]) continue;          // not timed: stays 0
+            if (sel >= 0 && (int)i != sel) continue;                          // rotation: not the op timed in this forward
             RPN_HIP_CHECK(hipEventSynchronize(evs[i + 1]));
             float t = 0.0f;
             RPN_HIP_CHECK(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
-            ms[i] += t / (float)kept;
+            sum[i] += t;
+            ++cnt[i];
         }
     }
+    for (size_t i = 0; i < m->ops.size(); ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
     if (n_forwards) *n_forwards = kept;
     return RPN_OK;
 }

@@ -165,6 +165,10 @@ class RPNModel(object):
         buf = (ctypes.c_ubyte * len(mask))(*[1 if v else 0 for v in mask])
         L.check(L.lib().rpn_model_set_profiling_mask(self._h, buf, len(mask)), "rpn_model_set_profiling_mask")
 
+    def set_profiling_rotate(self, on=True):
+        """With a mask: time one marked op per forward, round robin (2 events per forward)."""
+        L.check(L.lib().rpn_model_set_profiling_rotate(self._h, 1 if on else 0), "rpn_model_set_profiling_rotate")
+
     def ops(self):
         """[{name, kernel, flops_per_image, bytes_per_image}] in launch order."""
         lib = L.lib()
