@@ -12,7 +12,8 @@ Images shard over ranks (weak scaling: the per-GPU batch is fixed), no other dat
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (f16x3 / bf16x3: the persistent LDS-DMA
 16x16x32-MFMA conv; f32: the 128x128 f32-MFMA implicit-GEMM conv), found by an untimed pre-pass and then timed
-live with HIP events recorded on the launch stream around each of its launches in the K timed steps;
+live with HIP events recorded on the launch stream around its launches in the K timed steps (one launch per step,
+round robin, when K samples every launch at least twice; else all of them);
 `cpu_baseline` is the CPU oracle (torch-CPU conv stack + plain-C decode/NMS restatement: a "port", the
 TF2 reference cannot run here) timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
