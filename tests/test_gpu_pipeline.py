@@ -203,3 +203,27 @@ def test_predictor_cli_on_a_folder_of_images(tmp_path):
     for i, r in enumerate(res):
         np.testing.assert_allclose(r["scores"], scores[i].cpu().numpy(), rtol=0, atol=1e-6)
         np.testing.assert_array_equal(np.array(r["boxes_y1x1y2x2"]), np.round(boxes[i].cpu().numpy() * np.float32(500)).astype(int))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--force-dist"], ["--serial-nms", "--steps", "4"]])
+def test_bench_prints_one_json_line(extra):
+    """The driver's contract: rank 0 prints ONE JSON line on stdout (RCCL's version banner must not land there), with the
+    roofline object; `--force-dist` runs the N > 1 code path on a world-size-1 RCCL group."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "16", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["value"] > 100
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "conv3x3_split16_dma" in rf["kernel"] and 0.2 < rf["frac"] < 1.0
+    if "--force-dist" in extra:
+        assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0
