@@ -365,3 +365,27 @@ def test_rpn_targets_many_positives_and_default_rng():
     d2, l2 = train_utils.calculate_rpn_actual_outputs(anchors, gt, labels, hp)          # torch RNG
     l2 = l2.reshape(2, -1)
     assert ((l2 == 1).sum(axis=1) == 128).all() and ((l2 == 0).sum(axis=1) == 128).all()
+
+
+@pytest.mark.gpu
+def test_rpn_generator_cycles_the_dataset():
+    """train_utils.py:67-82: endless (img, (deltas, labels)) stream; targets per batch as calculate_rpn_actual_outputs gives."""
+    hp = bo.get_hyper_params("vgg16")
+    anchors = bo.generate_anchors(hp)
+    rng = np.random.RandomState(5)
+    batches = []
+    for b in range(2):
+        gt = cases.gt_boxes(rng, 2, G=6, n_valid=4)
+        labels = np.full((2, 6), -1, np.int32)
+        labels[:, :4] = rng.randint(1, 21, size=(2, 4))
+        batches.append((np.full((2, 4, 4, 3), float(b), np.float32), gt, labels))
+    from tf_rpn_amd.utils import train_utils
+    gen = train_utils.rpn_generator(batches, anchors, hp)
+    out = [next(gen) for _ in range(5)]                      # 2.5 epochs
+    for i, (img, (deltas, lab)) in enumerate(out):
+        assert float(np.asarray(img).flat[0]) == float(i % 2)
+        assert np.asarray(deltas).shape == (2, len(anchors), 4)
+        assert np.asarray(lab).shape == (2, 31, 31, 9)
+        assert set(np.unique(np.asarray(lab))) <= {-1.0, 0.0, 1.0}
+        lab2 = np.asarray(lab).reshape(2, -1)               # per image: <= 128 positives, negatives fill up to 256
+        assert ((lab2 == 1).sum(axis=1) <= 128).all() and ((lab2 == 1).sum(axis=1) + (lab2 == 0).sum(axis=1) == 256).all()

@@ -183,3 +183,10 @@ def test_custom_image_generator(tmp_path):
         ref = np.asarray(Image.open(path).resize((24, 20), Image.LANCZOS), dtype=np.uint8)
         np.testing.assert_array_equal(img, ref.astype(np.float32) * np.float32(1.0 / 255.0))
         assert boxes.shape == (1, 0) and boxes.dtype == np.float32 and labels.shape == (0,) and labels.dtype == np.int32
+
+
+def test_get_step_size():
+    """train_utils.py:40-48: math.ceil(total_items / batch_size)."""
+    import math
+    for total, bs in ((4952, 4), (4952, 8), (1, 8), (16, 8), (17, 8), (5011, 3)):
+        assert train_utils.get_step_size(total, bs) == math.ceil(total / bs)

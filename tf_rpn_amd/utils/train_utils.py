@@ -37,6 +37,21 @@ def get_hyper_params(backbone, **kwargs):
     return params
 
 
+def get_step_size(total_items, batch_size):
+    """Batches per epoch: ceil(total_items / batch_size) (utils/train_utils.py:40-48)."""
+    return -(-int(total_items) // int(batch_size))
+
+
+def rpn_generator(dataset, anchors, hyper_params):
+    """Endless ``(img, (bbox_deltas, bbox_labels))`` stream over ``dataset`` -- any re-iterable of
+    ``(img, gt_boxes, gt_labels)`` batches -- with the targets computed on the device
+    (utils/train_utils.py:67-82, the consumer of ``calculate_rpn_actual_outputs``)."""
+    while True:
+        for img, gt_boxes, gt_labels in dataset:
+            bbox_deltas, bbox_labels = calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params)
+            yield img, (bbox_deltas, bbox_labels)
+
+
 def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, random_pos=None, random_neg=None):
     """Training targets for one batch on the device -- utils/train_utils.py:84-144 (with
     ``randomly_select_xyz_mask``, :50-65).
