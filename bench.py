@@ -16,10 +16,18 @@ live with HIP events recorded on the launch stream around its launches in the K 
 round robin, when K samples every launch at least twice; else all of them);
 `cpu_baseline` is the CPU oracle (torch-CPU conv stack + plain-C decode/NMS restatement: a "port", the
 TF2 reference cannot run here) timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
+The N = 1 line also carries `c3` (BASELINE.json configs[2]: batch 64, box path only -- decode / IoU-map GB/s and the
+metric's "NMS boxes/sec", every kernel timed with HIP events in this run) and `exact_f32` (the same workload on the
+parity-clean exact-float32 MFMA path with its own roofline fraction).
+
+`python bench.py --gpus N` with N > 1 and no launcher starts one child process per GPU itself (`spawn_ranks`) and
+forwards rank 0's JSON line; under `torch.distributed.run` (WORLD_SIZE set) it is a plain rank.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +36,70 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "f16x3": 2500.0 / 3.0}   # MI355X_MICROARCH.md: f32 MFMA; dense 16-bit MFMA / 3 products
+
+
+def spawn_ranks(n, cmd, env=None, timeout=None, poll=0.2):
+    """Run `cmd` n times as child processes, one per rank (RANK / LOCAL_RANK = 0..n-1, WORLD_SIZE = n, MASTER_ADDR =
+    127.0.0.1 and a free MASTER_PORT in their environment), the way `python -m torch.distributed.run --nproc-per-node n`
+    would.  The parent never touches a GPU (a process that has initialised HIP must not exec or fork workers on this
+    pool).  Rank 0's stdout is captured (through a temporary file, so a chatty child can never block on a full pipe)
+    and returned; the other ranks' stdout goes to stderr.  When a child fails or the timeout expires the others are
+    terminated by PID.  Returns (exit code, rank-0 stdout): 0 only if every rank exited 0; 124 on timeout."""
+    import tempfile
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as cap:
+        for r in range(n):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen(cmd, env=e, stdout=cap if r == 0 else sys.stderr))
+        deadline = None if timeout is None else time.time() + timeout
+        rc = 0
+        try:
+            while rc == 0:
+                codes = [p.poll() for p in procs]
+                failed = [c for c in codes if c not in (None, 0)]
+                if failed:
+                    rc = failed[0]
+                elif all(c == 0 for c in codes):
+                    break
+                elif deadline is not None and time.time() > deadline:
+                    rc = 124
+                else:
+                    time.sleep(poll)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        cap.seek(0)
+        return rc, cap.read()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start one process per GPU.  Nothing here initialises HIP:
+    torch.cuda.device_count() only counts devices."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but this machine exposes %d HIP device(s)\n" % (args.gpus, have))
+        return 2
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    rc, out = spawn_ranks(args.gpus, cmd, timeout=float(os.environ.get("BENCH_SPAWN_TIMEOUT", "1700")))
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with code %d\n" % rc)
+    return rc
 
 
 def parse_args():
@@ -51,6 +123,8 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise a world-size-1 RCCL group and run the N > 1 code path (record packing + all-gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the configs[2] box-path leg (`c3`) and the exact-float32 leg (`exact_f32`) of the N = 1 line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     return ap.parse_args()
@@ -115,21 +189,135 @@ def cpu_baseline(backbone, hyper_params, weights, iou_threshold, target_seconds)
 def measured_traffic(kernel, precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_traffic.json, written by scripts/make_traffic.py under the same kernel names as this file's
-    per-op table: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command);
-    null when no profile matches the kernel and precision being run."""
+    per-op table: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command) -- PMC
+    counters cannot be collected from inside an un-profiled run, so the figure is read back from the newest committed
+    profile and labelled with its file name (`traffic_source`).  (None, None) when no profile matches."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % precision)))
-    if not paths:
-        return None
-    try:
-        with open(paths[-1]) as f:
-            return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=5, warmup=2):
+    """The parity-clean arithmetic beside the headline (report both): the same workload with every conv
+    on the exact float32 MFMA (v_mfma_f32_32x32x2_f32, bit-for-bit an ordered fmaf chain), timed over `steps` steps in
+    this same run, with the dominant kernel's fraction of the 157.3 TFLOP/s f32-MFMA peak from a per-op event pass."""
+    import torch
+
+    from tf_rpn_amd.predictor import Proposer
+    prop = Proposer(backbone, hyper_params=hp, weights=weights, precision="f32", max_batch=B,
+                    iou_threshold=iou_threshold, overlap_nms=True)
+    for _ in range(warmup):
+        prop.propose_async(imgs)
+    prop.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prop.propose_async(imgs)
+    prop.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model = prop.rpn_model
+    ops = model.ops()
+    model.set_profiling(3)
+    for _ in range(3):
+        prop.propose_async(imgs)
+    prop.wait()
+    torch.cuda.synchronize()
+    ms, _ = model.profile_ms()
+    model.set_profiling(0)
+    tot = {}
+    for op, t in zip(ops, ms):
+        d = tot.setdefault(op["kernel"], [0.0, 0.0, 0])
+        d[0] += t
+        d[1] += op["flops_per_image"] * B
+        d[2] += 1
+    dom = max(tot, key=lambda k: tot[k][0])
+    achieved = tot[dom][1] / (tot[dom][0] * 1e-3) / 1e12
+    del prop
+    torch.cuda.empty_cache()
+    return {"value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4),
+            "steps": steps, "dtype": "f32",
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS["f32"],
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["f32"], 4),
+                         "launches_per_step": tot[dom][2], "avg_launch_ms": round(tot[dom][0] / tot[dom][2], 4)}}
+
+
+def c3_leg(hp, n=30):
+    """BASELINE.json configs[2]: batch 64, box path only (no backbone) -- the metric's "NMS boxes/sec".  Inputs as
+    SURVEY.md 8(d): deltas ~ N(0,1) (x variances inside the kernel), scores = a seeded permutation of (i + 0.5) / A per
+    image (tie-free), gt = 42 rows per image of which the first 10 are boxes and the rest zero padding.  Every kernel
+    is timed with HIP events on the launch stream (torch's current stream) over `n` back-to-back launches; bandwidths
+    are ALGORITHMIC bytes / time against the 8 TB/s HBM peak."""
+    import numpy as np
+    import torch
+
+    from tf_rpn_amd import _lib as L
+    from tf_rpn_amd.utils import bbox_utils
+    B, G = 64, 42
+    anchors = bbox_utils.generate_anchors(hp)
+    A = int(anchors.shape[0])
+    deltas = torch.from_numpy(np.random.RandomState(2).standard_normal((B, A, 4)).astype(np.float32)).cuda()
+    rng = np.random.RandomState(3)
+    base = ((np.arange(A) + 0.5) / A).astype(np.float32)
+    scores = torch.from_numpy(np.stack([base[rng.permutation(A)] for _ in range(B)])).cuda()
+    rng = np.random.RandomState(4)
+    gt_np = np.zeros((B, G, 4), np.float32)
+    y1, x1 = rng.uniform(0, 0.7, size=(2, B, 10))
+    h, w = rng.uniform(0.05, 0.3, size=(2, B, 10))
+    gt_np[:, :10] = np.stack([y1, x1, y1 + h, x1 + w], axis=-1)
+    gt = torch.from_numpy(gt_np).cuda()
+    boxes = torch.empty((B, A, 4), device="cuda")
+    iou = torch.empty((B, A, G), device="cuda")
+    ob, osc = torch.zeros((B, 300, 4), device="cuda"), torch.zeros((B, 300), device="cuda")
+    oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda")
+    ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    _keep, vptr = L.host_floats(hp["variances"])
+    lib = L.lib()
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {"workload": "configs[2]: batch=64, %d anchors per image, G=42 gt rows, no backbone" % A, "B": B, "A": A, "G": G,
+           "hbm_peak_GBps": 8000.0}
+    t = timed(lambda: L.check(lib.rpn_decode(L.ptr(anchors), 0, L.ptr(deltas), vptr, B, A, L.ptr(boxes), L.stream_ptr()),
+                              "rpn_decode"), n)
+    by = 32.0 * B * A + 16.0 * A
+    out["decode"] = {"us": round(t * 1e6, 2), "GBps": round(by / t / 1e9, 1), "frac": round(by / t / 8e12, 4), "bytes": by}
+    t = timed(lambda: L.check(lib.rpn_iou_map(L.ptr(anchors), 0, A, L.ptr(gt), B, G, L.ptr(iou), L.stream_ptr()),
+                              "rpn_iou_map"), n)
+    by = 4.0 * B * A * G + 16.0 * (A + B * G)
+    out["iou_map"] = {"us": round(t * 1e6, 2), "GBps": round(by / t / 1e9, 1), "frac": round(by / t / 8e12, 4), "bytes": by}
+    for thr in (0.5, 0.7):
+        t = timed(lambda: L.check(lib.rpn_decode_nms(L.ptr(anchors), L.ptr(deltas), vptr, L.ptr(scores), B, A, 300, thr,
+                                                     float("-inf"), 1, L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0),
+                                                     0, L.stream_ptr()), "rpn_decode_nms"), max(5, n // 2))
+        by = B * (20.0 * A + 7204.0)
+        out["decode_nms_iou%.1f" % thr] = {"us": round(t * 1e6, 2), "boxes_per_sec": round(B * A / t, 1),
+                                           "GBps": round(by / t / 1e9, 2), "bytes": by,
+                                           "mean_valid": round(float(ov.float().mean().item()), 1)}
+    return out
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher (one child per GPU) BEFORE anything initialises HIP in this process
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -142,9 +330,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -170,7 +355,6 @@ def main():
         # device_id), RCCL's internal streams take the hardware queues and the NMS side stream ends up sharing a
         # queue with the conv stream -- measured: the NMS/conv overlap disappears (3.25 vs 3.05 ms/step).
         prop.propose(imgs)
-        prop.wait()
         torch.cuda.synchronize()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -200,6 +384,8 @@ def main():
     def step():
         if overlap and use_dist:
             return prop.propose_distributed_pipelined(imgs, gather_bufs)
+        if overlap:
+            return prop.propose_async(imgs)
         return prop.propose_distributed(imgs, gather_out=gathered)
 
     def fence():
@@ -246,7 +432,7 @@ def main():
             prop.propose_distributed_pipelined(imgs, gather_bufs)
             continue
         if overlap:
-            prop.propose(imgs)                    # convs on this stream, decode+NMS on the side stream
+            prop.propose_async(imgs)              # convs on this stream, decode+NMS on the side stream
             continue
         deltas, scores = prop.forward(imgs)
         nms_ev[k][0].record()                     # same stream as the launches (torch's current stream)
@@ -258,7 +444,7 @@ def main():
         _lib.check(st, "rpn_decode_nms")
         nms_ev[k][1].record()
         if world > 1:
-            rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3])
+            rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3], out=prop._record_buffer(2, B))
             dist.all_gather_into_tensor(gathered, rec)
     if overlap and use_dist:
         prop.flush_distributed(gather_bufs)       # the last step's NMS + all-gather finish inside the timed region
@@ -328,9 +514,9 @@ def main():
         d = by_kernel[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        traffic = measured_traffic(dom, args.precision)
+        traffic, traffic_source = measured_traffic(dom, args.precision)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flops_per_launch": d["flops"] / d["launches"],
                     "timing": ("HIP events on the launch stream around this kernel's launches in the K timed steps"
@@ -356,10 +542,20 @@ def main():
                        "nms_overlap": ("decode+NMS of step k on a second HIP stream, overlapping the convs of step k+1"
                                        + ("; all-gather of step k-1 issued behind the convs of step k" if use_dist else ""))
                                       if overlap else "serial on the conv stream"},
-            "nms_boxes_per_sec": round(B * prop.total_anchors / (nms_ms * 1e-3), 1),
             "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "roofline": roofline,
         }
+        if world == 1 and not args.no_extra_legs:
+            # the metric's second half ("NMS boxes/sec") is quoted on configs[2] (B = 64, box path only)
+            out["c3"] = c3_leg(hp)
+            out["nms_boxes_per_sec"] = out["c3"]["decode_nms_iou0.7"]["boxes_per_sec"]
+            out["nms_boxes_per_sec_note"] = "configs[2] (B=64), fused decode+NMS(300), iou 0.7; `c3` has iou 0.5 and the GB/s"
+            if args.precision != "f32":
+                out["exact_f32"] = exact_f32_leg(args.backbone, hp, weights, B, args.iou_threshold, imgs)
+        else:
+            out["nms_boxes_per_sec"] = round(B * prop.total_anchors / (nms_ms * 1e-3), 1)
+            out["nms_boxes_per_sec_note"] = "this run's own decode+NMS at its per-GPU batch (%d images)" % B
         if args.layers:
             for op, ms in zip(ops, last_ms):
                 tf = op["flops_per_image"] * B / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

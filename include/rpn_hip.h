@@ -174,6 +174,13 @@ int rpn_model_set_layer(rpn_model *m, const char *name, const float *kernel, con
  * d_reg (B,F,F,4K), d_cls (B,F,F,K) -- the reference's output order is [reg, cls]
  * (models/rpn_vgg16.py:21). */
 int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float *d_reg, float *d_cls, void *stream);
+/* Sticky status flags of the forwards run so far (no reference counterpart: TF computes in float32 throughout).
+ * RPN_STATUS_F16_RANGE: under RPN_PRECISION_F16X3 some activation did not fit float16 (|x| > 65504 or non-finite) when
+ * it was written in split form -- outputs of that forward are invalid (use BF16X3 or F32 for such weights).  The flag
+ * is raised on the device by the kernel that hits it; a forward never reads it back (no host synchronisation on the
+ * hot path).  This call copies the word to the host (synchronising on `stream`) and clears it when `reset` != 0. */
+#define RPN_STATUS_F16_RANGE 1u
+int rpn_model_status(rpn_model *m, unsigned *flags, int reset, void *stream);
 /* debug / test hook: copy the activation of layer `name` (NHWC float32) into d_out */
 int rpn_model_get_activation(rpn_model *m, const char *name, float *d_out, size_t out_bytes, int shape[4],
                              void *stream);

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tf_rpn_amd.predictor import Proposer, shard_bounds
+from tf_rpn_amd.predictor import Proposer, compact_gathered, pad_records, shard_bounds
 
 M = 6
 
@@ -39,19 +39,27 @@ def _worker(rank, world, port, total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lo, hi = shard_bounds(total, world, rank)
-        rec = _records_for(lo, hi)
-        out = torch.empty((world * rec.shape[0], rec.shape[1]))
+        rows = -(-total // world)                     # uneven shards: every rank contributes ceil(total / world) rows
+        rec = pad_records(_records_for(lo, hi), rows)
+        out = torch.empty((world * rows, rec.shape[1]))
         dist.all_gather_into_tensor(out, rec)
+        out = compact_gathered(out, total, world)
         ok = torch.equal(out, _records_for(0, total))
         b, s, v = Proposer.unpack_records(out, M)
-        ok = ok and b.shape == (total, M, 4) and int(v[5]) == 5 % (M + 1)
+        ok = ok and b.shape == (total, M, 4) and v.dtype == torch.int32 and int(v[total - 1]) == (total - 1) % (M + 1)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_proposals_all_gather_world2():
-    world, total = 2, 8
+import pytest
+
+
+@pytest.mark.parametrize("total", [8, 7, 1])
+def test_sharded_proposals_all_gather_world2(total):
+    """Even (8 -> 4 + 4) and uneven (7 -> 4 + 3, 1 -> 1 + 0) contiguous shards: the all-gather needs equal sizes, so
+    short shards are padded with valid = 0 records that are dropped after the gather."""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

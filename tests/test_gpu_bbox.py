@@ -389,3 +389,25 @@ def test_rpn_generator_cycles_the_dataset():
         assert set(np.unique(np.asarray(lab))) <= {-1.0, 0.0, 1.0}
         lab2 = np.asarray(lab).reshape(2, -1)               # per image: <= 128 positives, negatives fill up to 256
         assert ((lab2 == 1).sum(axis=1) <= 128).all() and ((lab2 == 1).sum(axis=1) + (lab2 == 0).sum(axis=1) == 256).all()
+
+
+def test_nms_kernel_against_recalled_tf_unit_test_vectors():
+    """The HIP CombinedNMS through the C ABI on the known-answer vectors of TensorFlow's own unit tests (recalled from
+    non_max_suppression_op_test.cc, see tests/golden/tf_nms_kat.py for the provenance caveat)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("tf_nms_kat", os.path.join(os.path.dirname(__file__), "golden", "tf_nms_kat.py"))
+    kat = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kat)
+    from tf_rpn_amd.utils import bbox_utils
+    for name, boxes, scores, max_out, iou, thr, want in kat.NMS_CASES:
+        _b, _s, _c, v, idx = bbox_utils.non_max_suppression(boxes[None, :, None, :], scores[None, :, None],
+                                                            max_output_size_per_class=max_out, max_total_size=max_out,
+                                                            iou_threshold=iou, score_threshold=thr, clip_boxes=False,
+                                                            return_indices=True)
+        assert int(v[0]) == len(want) and idx[0, :len(want)].tolist() == want, name
+    for name, boxes, scores, per_class, total, iou, thr, clip, wb, ws, wv in kat.COMBINED_CASES:
+        b, s, c, v = bbox_utils.non_max_suppression(boxes[None, :, None, :], scores[None, :, None],
+                                                    max_output_size_per_class=per_class, max_total_size=total,
+                                                    iou_threshold=iou, score_threshold=thr, clip_boxes=clip)
+        assert int(v[0]) == wv and np.array_equal(b[0], wb) and np.array_equal(s[0], ws) and (c[0] == 0).all(), name

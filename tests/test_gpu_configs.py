@@ -1,0 +1,226 @@
+"""GPU parity at the BASELINE.json configurations that round 1 left untested on the device, and the float16-range
+safety of the ``f16x3`` conv arithmetic.
+
+* C5 = configs[4]: MobileNetV2, 1024x1024, 3 scales x 5 aspect ratios = 15 anchors per cell (F = 64, A = 61 440), one
+  image per GPU.  ``get_hyper_params`` is driven exactly as /root/reference/utils/train_utils.py:33-37 allows
+  (keyword overrides of existing keys; ``anchor_count`` recomputed).
+* C4 = configs[3]: VGG16 at 500x500, 32 images per GPU (batch 256 on 8 GPUs).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+from oracle import conv_oracle as cv
+from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+from tf_rpn_amd.predictor import Proposer
+from tf_rpn_amd.utils import train_utils
+
+pytestmark = pytest.mark.gpu
+
+C5_RATIOS = [1.0, 2.0, 1.0 / 2.0, 3.0, 1.0 / 3.0]
+
+
+def _c5_hyper_params():
+    hp = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                           anchor_ratios=list(C5_RATIOS)))
+    train_utils.get_hyper_params("mobilenet_v2", img_size=500, feature_map_shape=32,        # the table is a mutated
+                                 anchor_ratios=[1.0, 2.0, 0.5])                               # global: put it back
+    assert hp["anchor_count"] == 15 and hp["img_size"] == 1024 and hp["feature_map_shape"] == 64
+    return hp
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c5_mobilenet_v2_1024_k15_against_oracle(precision):
+    """configs[4], one image: conv stack + head within 1e-4 of torch-CPU (float64 oracle AND float32), then the
+    proposal stage bit-exact (indices, valid counts) against the C oracle fed the GPU head outputs."""
+    hp = _c5_hyper_params()
+    weights = synthetic_weights("mobilenet_v2", hp, seed=1)
+    prop = Proposer("mobilenet_v2", hyper_params=dict(hp), weights=weights, precision=precision, max_batch=1,
+                    iou_threshold=0.7)
+    assert prop.total_anchors == 64 * 64 * 15 == 61440
+    imgs = np.random.RandomState(0).uniform(0, 1, size=(1, 1024, 1024, 3)).astype(np.float32)
+    x = torch.from_numpy(imgs).cuda()
+    boxes, scores, valid, idx = [t.cpu().numpy() for t in prop.propose(x)]
+    deltas, obj = [t.cpu().numpy() for t in prop.forward(x)]
+    ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64)
+    assert ref[0].shape == (1, 64, 64, 60) and ref[1].shape == (1, 64, 64, 15)
+    e_reg = np.abs(deltas.reshape(ref[0].shape) - ref[0]).max()
+    e_cls = np.abs(obj.reshape(ref[1].shape) - ref[1]).max()
+    print("c5 %s: max|err| vs float64 oracle: reg %.3e cls %.3e" % (precision, e_reg, e_cls))
+    assert e_reg <= 1e-4 and e_cls <= 1e-4
+    if precision == "f16x3":
+        assert not prop.rpn_model.status()["f16_range"]
+    anchors = bo.generate_anchors(hp)
+    assert np.array_equal(prop.anchors.cpu().numpy(), anchors)
+    dec = co.decode(anchors, deltas, np.float32(hp["variances"]))
+    rb, rs, _rc, rv, ri = co.combined_nms(dec[:, :, None, :], obj[:, :, None], 300, 300, iou_threshold=0.7)
+    assert np.array_equal(valid, rv) and np.array_equal(idx, ri)
+    assert np.abs(boxes - rb).max() <= 1e-4 and np.array_equal(scores, rs)
+
+
+def test_c4_vgg16_batch32_invariance_and_properties():
+    """configs[3] per-GPU shard: 32 images through the f16x3 path.  Image i inside the batch of 32 gives bit-identical
+    head outputs and proposals to image i alone (batch 1 handle, same weights); output contract as in C2."""
+    hp = dict(bo.get_hyper_params("vgg16"))
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    big = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=32, iou_threshold=0.7)
+    imgs = torch.rand((32, 500, 500, 3), generator=torch.Generator().manual_seed(0)).cuda()
+    boxes, scores, valid, idx = [t.clone() for t in big.propose(imgs)]
+    deltas, obj = [t.clone() for t in big.forward(imgs)]
+    assert not big.rpn_model.status()["f16_range"]
+    assert boxes.shape == (32, 300, 4) and valid.dtype == torch.int32
+    assert (valid > 0).all() and (valid <= 300).all() and boxes.min() >= 0 and boxes.max() <= 1
+    assert torch.isfinite(deltas).all() and torch.isfinite(obj).all()
+    for b in range(32):
+        v = int(valid[b])
+        s = scores[b, :v]
+        assert (s[:-1] >= s[1:]).all() and (scores[b, v:] == 0).all() and (idx[b, v:] == -1).all()
+        assert len(set(idx[b, :v].tolist())) == v
+    one = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=1, iou_threshold=0.7)
+    for i in (0, 13, 31):
+        xi = imgs[i:i + 1].contiguous()
+        b1, s1, v1, i1 = [t.clone() for t in one.propose(xi)]
+        d1, o1 = one.forward(xi)
+        assert torch.equal(d1[0], deltas[i]) and torch.equal(o1[0], obj[i])
+        assert torch.equal(b1[0], boxes[i]) and torch.equal(i1[0], idx[i]) and int(v1[0]) == int(valid[i])
+    # oracle on one image of the batch: the box stage bit-exact against the C restatement fed the GPU head outputs
+    anchors = bo.generate_anchors(hp)
+    dec = co.decode(anchors, deltas[13:14].cpu().numpy(), np.float32(hp["variances"]))
+    _rb, _rs, _rc, rv, ri = co.combined_nms(dec[:, :, None, :], obj[13:14].cpu().numpy()[:, :, None], 300, 300,
+                                            iou_threshold=0.7)
+    assert int(rv[0]) == int(valid[13]) and np.array_equal(ri[0], idx[13].cpu().numpy())
+
+
+# ---- float16 range safety of the f16x3 arithmetic ------------------------------------------------------------------
+def _scaled_pair(weights, first, second, s):
+    """ReLU is positively homogeneous: scaling layer `first` (kernel and bias) by s and the kernel of the layer that
+    consumes it by 1/s leaves every later activation mathematically unchanged -- only `first`'s output grows by s."""
+    w = {k: dict(v) for k, v in weights.items()}
+    w[first]["kernel"] = (weights[first]["kernel"] * np.float32(s)).astype(np.float32)
+    w[first]["bias"] = (weights[first]["bias"] * np.float32(s)).astype(np.float32)
+    w[second]["kernel"] = (weights[second]["kernel"] / np.float32(s)).astype(np.float32)
+    return w
+
+
+def test_f16x3_overflow_is_flagged_never_silent():
+    """Activations pushed past 65504 (block2_conv1 scaled by 2^20, block2_conv2 by 2^-20): the exact-f32 and bf16x3
+    paths still meet the 1e-4 bound; f16x3 raises the device flag, ``predict_on_batch`` on numpy input refuses to
+    return, and the flag is sticky until reset."""
+    hp = bo.get_hyper_params("vgg16", img_size=96, feature_map_shape=6)
+    base = synthetic_weights("vgg16", hp, seed=1)
+    weights = _scaled_pair(base, "block2_conv1", "block2_conv2", 2.0 ** 20)
+    imgs = np.random.RandomState(0).uniform(0, 1, size=(2, 96, 96, 3)).astype(np.float32)
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    for precision in ("f32", "bf16x3"):
+        model = RPNModel("vgg16", hp, precision=precision, max_batch=2)
+        model.set_weights(weights)
+        reg, cls = model.predict_on_batch(imgs)
+        assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4, precision
+        assert not model.status()["f16_range"]
+    model = RPNModel("vgg16", hp, precision="f16x3", max_batch=2)
+    model.set_weights(weights)
+    with pytest.raises(FloatingPointError, match="float16 range"):
+        model.predict_on_batch(imgs)
+    x = torch.from_numpy(imgs).cuda()
+    model.predict_on_batch(x)                                   # CUDA tensors: no host read-back on the hot path ...
+    assert model.status()["f16_range"]                          # ... the flag is there for whoever polls
+    assert model.status(reset=True)["f16_range"] and not model.status()["f16_range"]
+    # the unscaled weights on the same handle: clean again, and within the bound
+    model.set_weights(base)
+    reg, cls = model.predict_on_batch(imgs)
+    ref0 = cv.rpn_forward("vgg16", imgs, base, dtype=torch.float64)
+    assert np.abs(reg - ref0[0]).max() <= 1e-4 and np.abs(cls - ref0[1]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3"])
+def test_split_precision_tiny_inputs_subnormal_halves(precision):
+    """Images ~1e-6: the float16 hi halves of the first activations are subnormal and their lo halves vanish.  The
+    absolute error this leaves on the head outputs must stay inside the 1e-4 bound (it is absolute, not relative)."""
+    hp = bo.get_hyper_params("vgg16", img_size=96, feature_map_shape=6)
+    weights = synthetic_weights("vgg16", hp, seed=2)
+    for w in weights.values():                                  # biases off so that the tiny signal is all there is
+        if "bias" in w:
+            w["bias"] = np.zeros_like(w["bias"])
+    imgs = (np.random.RandomState(1).uniform(0, 1, size=(1, 96, 96, 3)) * 1e-6).astype(np.float32)
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    model = RPNModel("vgg16", hp, precision=precision, max_batch=1)
+    model.set_weights(weights)
+    reg, cls = model.predict_on_batch(imgs)
+    assert np.isfinite(reg).all() and np.isfinite(cls).all()
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+def test_mobilenet_v2_wide_batchnorm_scales(precision):
+    """BatchNorm scales gamma / sqrt(var + 1e-3) spanning 1e-2 ... 50 (a Keras checkpoint with small moving variances
+    gives ~31 already): the power-of-two pre-scale of the float16 weights is derived from the FOLDED kernel, so the hi
+    halves stay finite and the outputs stay within the bound."""
+    hp = bo.get_hyper_params("mobilenet_v2", img_size=96, feature_map_shape=6)
+    weights = synthetic_weights("mobilenet_v2", hp, seed=5)
+    rng = np.random.RandomState(9)
+    for name, w in weights.items():
+        if "gamma" in w:
+            n = w["gamma"].shape[0]
+            scale = np.exp(rng.uniform(np.log(1e-2), np.log(50.0), size=n))
+            w["var"] = rng.uniform(1e-4, 2e-3, size=n).astype(np.float32)          # tiny moving variances
+            w["gamma"] = (scale * np.sqrt(w["var"] + 1e-3)).astype(np.float32)
+    # keep the signal alive through ReLU6 saturation: only the stem and the depthwise BNs get the wide scales, the
+    # project BNs (linear, unbounded) a narrow one
+    for name, w in weights.items():
+        if "gamma" in w and "project" in name:
+            w["gamma"] = (np.sqrt(w["var"] + 1e-3) * rng.uniform(0.5, 1.5, size=w["gamma"].shape[0])).astype(np.float32)
+    imgs = np.random.RandomState(2).uniform(0, 1, size=(2, 96, 96, 3)).astype(np.float32)
+    ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64)
+    model = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=2)
+    model.set_weights(weights)
+    reg, cls = model.predict_on_batch(imgs)
+    assert np.isfinite(reg).all() and np.isfinite(cls).all()
+    scale = max(1.0, float(np.abs(ref[0]).max()))
+    assert np.abs(reg - ref[0]).max() <= 1e-4 * scale and np.abs(cls - ref[1]).max() <= 1e-4
+    assert not model.status()["f16_range"]
+
+
+def test_hot_path_rejects_malformed_batches():
+    """``Proposer.forward`` / ``forward_into`` hand raw pointers to the C side: dtype, device, layout and shape are
+    checked in Python first (a uint8 / NCHW / oversized batch would otherwise be read out of bounds)."""
+    hp = dict(bo.get_hyper_params("vgg16", img_size=64, feature_map_shape=4))
+    prop = Proposer("vgg16", hyper_params=dict(hp), max_batch=2)
+    good = torch.rand((2, 64, 64, 3), device="cuda")
+    prop.propose(good)
+    bad = [good.cpu(), good.to(torch.float16), good.permute(0, 3, 1, 2), good[:, :32], torch.rand((3, 64, 64, 3), device="cuda"),
+           (good * 255).to(torch.uint8), good.transpose(1, 2)]   # the last one: right shape, not contiguous
+    for x in bad:
+        with pytest.raises(ValueError):
+            prop.propose(x)
+    reg = torch.empty((2, 4, 4, 36), device="cuda")
+    with pytest.raises(ValueError):
+        prop.rpn_model.forward_into(good, reg, torch.empty((2, 4, 4, 8), device="cuda"))
+
+
+def test_target_assignment_priority_contract():
+    """utils/train_utils.py:59-60: each randomly_select_xyz_mask call draws from [1, reduce_max(select_xyz) * 10).
+    User-supplied priorities must be >= 1 (0 marks a non-candidate); the default draws honour the per-call maxval and
+    select exactly min(total_pos, candidates) positives and 256 - pos negatives."""
+    hp = dict(bo.get_hyper_params("vgg16"))
+    anchors = bo.generate_anchors(hp)
+    rng = np.random.RandomState(4)
+    B, G, A = 3, 6, anchors.shape[0]
+    gt = np.zeros((B, G, 4), np.float32)
+    for b in range(B):
+        for g in range(4):
+            y, x = rng.uniform(0.05, 0.5, size=2)
+            h, w = rng.uniform(0.2, 0.45, size=2)
+            gt[b, g] = [y, x, y + h, x + w]
+    labels = np.full((B, G), -1, np.int32)
+    labels[:, :4] = 1
+    deltas, lab = train_utils.calculate_rpn_actual_outputs(anchors, gt, labels, hp)
+    lab = lab.reshape(B, -1)
+    pos, neg = (lab == 1).sum(1), (lab == 0).sum(1)
+    assert (pos <= 128).all() and (pos >= 1).all() and ((pos + neg) == 256).all()
+    assert np.isfinite(deltas).all() and (np.abs(deltas[lab != 1]) == 0).all()
+    bad = np.ones((B, A), np.int32)
+    bad[1, 7] = 0
+    with pytest.raises(ValueError, match=">= 1"):
+        train_utils.calculate_rpn_actual_outputs(anchors, gt, labels, hp, random_pos=bad, random_neg=np.ones((B, A), np.int32))

@@ -225,5 +225,12 @@ def test_bench_prints_one_json_line(extra):
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "conv3x3_split16_dma" in rf["kernel"] and 0.2 < rf["frac"] < 1.0
+    assert d["rccl_ranks"] == 1 and "traffic_source" in rf
+    # the N = 1 line carries the box-path leg (configs[2], the metric's "NMS boxes/sec") and the exact-f32 leg
+    c3 = d["c3"]
+    assert c3["B"] == 64 and c3["iou_map"]["GBps"] > 100 and c3["decode"]["GBps"] > 100
+    assert d["nms_boxes_per_sec"] == c3["decode_nms_iou0.7"]["boxes_per_sec"] > 1e8
+    f32 = d["exact_f32"]
+    assert f32["dtype"] == "f32" and 100 < f32["value"] < d["value"] and 0.2 < f32["roofline"]["frac"] < 1.0
     if "--force-dist" in extra:
         assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -190,3 +191,40 @@ def test_get_step_size():
     import math
     for total, bs in ((4952, 4), (4952, 8), (1, 8), (16, 8), (17, 8), (5011, 3)):
         assert train_utils.get_step_size(total, bs) == math.ceil(total / bs)
+
+
+# ---- bench.py launches its own ranks (python bench.py --gpus N without torchrun) -------------------------------------
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_spawn_ranks_environment_and_failure_handling():
+    import time
+    bench = _bench_module()
+    code = "import os; print(os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']) > 0)"
+    rc, out = bench.spawn_ranks(3, [sys.executable, "-c", code])
+    assert rc == 0 and out.strip() == "0 0 3 127.0.0.1 True"          # rank 0's stdout only
+    # one rank fails: its code is returned and the sleeping ranks are terminated, not waited for
+    t0 = time.time()
+    rc, _ = bench.spawn_ranks(3, [sys.executable, "-c",
+                                  "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '2' else time.sleep(60)"])
+    assert rc == 7 and time.time() - t0 < 30
+    t0 = time.time()
+    rc, _ = bench.spawn_ranks(2, [sys.executable, "-c", "import time; time.sleep(60)"], timeout=1.0)
+    assert rc == 124 and time.time() - t0 < 30
+
+
+def test_bench_gpus_n_without_launcher_fails_cleanly_without_devices():
+    """`python bench.py --gpus 2` on a box with fewer than 2 HIP devices: non-zero exit, a message, no hang, no JSON."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr

@@ -256,3 +256,34 @@ def test_resize_restatement_matches_scikit_image():
         got = bo.preprocess_image(src, ref.shape[0], ref.shape[1])
         assert got.dtype == np.float32 and got.shape == ref.shape
         assert np.abs(got - ref).max() <= 2e-5          # float32 rounding of a [0,1] image (observed 7e-6)
+
+
+# ---- (d) TensorFlow's own published known-answer tests for the NMS kernels (recalled; tests/golden/tf_nms_kat.py) ----
+def _kat():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tf_nms_kat", os.path.join(os.path.dirname(__file__), "golden", "tf_nms_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("impl", ["numpy", "c"])
+def test_nms_restatements_against_recalled_tf_unit_test_vectors(impl):
+    kat = _kat()
+
+    def run(boxes, scores, per_class, total, iou, thr, clip):
+        b, s = boxes[None, :, None, :], scores[None, :, None]
+        if impl == "c":
+            return co.combined_nms(b, s, per_class, total, iou_threshold=iou, score_threshold=thr, clip_boxes=clip)
+        ob, osc, oc, ov, oi = bo.combined_non_max_suppression(b, s, per_class, total, iou_threshold=iou, score_threshold=thr,
+                                                              clip_boxes=clip, return_indices=True)
+        return ob, osc, oc, ov, oi
+
+    for name, boxes, scores, max_out, iou, thr, want in kat.NMS_CASES:
+        _ob, _os, _oc, ov, oi = run(boxes, scores, max_out, max_out, iou, thr, False)
+        assert int(ov[0]) == len(want) and oi[0, :len(want)].tolist() == want, name
+        assert (oi[0, len(want):] == -1).all(), name
+    for name, boxes, scores, per_class, total, iou, thr, clip, wb, ws, wv in kat.COMBINED_CASES:
+        ob, osc, oc, ov, _oi = run(boxes, scores, per_class, total, iou, thr, clip)
+        assert int(ov[0]) == wv, name
+        assert np.array_equal(ob[0], wb) and np.array_equal(osc[0], ws) and (oc[0] == 0).all(), name

@@ -22,6 +22,7 @@ vp = ctypes.c_void_p
 RPN_OK, RPN_ERR_INVALID, RPN_ERR_NO_DEVICE, RPN_ERR_WORKSPACE, RPN_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16x3": 1, "f16x3": 2, "fp16x3": 2}
 BACKBONES = {"vgg16": 0, "mobilenet_v2": 1}
+STATUS_F16_RANGE = 1
 ACTS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "relu6": 3}
 
 # name -> (restype, argtypes); mirrors include/rpn_hip.h one to one
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "rpn_model_keep_activations": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_model_set_layer": (ctypes.c_int, [vp, ctypes.c_char_p] + [c_float_p] * 6),
     "rpn_model_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
+    "rpn_model_status": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_uint), ctypes.c_int, vp]),
     "rpn_model_get_activation": (ctypes.c_int, [vp, ctypes.c_char_p, vp, ctypes.c_size_t, c_int_p, vp]),
     "rpn_model_flops_per_image": (ctypes.c_double, [vp]),
     "rpn_model_set_profiling": (ctypes.c_int, [vp, ctypes.c_int]),

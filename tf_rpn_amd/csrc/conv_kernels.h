@@ -54,6 +54,11 @@ hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const fl
                             int stride, int pad_t, int pad_l, int OH, int OW, int act, float *out,
                             hipStream_t stream);
 
+// Device word into which the split-format writers launched from THIS host thread flag float16 range violations
+// (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.
+void set_range_status(unsigned *p);
+unsigned *range_status();
+
 // ---- x3-split 16-bit MFMA path (conv_split_kernels.hip) ----------------------------------------
 // SPLIT16 activation layout: [B][H][W][C/16][64 B] = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} (bf16 or f16).
 // Split weights: [Cin/16][9][cout_pad][64 B], cout_pad = 64 for Cout <= 64, else round_up(Cout, 128).

@@ -115,11 +115,22 @@ template <> struct Half<true> {
 };
 
 // 8 floats -> one 16-byte piece: the hi halves, or the lo halves (x - hi)
+// `status` (may be null): device word that receives RPN_STATUS_F16_RANGE when an activation does not fit float16
+// (|x| > 65504, or non-finite): its hi half would become inf and every later layer silently garbage (ReLU turns the
+// resulting NaNs into zeros).  Checked once per piece, by the lane that produces the hi halves; bf16 halves have
+// float32's range.
 template <bool F16>
-__device__ __forceinline__ uint4 split_piece(const float (&x)[8], bool lo)
+__device__ __forceinline__ uint4 split_piece(const float (&x)[8], bool lo, unsigned *status = nullptr)
 {
     using E = typename Half<F16>::elem;
     typename Half<F16>::vec v;
+    if constexpr (F16) {
+        if (status && !lo) {
+            const float m = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))),
+                                  fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7]))));
+            if (!(m <= 65504.0f)) atomicOr(status, 1u /* RPN_STATUS_F16_RANGE */);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const E h = (E)x[k];
@@ -150,6 +161,7 @@ struct SplitConvArgs {
     float out_scale;      // 2^-s when the weights were pre-scaled by 2^s
     int act, out_f32;
     unsigned *sched;      // persistent kernel: 17 zero-initialised counters (per XCD label: tile queue, exits; labels done), or null
+    unsigned *status;     // float16 range flag of the owning model (split_piece), or null
 };
 
 // TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64).
@@ -384,7 +396,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                     xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
                     xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
                     out[((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
-                        split_piece<F16>(xs, (pc & 1) != 0);
+                        split_piece<F16>(xs, (pc & 1) != 0, a.status);
                 }
             }
         }
@@ -511,7 +523,7 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float
                     xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
                     xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
                     out[RPN_STORE_INDEX(((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc)] =
-                        split_piece<F16>(xs, (pc & 1) != 0);
+                        split_piece<F16>(xs, (pc & 1) != 0, a.status);
                 }
             }
         }
@@ -1141,7 +1153,7 @@ template <bool F16, bool OUT_SPLIT, int STRIDE, int NTILES>
 __global__ void __launch_bounds__(256)
 conv_cin3_mfma_kernel(const float *__restrict__ x, const uint4 *__restrict__ w /* [Cout_pad][8 pieces] */,
                       const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
-                      int pad_t, int pad_l, int act, float out_scale, int tiles_x, int tiles_y)
+                      int pad_t, int pad_l, int act, float out_scale, int tiles_x, int tiles_y, unsigned *status)
 {
     constexpr int COUT = 16 * NTILES;
     constexpr int PR = 7 * STRIDE + 3, PC = 31 * STRIDE + 3;            // input patch rows / columns
@@ -1240,7 +1252,7 @@ conv_cin3_mfma_kernel(const float *__restrict__ x, const uint4 *__restrict__ w /
                     const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
                     xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
                     xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-                    reinterpret_cast<uint4 *>(out)[pix * PPX + q] = split_piece<F16>(xs, (pc & 1) != 0);
+                    reinterpret_cast<uint4 *>(out)[pix * PPX + q] = split_piece<F16>(xs, (pc & 1) != 0, status);
                 } else {
                     reinterpret_cast<float4 *>(out)[pix * PPX + q] =
                         *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
@@ -1288,7 +1300,7 @@ hipError_t launch_conv_cin3_mfma(const float *x, const void *w, const float *bia
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
 #define RPN_C3M(F16_, SPLIT_, STRIDE_, NT_)                                                                          \
     hipLaunchKernelGGL((conv_cin3_mfma_kernel<F16_, SPLIT_, STRIDE_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, s, x, \
-                       (const uint4 *)w, bias, out, B, H, W, OH, OW, pad_t, pad_l, act, out_scale, tiles_x, tiles_y)
+                       (const uint4 *)w, bias, out, B, H, W, OH, OW, pad_t, pad_l, act, out_scale, tiles_x, tiles_y, range_status())
 #define RPN_C3M_FMT(F16_, STRIDE_, NT_) \
     { if (out_fmt) RPN_C3M(F16_, true, STRIDE_, NT_); else RPN_C3M(F16_, false, STRIDE_, NT_); }
 #define RPN_C3M_ST(F16_, NT_) \
@@ -1304,7 +1316,7 @@ hipError_t launch_conv_cin3_mfma(const float *x, const void *w, const float *bia
 // ---- float32 NHWC <-> SPLIT16 ---------------------------------------------------------------
 template <bool F16>
 __global__ void __launch_bounds__(256)
-f32_to_split_kernel(const float *__restrict__ x, long long npieces, uint4 *__restrict__ out)
+f32_to_split_kernel(const float *__restrict__ x, long long npieces, uint4 *__restrict__ out, unsigned *status)
 {
     // piece p: pixel-major; 4 pieces per 16 channels; piece (g*2 + lo) covers channels 8g..8g+7
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npieces; p += (long long)gridDim.x * 256) {
@@ -1314,7 +1326,7 @@ f32_to_split_kernel(const float *__restrict__ x, long long npieces, uint4 *__res
         const float4 v0 = *reinterpret_cast<const float4 *>(src);
         const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
         const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        out[p] = split_piece<F16>(xs, (pc & 1) != 0);
+        out[p] = split_piece<F16>(xs, (pc & 1) != 0, status);
     }
 }
 
@@ -1396,7 +1408,7 @@ template <bool F16, bool OUT_SPLIT, int STRIDE>
 __global__ void __launch_bounds__(256)
 conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27, Cout) */,
                  const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
-                 int Cout, int stride, int pad_t, int pad_l, int act, long long npairs)
+                 int Cout, int stride, int pad_t, int pad_l, int act, long long npairs, unsigned *status)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [27][Cout] + bias[Cout], then the stage
     const int CG = Cout >> 4;
@@ -1482,9 +1494,9 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
         if constexpr (OUT_SPLIT) {
             const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
             const float hi8[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
-            dst[0] = split_piece<F16>(lo8, false);
+            dst[0] = split_piece<F16>(lo8, false, status);
             dst[1] = split_piece<F16>(lo8, true);
-            dst[2] = split_piece<F16>(hi8, false);
+            dst[2] = split_piece<F16>(hi8, false, status);
             dst[3] = split_piece<F16>(hi8, true);
         } else {
 #pragma unroll
@@ -1528,7 +1540,7 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
     const size_t lds = (size_t)28 * Cout * sizeof(float) + (size_t)2048 * 16;   // weights + bias + staged records
 #define RPN_CIN3(F16_, SPLIT_, STRIDE_)                                                                       \
     hipLaunchKernelGGL((conv_cin3_kernel<F16_, SPLIT_, STRIDE_>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, \
-                       H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs)
+                       H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs, range_status())
     if (stride != 1 && stride != 2) return hipErrorInvalidValue;
     if (out_fmt == 0) {
         if (stride == 1) RPN_CIN3(false, false, 1); else RPN_CIN3(false, false, 2);
@@ -1542,6 +1554,12 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// Device word that the kernels launched from this thread flag float16 range violations into (rpn_model_forward sets
+// it to the model's status word around its launches; null = no reporting).
+static thread_local unsigned *t_range_status = nullptr;
+void set_range_status(unsigned *p) { t_range_status = p; }
+unsigned *range_status() { return t_range_status; }
+
 static inline unsigned short f32_to_bf16_rne(float f)
 {
     unsigned u;
@@ -1650,8 +1668,8 @@ hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, 
     if (C % 16 != 0) return hipErrorInvalidValue;
     const long long pieces = npix * (C / 16) * 4;
     if (pieces == 0) return hipSuccess;
-    if (f16) hipLaunchKernelGGL(f32_to_split_kernel<true>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out);
-    else hipLaunchKernelGGL(f32_to_split_kernel<false>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out);
+    if (f16) hipLaunchKernelGGL(f32_to_split_kernel<true>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out, range_status());
+    else hipLaunchKernelGGL(f32_to_split_kernel<false>, dim3(grid_cap(pieces)), dim3(256), 0, s, x, pieces, (uint4 *)out, range_status());
     return hipGetLastError();
 }
 
@@ -1786,6 +1804,7 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
 {
     if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     SplitConvArgs a{};
+    a.status = range_status();
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
@@ -1856,6 +1875,7 @@ hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias,
 {
     if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     SplitConvArgs a{};
+    a.status = range_status();
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;

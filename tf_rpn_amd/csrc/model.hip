@@ -75,6 +75,7 @@ struct rpn_model {
     std::vector<Param> params;
     size_t weight_floats = 0, arena_floats = 0;   // arena: per-image floats
     float *d_weights = nullptr, *d_arena = nullptr;
+    unsigned *d_status = nullptr;          // RPN_STATUS_* flags raised by the kernels (sticky until rpn_model_status resets)
     const float *last_input = nullptr;
     double flops = 0.0;
     // optional per-op timing: one hipEvent before the first op and one after every op
@@ -386,6 +387,10 @@ static int ensure_device(rpn_model *m)
     if (!m->d_arena) {
         RPN_HIP_CHECK(hipMalloc(&m->d_arena, m->arena_floats * (size_t)m->max_batch * sizeof(float)));
     }
+    if (!m->d_status) {
+        RPN_HIP_CHECK(hipMalloc(&m->d_status, 64));
+        RPN_HIP_CHECK(hipMemset(m->d_status, 0, 64));
+    }
     return RPN_OK;
 }
 
@@ -428,6 +433,7 @@ extern "C" void rpn_model_destroy(rpn_model *m)
     if (!m) return;
     if (m->d_weights) (void)hipFree(m->d_weights);
     if (m->d_arena) (void)hipFree(m->d_arena);
+    if (m->d_status) (void)hipFree(m->d_status);
     for (auto &ev : m->events) (void)hipEventDestroy(ev);
     delete m;
 }
@@ -525,9 +531,14 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
     } else if (op.cin3_mfma) {
-        const int wshift = split_weight_shift(kernel, (size_t)27 * p.Cout, m->f16);
+        // the power-of-two pre-scale is derived from the FOLDED weights (a BatchNorm scale of 30 on top of a shift
+        // chosen for the raw kernel would push the float16 hi halves past 65504)
+        std::vector<float> folded(kernel, kernel + (size_t)27 * p.Cout);
+        if (has_bn)
+            for (size_t i = 0; i < folded.size(); ++i) folded[i] *= scale[i % (size_t)p.Cout];
+        const int wshift = split_weight_shift(folded.data(), folded.size(), m->f16);
         std::vector<unsigned short> packed((size_t)p.Cout * 64);
-        pack_weights_cin3_mfma_host(kernel, has_bn ? scale.data() : nullptr, p.Cout, p.Cout, m->f16, wshift, packed.data());
+        pack_weights_cin3_mfma_host(folded.data(), nullptr, p.Cout, p.Cout, m->f16, wshift, packed.data());
         op.out_scale = ldexpf(1.0f, -wshift);
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(unsigned short),
                                 hipMemcpyHostToDevice));
@@ -543,14 +554,15 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                 hipMemcpyHostToDevice));
     } else if (op.split) {
         const int cpad = split_cout_pad(op.Cout);
-        const int wshift = split_weight_shift(kernel, (size_t)9 * p.Cin * p.Cout, m->f16);
+        std::vector<float> folded(kernel, kernel + (size_t)9 * p.Cin * p.Cout);       // BatchNorm folded BEFORE the shift
+        if (has_bn)
+            for (size_t i = 0; i < folded.size(); ++i) folded[i] *= scale[i % (size_t)p.Cout];
+        const int wshift = split_weight_shift(folded.data(), folded.size(), m->f16);
         std::vector<unsigned short> packed(split_weight_bytes(op.Cin, op.Cout) / sizeof(unsigned short));
         if (op.k16)
-            pack_weights_split32_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
-                                      packed.data());
+            pack_weights_split32_host(folded.data(), nullptr, p.Cin, p.Cout, cpad, m->f16, wshift, packed.data());
         else
-            pack_weights_split_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, cpad, m->f16, wshift,
-                                    packed.data());
+            pack_weights_split_host(folded.data(), nullptr, p.Cin, p.Cout, cpad, m->f16, wshift, packed.data());
         op.out_scale = ldexpf(1.0f, -wshift);
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(unsigned short),
                                 hipMemcpyHostToDevice));
@@ -578,6 +590,10 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     if (st != RPN_OK) return st;
     hipStream_t s = as_stream(stream);
     m->last_input = d_imgs;
+    struct StatusScope {                   // the split-format writers launched below flag float16 range violations here
+        explicit StatusScope(unsigned *p) { set_range_status(p); }
+        ~StatusScope() { set_range_status(nullptr); }
+    } status_scope(m->f16 ? m->d_status : nullptr);
     hipEvent_t *evs = nullptr;
     int sel_op = -1;
     if (m->profiling > 0) {
@@ -669,6 +685,18 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
         ++op_index;
         if (evs && want_event((size_t)op_index)) RPN_HIP_CHECK(hipEventRecord(evs[op_index], s));
     }
+    return RPN_OK;
+}
+
+extern "C" int rpn_model_status(rpn_model *m, unsigned *flags, int reset, void *stream)
+{
+    RPN_REQUIRE(m && flags, "rpn_model_status: null argument");
+    *flags = 0;
+    if (!m->d_status) return RPN_OK;                                // no forward has run
+    hipStream_t s = as_stream(stream);
+    RPN_HIP_CHECK(hipMemcpyAsync(flags, m->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    if (reset) RPN_HIP_CHECK(hipMemsetAsync(m->d_status, 0, sizeof(unsigned), s));
+    RPN_HIP_CHECK(hipStreamSynchronize(s));
     return RPN_OK;
 }
 

@@ -2,8 +2,8 @@
 the reference's Keras ``rpn_model`` stands (models/rpn_vgg16.py:21, predictor.py:41-50).
 
 Only the inference surface the proposal path touches is mirrored: ``predict_on_batch``,
-``__call__`` and ``load_weights`` (from a ``.npz`` in this repo's flat format; Keras ``.h5``
-files need h5py, which is absent from the build image -- SURVEY.md 8f row N4).
+``__call__`` and ``load_weights`` (Keras ``.h5`` checkpoints through ``utils/h5_weights.py`` -- no h5py
+needed -- or a flat ``.npz``).
 """
 import ctypes
 
@@ -143,14 +143,45 @@ class RPNModel(object):
         reg = torch.empty((B, F, F, 4 * K), dtype=torch.float32, device="cuda")
         cls = torch.empty((B, F, F, K), dtype=torch.float32, device="cuda")
         self.forward_into(x, reg, cls)
+        if was_np and self.precision in ("f16x3", "fp16x3"):
+            # numpy in / numpy out synchronises anyway: never hand back silently wrong outputs.  CUDA-tensor callers
+            # (the hot path) poll ``status()`` themselves, a forward never reads the flag back.
+            self.raise_on_range_error()
         return [L.from_device(reg, was_np), L.from_device(cls, was_np)]
 
     __call__ = predict_on_batch
 
     def forward_into(self, x, reg, cls):
-        """Forward on preallocated CUDA tensors (no allocation: graph-capturable)."""
+        """Forward on preallocated CUDA tensors (no allocation: graph-capturable).  The C side sees raw pointers, so
+        dtype / device / layout / shape are checked here."""
+        B = int(x.shape[0]) if isinstance(x, torch.Tensor) and x.dim() == 4 else -1
+        F, K = self.feature_map_shape, self.anchor_count
+        for t, shape, what in ((x, (B, self.img_size, self.img_size, 3), "imgs"), (reg, (B, F, F, 4 * K), "reg"),
+                               (cls, (B, F, F, K), "cls")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                    and tuple(t.shape) == shape):
+                raise ValueError("%s must be a contiguous CUDA float32 tensor of shape %s, got %s"
+                                 % (what, shape, (tuple(t.shape), t.dtype, t.device) if isinstance(t, torch.Tensor) else type(t)))
+        if not 1 <= B <= self.max_batch:
+            raise ValueError("batch %d outside [1, %d]" % (B, self.max_batch))
         st = L.lib().rpn_model_forward(self._h, L.ptr(x), int(x.shape[0]), L.ptr(reg), L.ptr(cls), L.stream_ptr())
         L.check(st, "rpn_model_forward")
+
+    # ---- float16 range status (precision "f16x3") ---------------------------------------------------
+    def status(self, reset=False):
+        """Sticky flags raised on the device by the forwards so far -> {"f16_range": bool}.  ``f16_range``: some
+        activation did not fit float16 when it was written in split form (|x| > 65504 or non-finite), the outputs of
+        that forward are invalid.  Synchronises the current stream (not part of the hot path)."""
+        flags = ctypes.c_uint(0)
+        L.check(L.lib().rpn_model_status(self._h, ctypes.byref(flags), 1 if reset else 0, L.stream_ptr()),
+                "rpn_model_status")
+        return {"f16_range": bool(flags.value & L.STATUS_F16_RANGE)}
+
+    def raise_on_range_error(self):
+        if self.status(reset=True)["f16_range"]:
+            raise FloatingPointError("precision 'f16x3': an activation left the float16 range (|x| > 65504); the outputs "
+                                     "are invalid -- use precision='bf16x3' (float32 range, same speed) or 'f32' for "
+                                     "these weights")
 
     # ---- per-op timing (HIP events on the launch stream) ---------------------------------------
     def set_profiling(self, n_forwards=1):

@@ -72,15 +72,28 @@ class Proposer(object):
     # -- the hot path ---------------------------------------------------------------------
     def forward(self, imgs):
         """imgs: CUDA float32 (B,img,img,3).  Returns views (deltas (B,A,4), objectness (B,A))."""
-        B = int(imgs.shape[0])
+        B = self._check_imgs(imgs)
         reg, cls = self._reg[:B], self._cls[:B]
         self.rpn_model.forward_into(imgs, reg, cls)                           # predictor.py:50
         return reg.view(B, -1, 4), cls.view(B, -1)                             # predictor.py:52-53
 
+    def _check_imgs(self, imgs):
+        """The C side only sees a raw pointer: refuse anything that is not a contiguous CUDA float32
+        (B, img_size, img_size, 3) batch with B <= max_batch (a wrong dtype / layout would be read out of bounds)."""
+        s = int(self.hyper_params["img_size"])
+        if not (isinstance(imgs, torch.Tensor) and imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
+                and imgs.dim() == 4 and tuple(imgs.shape[1:]) == (s, s, 3) and 1 <= int(imgs.shape[0]) <= self.max_batch):
+            raise ValueError("imgs must be a contiguous CUDA float32 tensor (B<=%d, %d, %d, 3) NHWC; got %s"
+                             % (self.max_batch, s, s, "%s %s" % (tuple(imgs.shape), imgs.dtype)
+                                if isinstance(imgs, torch.Tensor) else type(imgs)))
+        return int(imgs.shape[0])
+
     def propose(self, imgs):
         """imgs -> (boxes (B,300,4), scores (B,300), valid (B,) int32, indices (B,300) int32)."""
         if self.overlap_nms:
-            return self._propose_pipelined(imgs)
+            out = self.propose_async(imgs)
+            self.wait()                               # consumers on the current stream see finished proposals
+            return out
         B = int(imgs.shape[0])
         deltas, scores = self.forward(imgs)
         ob, osc, oi, ov = self._boxes[:B], self._scores[:B], self._idx[:B], self._valid[:B]
@@ -90,11 +103,15 @@ class Proposer(object):
         L.check(st, "rpn_decode_nms")
         return ob, osc, ov, oi
 
-    def _propose_pipelined(self, imgs):
-        """Same results as ``propose``; the returned tensors are complete once the CURRENT stream has passed the
-        wait this method enqueues (consumers on the current stream see finished data, as with ``propose``), but the
-        next call's conv stack may start while this call's NMS is still running."""
-        B = int(imgs.shape[0])
+    def propose_async(self, imgs):
+        """Pipelined form (needs ``overlap_nms=True``): enqueues the conv stack on the current stream and decode+NMS
+        on the side stream and returns the output tensors WITHOUT ordering the current stream behind the NMS, so that
+        the next call's conv stack can start while this call's NMS is still running.  The tensors are complete only
+        after ``wait()`` (which makes the current stream wait for the NMS of the last call); ``propose`` does both.
+        Throughput loops call this and ``wait()`` once at the end."""
+        if not self.overlap_nms:
+            raise RuntimeError("propose_async needs overlap_nms=True")
+        B = self._check_imgs(imgs)
         main = torch.cuda.current_stream()
         buf = self._bufs[self._slot]
         self._slot ^= 1
@@ -145,19 +162,32 @@ class Proposer(object):
         return (top, order, torch.gather(scores, 1, order)) if return_scores else (top, order)
 
     # -- multi-GPU collection ---------------------------------------------------------------
-    def pack_records(self, boxes, scores, valid):
-        """(B,M,4),(B,M),(B,) -> one float32 record per image: M*5 floats + valid count."""
+    def pack_records(self, boxes, scores, valid, out=None):
+        """(B,M,4),(B,M),(B,) -> one record per image: M*5 float32 + the int32 valid count in the last 4 bytes
+        (bit copy, no float round trip).  ``out``: a (rows >= B, M*5+1) float32 buffer to fill (rows beyond B are
+        left as they are); without it a new tensor is allocated."""
         B, M = int(scores.shape[0]), int(scores.shape[1])
-        rec = torch.empty((B, M * 5 + 1), dtype=torch.float32, device=boxes.device)
+        rec = out[:B] if out is not None else torch.empty((B, M * 5 + 1), dtype=torch.float32, device=boxes.device)
         rec[:, :M * 4] = boxes.reshape(B, M * 4)
         rec[:, M * 4:M * 5] = scores
-        rec[:, M * 5] = valid.to(torch.float32)
+        rec.view(torch.int32)[:, M * 5] = valid
         return rec
 
     @staticmethod
     def unpack_records(rec, M):
         B = int(rec.shape[0])
-        return (rec[:, :M * 4].reshape(B, M, 4), rec[:, M * 4:M * 5], rec[:, M * 5].to(torch.int32))
+        return (rec[:, :M * 4].reshape(B, M, 4), rec[:, M * 4:M * 5], rec.view(torch.int32)[:, M * 5])
+
+    def _record_buffer(self, slot, rows):
+        """Preallocated per-slot record buffers of the distributed step (no allocation inside a step); rows beyond the
+        local batch stay zero = records with valid = 0 (padding of uneven shards)."""
+        bufs = getattr(self, "_rec_bufs", None)
+        if bufs is None:
+            bufs = self._rec_bufs = {}
+        key = (slot, rows)
+        if key not in bufs:
+            bufs[key] = torch.zeros((rows, self.topn * 5 + 1), dtype=torch.float32, device="cuda")
+        return bufs[key]
 
     def propose_distributed_pipelined(self, local_imgs, gather_bufs):
         """Pipelined form for throughput runs (needs ``overlap_nms=True``): the convs of batch k run on the current
@@ -168,18 +198,28 @@ class Proposer(object):
         the same sequence of calls."""
         import torch.distributed as dist
         prev = getattr(self, "_dist_last", None)
-        self.propose(local_imgs)
+        self.propose_async(local_imgs)
         buf, B = self._last, int(self._last_batch)
         slot = getattr(self, "_gather_slot", 0) ^ 1
         self._gather_slot = slot
         out = gather_bufs[slot]
+        live = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if live else 1
+        rows = int(out.shape[0]) // world                                # per-rank rows (>= B: uneven shards are padded)
+        if rows < B:
+            raise ValueError("gather buffer holds %d rows per rank, the local batch has %d" % (rows, B))
         with torch.cuda.stream(self._nms_stream):                        # behind this batch's NMS
-            rec = self.pack_records(buf["boxes"][:B], buf["scores"][:B], buf["valid"][:B])
-            if dist.is_available() and dist.is_initialized():
-                dist.all_gather_into_tensor(out[:rec.shape[0] * dist.get_world_size()], rec)
+            rec = self._record_buffer(slot, rows)
+            self.pack_records(buf["boxes"][:B], buf["scores"][:B], buf["valid"][:B], out=rec)
+            if B < rows:
+                rec[B:].zero_()
+            if live:
+                dist.all_gather_into_tensor(out[:rows * world], rec)
             else:
-                out[:rec.shape[0]].copy_(rec)
-            done = torch.cuda.Event()
+                out[:rows].copy_(rec)
+            if not hasattr(self, "_gather_done"):
+                self._gather_done = [torch.cuda.Event(), torch.cuda.Event()]
+            done = self._gather_done[slot]
             done.record(self._nms_stream)
         self._dist_last = (out, done)
         if prev is None:
@@ -196,20 +236,57 @@ class Proposer(object):
         torch.cuda.current_stream().wait_event(prev[1])
         return prev[0]
 
-    def propose_distributed(self, local_imgs, gather_out=None):
+    def propose_distributed(self, local_imgs, gather_out=None, total=None):
         """Each rank proposes for its slice; one all-gather (RCCL over xGMI when the backend is
-        "nccl") returns every rank's records on every rank: (world*B_local, M*5+1)."""
+        "nccl") returns every rank's records on every rank.
+
+        ``total`` = global number of images when they were split with ``shard_bounds``: the all-gather needs equal
+        sizes, so every rank pads its records to ceil(total / world) rows (zero rows, valid = 0) and the padding is
+        dropped after the gather -> (total, M*5+1) in global image order.  Without ``total`` every rank must hold the
+        same number of images -> (world * B_local, M*5+1)."""
         import torch.distributed as dist
         boxes, scores, valid, _ = self.propose(local_imgs)
-        self.wait()
-        rec = self.pack_records(boxes, scores, valid)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return rec
-        world = dist.get_world_size()
+        B = int(scores.shape[0])
+        live = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if live else 1
+        rows = B if total is None else -(-int(total) // world)
+        if rows < B:
+            raise ValueError("this rank holds %d images but ceil(total / world) = %d" % (B, rows))
+        rec = self._record_buffer(2, rows)
+        self.pack_records(boxes, scores, valid, out=rec)
+        if B < rows:
+            rec[B:].zero_()
+        if world == 1:
+            return rec[:B]
         if gather_out is None:
-            gather_out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-        dist.all_gather_into_tensor(gather_out, rec)
-        return gather_out
+            gather_out = torch.empty((world * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(gather_out[:world * rows], rec)
+        return gather_out[:world * rows] if total is None else compact_gathered(gather_out[:world * rows], total, world)
+
+
+def pad_records(rec, rows):
+    """Pad (B, R) records with zero rows (valid = 0) to ``rows`` rows: equal-size contribution of an uneven shard."""
+    B = int(rec.shape[0])
+    if B == rows:
+        return rec
+    if B > rows:
+        raise ValueError("%d records do not fit %d rows" % (B, rows))
+    out = rec.new_zeros((rows, rec.shape[1]))
+    out[:B] = rec
+    return out
+
+
+def compact_gathered(gathered, total, world):
+    """Drop the padding rows of an all-gather of ``pad_records`` contributions: (world * ceil(total / world), R) ->
+    (total, R) in global image order (rank r contributed the images ``shard_bounds(total, world, r)``)."""
+    rows = -(-int(total) // int(world))
+    if total % world == 0:
+        return gathered[:total]
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(total, world, r)
+        parts.append(gathered[r * rows:r * rows + (hi - lo)])
+    return torch.cat(parts, dim=0)
 
 
 def shard_bounds(total, world, rank):
@@ -228,6 +305,7 @@ def main(argv=None):
     import argparse
     import json
     import os
+    import sys
 
     import numpy as np
 
@@ -257,7 +335,8 @@ def main(argv=None):
         if not os.path.exists(weights):
             raise SystemExit("weights file %r not found (train the reference, or pass --weights / --synthetic-weights)" % weights)
     B = max(1, int(args.batch_size))
-    prop = Proposer(args.backbone, hyper_params=hyper_params, weights=weights, precision=args.precision, max_batch=B)
+    state = {"prop": Proposer(args.backbone, hyper_params=hyper_params, weights=weights, precision=args.precision,
+                              max_batch=B)}
     results = []
     gen = data_utils.custom_data_generator(img_paths, img_size, img_size)
     batch, names = [], []
@@ -267,6 +346,14 @@ def main(argv=None):
             return
         imgs = torch.from_numpy(np.stack(batch)).cuda()
         n = len(batch)
+        prop = state["prop"]
+        prop.forward(imgs)
+        if prop.rpn_model.precision == "f16x3" and prop.rpn_model.status(reset=True)["f16_range"]:
+            # this checkpoint's activations leave the float16 range: same path on bfloat16 halves (float32 range)
+            print("precision f16x3: activations exceed the float16 range with these weights; switching to bf16x3",
+                  file=sys.stderr)
+            state["prop"] = prop = Proposer(args.backbone, hyper_params=hyper_params, weights=weights,
+                                            precision="bf16x3", max_batch=B)
         if args.nms:
             boxes, scores, valid, _ = prop.propose(imgs)
             boxes, scores, valid = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy(), valid[:n].cpu().numpy()

@@ -76,13 +76,23 @@ def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, ran
     if fm * fm * K != A:
         raise ValueError("anchors (%d) do not match feature_map_shape^2 * anchor_count (%d)" % (A, fm * fm * K))
     total_pos, total_neg = int(hyper_params["total_pos_bboxes"]), int(hyper_params["total_neg_bboxes"])
-    maxval = max(2, (total_pos + total_neg) * 10)
-    rp = (L.to_device(random_pos, dtype=torch.int32)[0] if random_pos is not None
-          else torch.randint(1, maxval, (B, A), dtype=torch.int32, device="cuda"))
-    rn = (L.to_device(random_neg, dtype=torch.int32)[0] if random_neg is not None
-          else torch.randint(1, maxval, (B, A), dtype=torch.int32, device="cuda"))
-    if tuple(rp.shape) != (B, A) or tuple(rn.shape) != (B, A):
-        raise ValueError("random_pos / random_neg must be (B, A)")
+
+    def given(r, what):
+        if not isinstance(r, torch.Tensor):
+            import numpy as np
+            r = torch.from_numpy(np.ascontiguousarray(np.asarray(r)))
+        if tuple(r.shape) != (B, A):
+            raise ValueError("random_pos / random_neg must be (B, A)")
+        if r.numel() and int(r.min()) < 1:          # key 0 marks a non-candidate: a priority <= 0 would silently drop it
+            raise ValueError("%s: priorities must be >= 1 (the reference draws them from [1, maxval))" % what)
+        return r.to(device="cuda", dtype=torch.int32).contiguous()
+
+    def draw(maxval):
+        """tf.random.uniform(shape, minval=1, maxval=maxval, dtype=int32) (utils/train_utils.py:59-60); ``maxval``
+        may be a device scalar (no host synchronisation)."""
+        span = (torch.as_tensor(maxval, device="cuda") - 1).clamp(min=1).to(torch.float32)
+        return (torch.rand((B, A), device="cuda") * span).floor().to(torch.int32).clamp_(max=span.to(torch.int32) - 1) + 1
+
     deltas = torch.empty((B, A, 4), dtype=torch.float32, device="cuda")
     labels = torch.empty((B, A), dtype=torch.float32, device="cuda")
     if B > 0:
@@ -92,8 +102,23 @@ def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, ran
         ws_bytes = int(lib.rpn_targets_workspace_bytes(B, A, G))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device="cuda")
         _keep, vptr = L.host_floats(hyper_params["variances"])
-        st = lib.rpn_rpn_targets(L.ptr(a), L.ptr(g), L.ptr(lab), B, A, G, total_pos, total_neg, vptr, L.ptr(rp), L.ptr(rn),
-                                 L.ptr(deltas), L.ptr(labels), L.ptr(ws), ws_bytes, L.stream_ptr())
-        L.check(st, "calculate_rpn_actual_outputs")
+
+        def run(rp, rn):
+            st = lib.rpn_rpn_targets(L.ptr(a), L.ptr(g), L.ptr(lab), B, A, G, total_pos, total_neg, vptr, L.ptr(rp),
+                                     L.ptr(rn), L.ptr(deltas), L.ptr(labels), L.ptr(ws), ws_bytes, L.stream_ptr())
+            L.check(st, "calculate_rpn_actual_outputs")
+
+        # randomly_select_xyz_mask draws with maxval = reduce_max(select_xyz) * 10 PER CALL (:59): total_pos * 10 for the
+        # positives (:119), max over the batch of neg_count * 10 for the negatives (:122-125)
+        rp = given(random_pos, "random_pos") if random_pos is not None else draw(total_pos * 10)
+        if random_neg is not None:
+            run(rp, given(random_neg, "random_neg"))
+        else:
+            # neg_count depends on how many positives survive the subsampling: one pass with placeholder negative
+            # priorities yields the positive labels (they do not depend on random_neg), then the real draw
+            run(rp, torch.ones((B, A), dtype=torch.int32, device="cuda"))
+            pos_count = (labels == 1).sum(dim=1)
+            neg_maxval = ((total_pos + total_neg) - pos_count).max() * 10
+            run(rp, draw(neg_maxval))
     labels = labels.view(B, fm, fm, K)
     return L.from_device(deltas, was_np), L.from_device(labels, was_np)
