@@ -119,6 +119,36 @@ def test_model_forward_small(backbone, img, B):
     assert np.abs(reg - ref64[0]).max() <= 4 * np.abs(ref32[0] - ref64[0]).max() + 1e-6
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("img,B", [(64, 2), (125, 1), (150, 3), (224, 2), (500, 1)])
+def test_mobilenet_v2_fused_blocks(img, B, precision):
+    """The production MobileNetV2 graph: stem + expanded_conv and every inverted-residual block run as ONE launch each
+    (mnv2_block_kernels.hip; <= 16 launches per forward).  Held to the float64 oracle (1e-4) and to the layer-by-layer
+    path (keep_activations=True: the unfused kernels) on the same weights -- odd sizes exercise the stride-2
+    correct_pad cases (125 -> 63 -> 32) and ragged 4 x 8 tiles."""
+    hp = bo.get_hyper_params("mobilenet_v2", img_size=img, feature_map_shape=None)
+    weights = synthetic_weights("mobilenet_v2", hp, seed=7)
+    imgs = np.random.RandomState(3).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+    fused = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=B)
+    fused.set_weights(weights)
+    kernels = [op["kernel"] for op in fused.ops()]
+    assert sum(k.startswith("ir_block") for k in kernels) == 13 and len(kernels) <= 16, kernels
+    reg, cls = fused.predict_on_batch(imgs)
+    ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64, return_features=True)
+    feat = fused.get_activation(fused.tap_layer, batch=B).cpu().numpy()
+    fscale = max(1.0, float(np.abs(ref[2]).max()))
+    assert np.abs(feat - ref[2]).max() <= 5e-5 * fscale
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
+    layerwise = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=B, keep_activations=True)
+    layerwise.set_weights(weights)
+    assert not any(op["kernel"].startswith("ir_block") for op in layerwise.ops())
+    reg_u, cls_u = layerwise.predict_on_batch(imgs)
+    assert np.abs(reg - reg_u).max() <= 5e-5 and np.abs(cls - cls_u).max() <= 5e-5
+    # batch invariance of the fused path: image 0 alone, bit for bit
+    r1, c1 = fused.predict_on_batch(imgs[:1])
+    assert np.array_equal(r1[0], reg[0]) and np.array_equal(c1[0], cls[0])
+
+
 def test_model_layerwise_vgg16():
     """Every intermediate activation against the float64 oracle (catches an O(1)-wrong layer that a
     whole-model tolerance could hide)."""

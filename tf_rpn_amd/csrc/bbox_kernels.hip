@@ -11,6 +11,7 @@
 #include "rpn_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace rpn {
 
@@ -123,6 +124,68 @@ iou_map_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, cons
             *reinterpret_cast<float4 *>(outb + e0) = make_float4(r[0], r[1], r[2], r[3]);
         } else {
             for (int j = 0; j < 4 && e0 + j < per_img; ++j) outb[e0 + j] = r[j];
+        }
+    }
+}
+
+// IoU map, chunked form (the one that runs at BASELINE sizes).  A workgroup owns TA consecutive anchors of one image
+// = one contiguous run of TA*G output floats; TA % 4 == 0 and A*G % 4 == 0 make every run 16-byte aligned.  The
+// image's gt boxes and their areas are staged in LDS once per workgroup; a lane produces 4 consecutive floats per
+// iteration (one 16-byte store, consecutive lanes -> consecutive 16 bytes) and walks its (anchor, gt) position
+// incrementally: ONE integer division per lane per launch instead of one per vector, no gt-area recomputation, no
+// data-dependent reload branch (both candidate anchor rows of a vector are loaded, L1 hits, and selected per float).
+// Operation order per pair is iou_map_pair's (utils/bbox_utils.py:138-150): bit-exact with the generic kernel.
+// HBM-write-bound: 4*B*A*G bytes; NT = nontemporal stores (the map is never re-read by this kernel).
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+template <bool NT>
+__global__ void __launch_bounds__(kThreads)
+iou_map_chunk_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt, int G,
+                     int TA, float *__restrict__ out)
+{
+    extern __shared__ float4 iou_lds[];                       // G gt boxes, then G gt areas
+    float4 *gbox = iou_lds;
+    float *garea = reinterpret_cast<float *>(iou_lds + G);
+    const int b = blockIdx.y;
+    const int a0 = blockIdx.x * TA;
+    const int na = min(TA, A - a0);
+    const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
+    for (int g = threadIdx.x; g < G; g += kThreads) {
+        const Box gg = load_box(gtb + 4 * g);
+        gbox[g] = make_float4(gg.y1, gg.x1, gg.y2, gg.x2);
+        garea[g] = box_area_plain(gg);                        // :138
+    }
+    __syncthreads();
+    const float *__restrict__ bbb = bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a0;
+    float *__restrict__ outb = out + ((size_t)b * A + a0) * G;
+    const int nvec = (na * G) >> 2;                           // exact: a0*G and A*G are multiples of 4
+    int v = threadIdx.x;
+    int a = (4 * v) / G;                                      // the only integer division
+    int g = 4 * v - a * G;
+    const int step_a = (4 * kThreads) / G, step_g = (4 * kThreads) - step_a * G;
+    for (; v < nvec; v += kThreads) {
+        const Box b0 = load_box(bbb + 4 * a);
+        const Box b1 = load_box(bbb + 4 * min(a + 1, na - 1));
+        const float area0 = box_area_plain(b0), area1 = box_area_plain(b1);      // :139
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool next = g + j >= G;                     // G >= 4: at most one anchor boundary inside a vector
+            const int gj = next ? g + j - G : g + j;
+            const float4 q = gbox[gj];
+            const Box gg{q.x, q.y, q.z, q.w};
+            const Box bb{next ? b1.y1 : b0.y1, next ? b1.x1 : b0.x1, next ? b1.y2 : b0.y2, next ? b1.x2 : b0.x2};
+            r[j] = iou_map_pair(bb, next ? area1 : area0, gg, garea[gj]);
+        }
+        f32x4_t val = {r[0], r[1], r[2], r[3]};
+        f32x4_t *dst = reinterpret_cast<f32x4_t *>(outb + 4 * (size_t)v);
+        if constexpr (NT) __builtin_nontemporal_store(val, dst);
+        else *dst = val;
+        a += step_a;
+        g += step_g;
+        if (g >= G) {
+            g -= G;
+            ++a;
         }
     }
 }
@@ -272,8 +335,25 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     RPN_REQUIRE_DEVICE();
     RPN_REQUIRE((long long)A * G < (1ll << 31) && B <= 65535, "rpn_iou_map: A*G or B too large");
     const int per_img = A * G;
-    hipLaunchKernelGGL(iou_map_kernel, dim3(grid_for((per_img + 3) / 4), B), dim3(kThreads), 0, as_stream(stream),
-                       d_bboxes, bboxes_batched, A, d_gt, G, (per_img % 4 == 0) ? 1 : 0, d_iou);
+    static const int chunked = getenv("RPN_IOU_CHUNKED") ? atoi(getenv("RPN_IOU_CHUNKED")) : 1;
+    static const int nt = getenv("RPN_IOU_NT") ? atoi(getenv("RPN_IOU_NT")) : 1;
+    static const int ta_floats = getenv("RPN_IOU_CHUNK_FLOATS") ? atoi(getenv("RPN_IOU_CHUNK_FLOATS")) : 4096;
+    if (chunked && per_img % 4 == 0 && G >= 4 && G <= 2048) {
+        int TA = (ta_floats / G + 3) & ~3;                    // anchors per workgroup: a multiple of 4, ~4096 floats
+        if (TA < 4) TA = 4;
+        const int chunks = (A + TA - 1) / TA;
+        RPN_REQUIRE(chunks <= 0x7fffffff / 2, "rpn_iou_map: too many chunks");
+        const size_t lds = (size_t)G * 20;
+        if (nt)
+            hipLaunchKernelGGL(iou_map_chunk_kernel<true>, dim3(chunks, B), dim3(kThreads), lds, as_stream(stream),
+                               d_bboxes, bboxes_batched, A, d_gt, G, TA, d_iou);
+        else
+            hipLaunchKernelGGL(iou_map_chunk_kernel<false>, dim3(chunks, B), dim3(kThreads), lds, as_stream(stream),
+                               d_bboxes, bboxes_batched, A, d_gt, G, TA, d_iou);
+    } else {
+        hipLaunchKernelGGL(iou_map_kernel, dim3(grid_for((per_img + 3) / 4), B), dim3(kThreads), 0, as_stream(stream),
+                           d_bboxes, bboxes_batched, A, d_gt, G, (per_img % 4 == 0) ? 1 : 0, d_iou);
+    }
     RPN_CHECK_LAUNCH();
     return RPN_OK;
 }

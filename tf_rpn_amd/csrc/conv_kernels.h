@@ -54,6 +54,15 @@ hipError_t launch_dwconv3x3(const float *x, int B, int H, int W, int C, const fl
                             int stride, int pad_t, int pad_l, int OH, int OW, int act, float *out,
                             hipStream_t stream);
 
+// ---- MobileNetV2 inverted-residual block in one launch (mnv2_block_kernels.hip) --------------------------------
+// expand 1x1 + BN + ReLU6 -> depthwise 3x3 + BN + ReLU6 -> project 1x1 + BN (+ residual); `stem`: Conv1 (3x3 s2 from the
+// image) takes the place of the expand stage (stem + expanded_conv block).  Weights (BatchNorm folded): we [KP][cexp]
+// (KP = cin; stem: 28 = 27 im2col rows + a zero row), wd [9][cexp], wp [cexp][round_up(cout, 16)] + their biases.
+bool ir_block_supported(int cin, int cexp, int cout, int stride, bool residual);
+hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
+                           bool stem, int pad, int OH, int OW, const float *we, const float *be, const float *wd,
+                           const float *bd, const float *wp, const float *bp, float *out, hipStream_t s);
+
 // Device word into which the split-format writers launched from THIS host thread flag float16 range violations
 // (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.
 void set_range_status(unsigned *p);

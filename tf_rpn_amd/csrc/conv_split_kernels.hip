@@ -128,7 +128,10 @@ __device__ __forceinline__ uint4 split_piece(const float (&x)[8], bool lo, unsig
         if (status && !lo) {
             const float m = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))),
                                   fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7]))));
-            if (!(m <= 65504.0f)) atomicOr(status, 1u /* RPN_STATUS_F16_RANGE */);
+            float nan_probe = 0.0f;                           // fmaxf drops NaNs: x * 0 accumulates to NaN for any NaN / inf
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nan_probe = fmaf(x[k], 0.0f, nan_probe);
+            if (!(m <= 65504.0f) || nan_probe != 0.0f) atomicOr(status, 1u /* RPN_STATUS_F16_RANGE */);
         }
     }
 #pragma unroll
@@ -1588,8 +1591,8 @@ int split_weight_shift(const float *hwio, size_t count, bool f16)
     int e = 0;
     (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
     int s = 12 - e;                             // largest weight lands in [2^11, 2^12): far from fp16 overflow
-    if (s < 0) s = 0;
-    if (s > 24) s = 24;
+    if (s < -100) s = -100;                     // negative: weights beyond the float16 range are scaled DOWN (their hi
+    if (s > 24) s = 24;                         // halves would be inf), the epilogue's 2^-s restores the magnitude
     return s;
 }
 

@@ -22,7 +22,7 @@ namespace rpn {
 
 constexpr float kBnEps = 1e-3f;
 
-enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3, OP_TOSPLIT = 4 };
+enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3, OP_TOSPLIT = 4, OP_IRBLOCK = 5 };
 
 struct Tensor {
     std::string name;
@@ -59,6 +59,12 @@ struct Op {
     bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
+    // OP_IRBLOCK (one fused MobileNetV2 block; Cin / Cout = block input / output channels, stride = the depthwise's):
+    int cexp = 0;                      // expanded channels
+    bool ir_stem = false;              // Conv1 + expanded_conv block: the expand stage is the 3x3 s2 stem conv
+    bool ir_res = false;               // + block input
+    int ir_pad = 0;                    // top/left padding of the depthwise (stem: of Conv1)
+    size_t ir_off[6] = {0, 0, 0, 0, 0, 0};   // we, be, wd, bd, wp, bp (floats into the weight blob)
 };
 
 }  // namespace rpn
@@ -239,6 +245,30 @@ static void build_vgg16(rpn_model *m)
     add_head(m, t);
 }
 
+// One fused inverted-residual block (mnv2_block_kernels.hip).  Parameters keep their Keras names, in the order
+// expand (or Conv1), depthwise, project -- set_layer addresses them by that position.
+static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, int cout, int stride, int pad, bool res,
+                       bool stem, int OH, int OW, const std::string (&pn)[3], const std::string (&bn)[3])
+{
+    const Tensor ti = m->tensors[in];
+    Op op;
+    op.kind = OP_IRBLOCK; op.name = name; op.in = in;
+    op.Cin = ti.C; op.Cout = cout; op.cexp = cexp; op.stride = stride; op.ir_pad = pad; op.ir_res = res; op.ir_stem = stem;
+    op.R = op.S = 3;
+    op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = ACT_LINEAR;
+    op.out = add_tensor(m, name, OH, OW, cout);
+    m->ops.push_back(op);
+    const int oi = (int)m->ops.size() - 1;
+    // expanded-tensor size (the depthwise's input grid)
+    const int DH = stem ? (ti.H + pad + 1 - 3) / 2 + 1 : ti.H, DW = stem ? (ti.W + pad + 1 - 3) / 2 + 1 : ti.W;
+    if (stem) add_param(m, oi, pn[0], bn[0], 1, 3, 3, 3, cexp);
+    else add_param(m, oi, pn[0], bn[0], 1, 1, 1, ti.C, cexp);
+    add_param(m, oi, pn[1], bn[1], 2, 3, 3, cexp, cexp);
+    add_param(m, oi, pn[2], bn[2], 1, 1, 1, cexp, cout);
+    m->flops += 2.0 * DH * DW * cexp * (stem ? 27 : ti.C) + 2.0 * OH * OW * cexp * 9 + 2.0 * OH * OW * cexp * cout;
+    return op.out;
+}
+
 // keras_applications.correct_pad for a 3x3 kernel: (before, after) per spatial dim
 static void correct_pad(int n, int *before, int *after)
 {
@@ -250,23 +280,49 @@ static void correct_pad(int n, int *before, int *after)
 static void build_mobilenet_v2(rpn_model *m)
 {
     int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
-    {   // Conv1_pad + Conv1 (3x3 s2 valid, no bias) + bn_Conv1 + ReLU6
+    // One launch per inverted-residual block unless every intermediate activation must exist (keep_all) or
+    // RPN_MN_FUSE=0 (the unfused layer-by-layer path: the cross-check of the fused kernels in the tests).
+    const bool fuse = !m->keep_all && !(getenv("RPN_MN_FUSE") && atoi(getenv("RPN_MN_FUSE")) == 0);
+    const int blocks[13][4] = {{32, 1, 16, 1}, {16, 6, 24, 2}, {24, 6, 24, 1}, {24, 6, 32, 2}, {32, 6, 32, 1},
+                               {32, 6, 32, 1}, {32, 6, 64, 2}, {64, 6, 64, 1}, {64, 6, 64, 1}, {64, 6, 64, 1},
+                               {64, 6, 96, 1}, {96, 6, 96, 1}, {96, 6, 96, 1}};
+    int first_block = 0;
+    if (fuse) {     // Conv1_pad + Conv1 + bn_Conv1 + ReLU6 + expanded_conv (depthwise, project): one launch
+        const Tensor ti = m->tensors[t];
+        int pb, pa;
+        correct_pad(ti.H, &pb, &pa);
+        const int OH = (ti.H + pb + pa - 3) / 2 + 1;
+        const std::string pn[3] = {"Conv1", "expanded_conv_depthwise", "expanded_conv_project"};
+        const std::string bn[3] = {"bn_Conv1", "expanded_conv_depthwise_BN", "expanded_conv_project_BN"};
+        t = add_irblock(m, "expanded_conv_project", t, 32, 16, 1, pb, false, true, OH, OH, pn, bn);
+        first_block = 1;
+    } else {   // Conv1_pad + Conv1 (3x3 s2 valid, no bias) + bn_Conv1 + ReLU6
         const Tensor ti = m->tensors[t];
         int pb, pa;
         correct_pad(ti.H, &pb, &pa);
         const int OH = (ti.H + pb + pa - 3) / 2 + 1;
         t = add_conv(m, "Conv1", "bn_Conv1", t, 32, 3, 2, pb, pb, OH, OH, ACT_RELU6);
     }
-    const int blocks[13][4] = {{32, 1, 16, 1}, {16, 6, 24, 2}, {24, 6, 24, 1}, {24, 6, 32, 2}, {32, 6, 32, 1},
-                               {32, 6, 32, 1}, {32, 6, 64, 2}, {64, 6, 64, 1}, {64, 6, 64, 1}, {64, 6, 64, 1},
-                               {64, 6, 96, 1}, {96, 6, 96, 1}, {96, 6, 96, 1}};
-    for (int bid = 0; bid < 13; ++bid) {
+    for (int bid = first_block; bid < 13; ++bid) {
         const int cin = blocks[bid][0], expand = blocks[bid][1], cout = blocks[bid][2], stride = blocks[bid][3];
         char pre[32];
         if (bid == 0) snprintf(pre, sizeof pre, "expanded_conv_");
         else snprintf(pre, sizeof pre, "block_%d_", bid);
         const std::string prefix = pre;
         const int inp = t;
+        if (fuse && bid != 0 && ir_block_supported(cin, cin * expand, cout, stride, cin == cout && stride == 1)) {
+            const Tensor ti = m->tensors[t];
+            int pb = 1, pa = 1, OH = ti.H;
+            if (stride == 2) {
+                correct_pad(ti.H, &pb, &pa);
+                OH = (ti.H + pb + pa - 3) / 2 + 1;
+            }
+            const std::string pn[3] = {prefix + "expand", prefix + "depthwise", prefix + "project"};
+            const std::string bn[3] = {prefix + "expand_BN", prefix + "depthwise_BN", prefix + "project_BN"};
+            t = add_irblock(m, prefix + "project", t, cin * expand, cout, stride, pb, cin == cout && stride == 1, false,
+                            OH, OH, pn, bn);
+            continue;
+        }
         if (bid != 0) {
             const Tensor ti = m->tensors[t];
             t = add_conv(m, prefix + "expand", prefix + "expand_BN", t, cin * expand, 1, 1, 0, 0, ti.H, ti.W,
@@ -372,6 +428,15 @@ static void plan_weights(rpn_model *m)
             off += ((size_t)9 * op.Cin + 63) & ~(size_t)63;
             op.b_off = off;
             off += ((size_t)op.Cin + 63) & ~(size_t)63;
+        } else if (op.kind == OP_IRBLOCK) {
+            const size_t kp = op.ir_stem ? 28 : (size_t)op.Cin, coutp = ((size_t)op.Cout + 15) / 16 * 16;
+            const size_t sizes[6] = {kp * op.cexp, (size_t)op.cexp, (size_t)9 * op.cexp, (size_t)op.cexp,
+                                     (size_t)op.cexp * coutp, coutp};
+            op.w_off = off;
+            for (int i = 0; i < 6; ++i) {
+                op.ir_off[i] = off;
+                off += (sizes[i] + 63) & ~(size_t)63;
+            }
         }
     }
     m->weight_floats = off;
@@ -478,9 +543,16 @@ extern "C" int rpn_model_memory_bytes(const rpn_model *m, size_t *weights, size_
 extern "C" int rpn_model_keep_activations(rpn_model *m, int keep)
 {
     RPN_REQUIRE(m, "rpn_model_keep_activations: null model");
-    RPN_REQUIRE(!m->d_arena, "rpn_model_keep_activations: arena already allocated");
+    RPN_REQUIRE(!m->d_arena && !m->d_weights, "rpn_model_keep_activations: must precede the first set_layer / forward");
     m->keep_all = keep != 0;
+    // the graph itself depends on it (MobileNetV2 blocks are fused into one launch only when their intermediate
+    // activations need not exist): rebuild
+    m->tensors.clear(); m->ops.clear(); m->params.clear(); m->flops = 0.0;
+    if (m->backbone == RPN_BACKBONE_VGG16) build_vgg16(m);
+    else build_mobilenet_v2(m);
+    m->F = m->tensors[m->feat_tensor].H;
     plan_arena(m);
+    plan_weights(m);
     return RPN_OK;
 }
 
@@ -515,7 +587,34 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
     if (bias)
         for (int n = 0; n < p.Cout; ++n) shift[n] += has_bn ? bias[n] * scale[n] : bias[n];
 
-    if (p.kind == 2) {
+    if (op.kind == OP_IRBLOCK) {
+        // role = position among the op's parameters: 0 expand / Conv1, 1 depthwise, 2 project.  Zero padding (the stem's
+        // 28th im2col row, projection columns beyond Cout) comes from the memset of the weight blob.
+        int role = 0;
+        while (role < 3 && op.params[(size_t)role] != pi) ++role;
+        std::vector<float> w;
+        size_t w_at, b_at, nb;
+        if (role == 0) {                                   // (R,S,Cin,Cexp) row-major == [K][Cexp]
+            const size_t rows = op.ir_stem ? 27 : (size_t)p.Cin;
+            w.resize(rows * p.Cout);
+            for (size_t k = 0; k < rows; ++k)
+                for (int n = 0; n < p.Cout; ++n) w[k * p.Cout + n] = kernel[k * p.Cout + n] * scale[n];
+            w_at = op.ir_off[0]; b_at = op.ir_off[1]; nb = (size_t)p.Cout;
+        } else if (role == 1) {                            // (3,3,C,1) == [9][C]
+            w.resize((size_t)9 * p.Cin);
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < p.Cin; ++c) w[(size_t)t * p.Cin + c] = kernel[(size_t)t * p.Cin + c] * scale[c];
+            w_at = op.ir_off[2]; b_at = op.ir_off[3]; nb = (size_t)p.Cin;
+        } else {                                           // (1,1,Cexp,Cout) -> [Cexp][coutp]
+            const size_t coutp = ((size_t)p.Cout + 15) / 16 * 16;
+            w.assign((size_t)p.Cin * coutp, 0.0f);
+            for (int k = 0; k < p.Cin; ++k)
+                for (int n = 0; n < p.Cout; ++n) w[(size_t)k * coutp + n] = kernel[(size_t)k * p.Cout + n] * scale[n];
+            w_at = op.ir_off[4]; b_at = op.ir_off[5]; nb = (size_t)p.Cout;
+        }
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + w_at, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + b_at, shift.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+    } else if (p.kind == 2) {
         std::vector<float> w((size_t)9 * p.Cin);
         for (int t = 0; t < 9; ++t)
             for (int c = 0; c < p.Cin; ++c) w[(size_t)t * p.Cin + c] = kernel[(size_t)t * p.Cin + c] * scale[c];
@@ -673,6 +772,11 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 a.out2 = nullptr; a.ld2 = 0; a.act2 = ACT_LINEAR;
             }
             e = launch_conv_f32(a, s);
+        } else if (op.kind == OP_IRBLOCK) {
+            const float *wb = m->d_weights;
+            e = launch_ir_block(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_stem, op.ir_pad,
+                                op.OH, op.OW, wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
+                                wb + op.ir_off[4], wb + op.ir_off[5], tensor_ptr(m, op.out, d_imgs), s);
         } else if (op.kind == OP_DWCONV) {
             e = launch_dwconv3x3(x, B, op.H, op.W, op.Cin, m->d_weights + op.w_off, m->d_weights + op.b_off,
                                  op.stride, op.pad_t, op.pad_l, op.OH, op.OW, op.act, tensor_ptr(m, op.out, d_imgs), s);
@@ -776,6 +880,15 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
                  op.ps.generic ? ",generic" : "");
         k = kname32;
+    } else if (op.kind == OP_IRBLOCK) {
+        const int DH = op.ir_stem ? (op.H + op.ir_pad + 1 - 3) / 2 + 1 : op.H, DW = op.ir_stem ? (op.W + op.ir_pad + 1 - 3) / 2 + 1 : op.W;
+        const double kin = op.ir_stem ? 27.0 : (double)op.Cin;
+        fl = 2.0 * DH * DW * op.cexp * kin + 2.0 * op.OH * op.OW * op.cexp * 9.0 + 2.0 * op.OH * op.OW * (double)op.cexp * op.Cout;
+        by = in_b + out_b + 4.0 * (kin * op.cexp + 10.0 * op.cexp + (double)op.cexp * op.Cout + op.Cout);
+        static thread_local char kir[64];
+        if (op.ir_stem) snprintf(kir, sizeof kir, "ir_block<stem,32,16,s1>");
+        else snprintf(kir, sizeof kir, "ir_block<%d,%d,%d,s%d%s>", op.Cin, op.cexp, op.Cout, op.stride, op.ir_res ? ",res" : "");
+        k = kir;
     } else if (op.kind == OP_DWCONV) {
         fl = 2.0 * op.OH * op.OW * op.Cin * 9;
         by = in_b + out_b;
