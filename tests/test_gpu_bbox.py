@@ -117,6 +117,20 @@ def test_iou_map_golden_batched_and_invariants(golden_dir):
     assert bbox_utils.generate_iou_map(b[0], np.zeros((2, 0, 4), np.float32)).shape == (2, 50, 0)
 
 
+@pytest.mark.parametrize("B,A,G,batched", [(3, 1001, 7, True), (5, 1027, 5, False), (2, 4099, 4, True), (7, 600, 9, True),
+                                              (64, 8649, 42, False), (1, 61440, 42, False)])
+def test_iou_map_chunked_kernel_alignment_cases(B, A, G, batched):
+    """The chunked IoU kernel cuts the flat (B, A, G) map into 16-byte-aligned runs of 4096 floats: image slabs that are
+    not multiples of 4 floats (runs straddle two images), G = 4 (every vector crosses an anchor), a total that is not a
+    multiple of 4 (scalar tail), batched and shared bboxes -- all bit-exact against the C restatement."""
+    rng = np.random.RandomState(B * 1000 + A)
+    boxes = cases.random_boxes(rng, (B, A) if batched else (A,))
+    gt = cases.gt_boxes(rng, B, G=G, n_valid=max(1, G // 2))
+    got = bbox_utils.generate_iou_map(boxes, gt)
+    want = co.iou_map(boxes, gt) if not batched else np.stack([co.iou_map(boxes[b], gt[b:b + 1])[0] for b in range(B)])
+    assert got.shape == (B, A, G) and np.array_equal(got, want)
+
+
 # ---- NMS: integer outputs bit-exact -------------------------------------------------------------
 def _check_nms(boxes, scores, **kw):
     ref = co.combined_nms(boxes, scores, **kw)

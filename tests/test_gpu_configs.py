@@ -154,32 +154,32 @@ def test_split_precision_tiny_inputs_subnormal_halves(precision):
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_mobilenet_v2_wide_batchnorm_scales(precision):
-    """BatchNorm scales gamma / sqrt(var + 1e-3) spanning 1e-2 ... 50 (a Keras checkpoint with small moving variances
+    """bn_Conv1 scales gamma / sqrt(var + 1e-3) spanning 1e-2 ... 50 (a Keras checkpoint with small moving variances
     gives ~31 already): the power-of-two pre-scale of the float16 weights is derived from the FOLDED kernel, so the hi
-    halves stay finite and the outputs stay within the bound."""
+    halves stay finite and the outputs stay within the bound -- on the layer-by-layer path (where Conv1 runs on the
+    split-precision MFMA kernel under f16x3) and on the fused-block path."""
     hp = bo.get_hyper_params("mobilenet_v2", img_size=96, feature_map_shape=6)
     weights = synthetic_weights("mobilenet_v2", hp, seed=5)
     rng = np.random.RandomState(9)
-    for name, w in weights.items():
-        if "gamma" in w:
-            n = w["gamma"].shape[0]
-            scale = np.exp(rng.uniform(np.log(1e-2), np.log(50.0), size=n))
-            w["var"] = rng.uniform(1e-4, 2e-3, size=n).astype(np.float32)          # tiny moving variances
-            w["gamma"] = (scale * np.sqrt(w["var"] + 1e-3)).astype(np.float32)
-    # keep the signal alive through ReLU6 saturation: only the stem and the depthwise BNs get the wide scales, the
-    # project BNs (linear, unbounded) a narrow one
-    for name, w in weights.items():
-        if "gamma" in w and "project" in name:
-            w["gamma"] = (np.sqrt(w["var"] + 1e-3) * rng.uniform(0.5, 1.5, size=w["gamma"].shape[0])).astype(np.float32)
+    # bn_Conv1 is the BatchNorm that is folded into a split-precision (float16-halves) kernel under f16x3.  Only it
+    # gets the wide scales: a gain of 50 on EVERY layer would turn the network into a chaotic map in which float32 and
+    # float64 arithmetic part ways by construction (rounding errors amplified 50x per layer), which tests nothing.
+    w = weights["bn_Conv1"]
+    n = w["gamma"].shape[0]
+    scale = np.exp(rng.uniform(np.log(1e-2), np.log(50.0), size=n))
+    scale[:2] = [1e-2, 50.0]
+    w["var"] = rng.uniform(1e-4, 2e-3, size=n).astype(np.float32)                  # tiny moving variances
+    w["gamma"] = (scale * np.sqrt(w["var"] + 1e-3)).astype(np.float32)
     imgs = np.random.RandomState(2).uniform(0, 1, size=(2, 96, 96, 3)).astype(np.float32)
     ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64)
-    model = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=2)
-    model.set_weights(weights)
-    reg, cls = model.predict_on_batch(imgs)
-    assert np.isfinite(reg).all() and np.isfinite(cls).all()
-    scale = max(1.0, float(np.abs(ref[0]).max()))
-    assert np.abs(reg - ref[0]).max() <= 1e-4 * scale and np.abs(cls - ref[1]).max() <= 1e-4
-    assert not model.status()["f16_range"]
+    for keep in (True, False):                  # layer by layer (Conv1 on its own kernel) / fused blocks
+        model = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=2, keep_activations=keep)
+        model.set_weights(weights)
+        reg, cls = model.predict_on_batch(imgs)
+        assert np.isfinite(reg).all() and np.isfinite(cls).all()
+        scale = max(1.0, float(np.abs(ref[0]).max()))
+        assert np.abs(reg - ref[0]).max() <= 1e-4 * scale and np.abs(cls - ref[1]).max() <= 1e-4, keep
+        assert not model.status()["f16_range"]
 
 
 def test_hot_path_rejects_malformed_batches():

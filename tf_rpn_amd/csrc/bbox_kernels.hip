@@ -128,57 +128,67 @@ iou_map_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, cons
     }
 }
 
-// IoU map, chunked form (the one that runs at BASELINE sizes).  A workgroup owns TA consecutive anchors of one image
-// = one contiguous run of TA*G output floats; TA % 4 == 0 and A*G % 4 == 0 make every run 16-byte aligned.  The
-// image's gt boxes and their areas are staged in LDS once per workgroup; a lane produces 4 consecutive floats per
-// iteration (one 16-byte store, consecutive lanes -> consecutive 16 bytes) and walks its (anchor, gt) position
-// incrementally: ONE integer division per lane per launch instead of one per vector, no gt-area recomputation, no
-// data-dependent reload branch (both candidate anchor rows of a vector are loaded, L1 hits, and selected per float).
-// Operation order per pair is iou_map_pair's (utils/bbox_utils.py:138-150): bit-exact with the generic kernel.
-// HBM-write-bound: 4*B*A*G bytes; NT = nontemporal stores (the map is never re-read by this kernel).
+// IoU map, chunked form (the one that runs at BASELINE sizes).  The (B, A, G) output is one flat array; a workgroup
+// owns one 16-byte-aligned run of kIouChunk floats of it (image slabs of A*G floats need not be 16-byte aligned --
+// VGG16's 8649 * 42 is not a multiple of 4 -- so a run may straddle two images; it never spans three because
+// kIouChunk <= A*G is required).  The gt boxes and areas of the (up to) two images are staged in LDS once per
+// workgroup; a lane produces 4 consecutive floats per iteration (one 16-byte store, consecutive lanes -> consecutive
+// 16 bytes) and walks its (image, anchor, gt) position incrementally: two integer divisions per lane per launch
+// instead of one per vector, no gt-area recomputation, no data-dependent reload branch (both candidate anchor rows of
+// a vector are loaded -- L1 hits -- and selected per float).  Operation order per pair is iou_map_pair's
+// (utils/bbox_utils.py:138-150): bit-exact with the generic kernel.  HBM-write-bound: 4*B*A*G bytes;
+// NT = nontemporal stores (the map is never re-read by this kernel).
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
+constexpr int kIouChunk = 4096;
 
 template <bool NT>
 __global__ void __launch_bounds__(kThreads)
 iou_map_chunk_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt, int G,
-                     int TA, float *__restrict__ out)
+                     int B, long long total, float *__restrict__ out)
 {
-    extern __shared__ float4 iou_lds[];                       // G gt boxes, then G gt areas
+    extern __shared__ float4 iou_lds[];                       // 2 x G gt boxes, then 2 x G gt areas
     float4 *gbox = iou_lds;
-    float *garea = reinterpret_cast<float *>(iou_lds + G);
-    const int b = blockIdx.y;
-    const int a0 = blockIdx.x * TA;
-    const int na = min(TA, A - a0);
-    const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
-    for (int g = threadIdx.x; g < G; g += kThreads) {
-        const Box gg = load_box(gtb + 4 * g);
-        gbox[g] = make_float4(gg.y1, gg.x1, gg.y2, gg.x2);
-        garea[g] = box_area_plain(gg);                        // :138
+    float *garea = reinterpret_cast<float *>(iou_lds + 2 * G);
+    const long long f0 = (long long)blockIdx.x * kIouChunk;   // first float of this workgroup's run
+    const int per_img = A * G;
+    const int b0 = (int)(f0 / per_img);                       // uniform: scalar division
+    for (int i = threadIdx.x; i < 2 * G; i += kThreads) {
+        const int bi = min(b0 + (i >= G ? 1 : 0), B - 1), g = i >= G ? i - G : i;
+        const Box gg = load_box(gt + 4 * ((size_t)bi * G + g));
+        gbox[i] = make_float4(gg.y1, gg.x1, gg.y2, gg.x2);
+        garea[i] = box_area_plain(gg);                        // :138
     }
     __syncthreads();
-    const float *__restrict__ bbb = bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a0;
-    float *__restrict__ outb = out + ((size_t)b * A + a0) * G;
-    const int nvec = (na * G) >> 2;                           // exact: a0*G and A*G are multiples of 4
+    const long long left = total - f0;
+    const int nvec = (int)((left < kIouChunk ? left : kIouChunk) >> 2);          // whole vectors (the tail is scalar)
     int v = threadIdx.x;
-    int a = (4 * v) / G;                                      // the only integer division
-    int g = 4 * v - a * G;
+    const int r0 = (int)(f0 - (long long)b0 * per_img) + 4 * v;   // offset inside image b0 (may run into image b0 + 1)
+    int sel = r0 >= per_img ? 1 : 0;                          // which of the two staged images
+    int r = r0 - sel * per_img;
+    int a = r / G;                                            // the only per-lane integer division
+    int g = r - a * G;
     const int step_a = (4 * kThreads) / G, step_g = (4 * kThreads) - step_a * G;
+    const size_t bstride = bboxes_batched ? 4 * (size_t)A : 0;
     for (; v < nvec; v += kThreads) {
-        const Box b0 = load_box(bbb + 4 * a);
-        const Box b1 = load_box(bbb + 4 * min(a + 1, na - 1));
-        const float area0 = box_area_plain(b0), area1 = box_area_plain(b1);      // :139
-        float r[4];
+        // the vector's first float is (image b0 + sel, anchor a, gt g); a later float may belong to the next anchor,
+        // which may be anchor 0 of the next image
+        const bool wrap = a + 1 == A;
+        const int a1 = wrap ? 0 : a + 1, sel1 = wrap ? min(sel + 1, 1) : sel;
+        const Box bx0 = load_box(bboxes + bstride * min(b0 + sel, B - 1) + 4 * (size_t)a);
+        const Box bx1 = load_box(bboxes + bstride * min(b0 + sel1, B - 1) + 4 * (size_t)a1);
+        const float area0 = box_area_plain(bx0), area1 = box_area_plain(bx1);    // :139
+        float rr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool next = g + j >= G;                     // G >= 4: at most one anchor boundary inside a vector
-            const int gj = next ? g + j - G : g + j;
+            const int gj = (next ? g + j - G : g + j) + (next ? sel1 : sel) * G;
             const float4 q = gbox[gj];
             const Box gg{q.x, q.y, q.z, q.w};
-            const Box bb{next ? b1.y1 : b0.y1, next ? b1.x1 : b0.x1, next ? b1.y2 : b0.y2, next ? b1.x2 : b0.x2};
-            r[j] = iou_map_pair(bb, next ? area1 : area0, gg, garea[gj]);
+            const Box bb{next ? bx1.y1 : bx0.y1, next ? bx1.x1 : bx0.x1, next ? bx1.y2 : bx0.y2, next ? bx1.x2 : bx0.x2};
+            rr[j] = iou_map_pair(bb, next ? area1 : area0, gg, garea[gj]);
         }
-        f32x4_t val = {r[0], r[1], r[2], r[3]};
-        f32x4_t *dst = reinterpret_cast<f32x4_t *>(outb + 4 * (size_t)v);
+        f32x4_t val = {rr[0], rr[1], rr[2], rr[3]};
+        f32x4_t *dst = reinterpret_cast<f32x4_t *>(out + f0 + 4 * (long long)v);
         if constexpr (NT) __builtin_nontemporal_store(val, dst);
         else *dst = val;
         a += step_a;
@@ -187,6 +197,19 @@ iou_map_chunk_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A
             g -= G;
             ++a;
         }
+        if (a >= A) {
+            a -= A;
+            sel = 1;
+        }
+    }
+    // scalar tail of the whole map (total % 4 floats), done by the last workgroup
+    if (left <= kIouChunk && threadIdx.x < (int)(left & 3)) {
+        const long long e = f0 + (left & ~3ll) + threadIdx.x;
+        const int bi = (int)(e / per_img), rem = (int)(e - (long long)bi * per_img);
+        const int ai = rem / G, gi = rem - ai * G;
+        const Box bb = load_box(bboxes + bstride * bi + 4 * (size_t)ai);
+        const Box gg = load_box(gt + 4 * ((size_t)bi * G + gi));
+        out[e] = iou_map_pair(bb, box_area_plain(bb), gg, box_area_plain(gg));
     }
 }
 
@@ -337,19 +360,16 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     const int per_img = A * G;
     static const int chunked = getenv("RPN_IOU_CHUNKED") ? atoi(getenv("RPN_IOU_CHUNKED")) : 1;
     static const int nt = getenv("RPN_IOU_NT") ? atoi(getenv("RPN_IOU_NT")) : 1;
-    static const int ta_floats = getenv("RPN_IOU_CHUNK_FLOATS") ? atoi(getenv("RPN_IOU_CHUNK_FLOATS")) : 4096;
-    if (chunked && per_img % 4 == 0 && G >= 4 && G <= 2048) {
-        int TA = (ta_floats / G + 3) & ~3;                    // anchors per workgroup: a multiple of 4, ~4096 floats
-        if (TA < 4) TA = 4;
-        const int chunks = (A + TA - 1) / TA;
-        RPN_REQUIRE(chunks <= 0x7fffffff / 2, "rpn_iou_map: too many chunks");
-        const size_t lds = (size_t)G * 20;
+    if (chunked && G >= 4 && G <= 2048 && per_img >= kIouChunk && total < (1ll << 40)) {
+        const long long chunks = (total + kIouChunk - 1) / kIouChunk;
+        RPN_REQUIRE(chunks <= 0x7fffffffll, "rpn_iou_map: too many chunks");
+        const size_t lds = (size_t)G * 40;
         if (nt)
-            hipLaunchKernelGGL(iou_map_chunk_kernel<true>, dim3(chunks, B), dim3(kThreads), lds, as_stream(stream),
-                               d_bboxes, bboxes_batched, A, d_gt, G, TA, d_iou);
+            hipLaunchKernelGGL(iou_map_chunk_kernel<true>, dim3((unsigned)chunks), dim3(kThreads), lds, as_stream(stream),
+                               d_bboxes, bboxes_batched, A, d_gt, G, B, total, d_iou);
         else
-            hipLaunchKernelGGL(iou_map_chunk_kernel<false>, dim3(chunks, B), dim3(kThreads), lds, as_stream(stream),
-                               d_bboxes, bboxes_batched, A, d_gt, G, TA, d_iou);
+            hipLaunchKernelGGL(iou_map_chunk_kernel<false>, dim3((unsigned)chunks), dim3(kThreads), lds, as_stream(stream),
+                               d_bboxes, bboxes_batched, A, d_gt, G, B, total, d_iou);
     } else {
         hipLaunchKernelGGL(iou_map_kernel, dim3(grid_for((per_img + 3) / 4), B), dim3(kThreads), 0, as_stream(stream),
                            d_bboxes, bboxes_batched, A, d_gt, G, (per_img % 4 == 0) ? 1 : 0, d_iou);

@@ -40,6 +40,9 @@ struct ConvArgs {
     int act, act2, split;   // split == Cout when there is a single output
     int ld1, ld2;
     PackedShape ps;
+    int out_split;          // 0: float32 NHWC; 1 / 2: `out` is SPLIT16 with bfloat16 / float16 halves (needs Cout % 32 == 0,
+                            // a single output, no residual): the consumer is a split-precision 3x3 conv
+    unsigned *status;       // float16 range flag (out_split == 2), or null
 };
 
 // dense convolution as an implicit GEMM on the f32 MFMA; returns hipGetLastError()

@@ -267,6 +267,41 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         float *__restrict__ obase = second ? a.out2 : a.out;
         const int ld = second ? a.ld2 : a.ld1;
         const int ch = second ? n - a.split : n;
+        if (a.out_split) {
+            // SPLIT16 record of (pixel, 16-channel slice) = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} 16-bit halves
+            // (x ~ hi + lo).  Lanes (2t, 2t+1) hold channels (2t, 2t+1): the even lane stores the pair's hi dword, the
+            // odd lane its lo dword -- one 4-byte store per lane, the 32 lanes cover the pixel's two 64-byte records.
+            unsigned *__restrict__ o32 = reinterpret_cast<unsigned *>(a.out);
+            const int cj = n & 15, odd = lane & 1;
+            const int dw = (n >> 4) * 16 + (cj >> 3) * 8 + odd * 4 + ((cj & 7) >> 1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = wm * MI * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                    const float v = apply_act(acc[i][j][e] + bias, act);
+                    unsigned hi, lo;
+                    if (a.out_split == 2) {
+                        if (a.status && !(fabsf(v) <= 65504.0f)) atomicOr(a.status, 1u);
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)(v - (float)h);
+                        hi = __builtin_bit_cast(unsigned short, h);
+                        lo = __builtin_bit_cast(unsigned short, l);
+                    } else {
+                        const __bf16 h = (__bf16)v;
+                        const __bf16 l = (__bf16)(v - (float)h);
+                        hi = __builtin_bit_cast(unsigned short, h);
+                        lo = __builtin_bit_cast(unsigned short, l);
+                    }
+                    const unsigned got = __shfl_xor(odd ? hi : lo, 1);          // even lane <- partner's hi, odd <- partner's lo
+                    const unsigned word = odd ? (got | (lo << 16)) : (hi | (got << 16));
+                    if (oy < a.OH && ox < a.OW)
+                        o32[(((size_t)img * a.OH + oy) * a.OW + ox) * a.Cout + dw] = word;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll

@@ -20,8 +20,8 @@
 //   3. + bias (+ the residual, read from the input tile already in LDS) -> NHWC float32.
 // The expanded tensor never exists in HBM.  Weight fragments (B operands) are read straight from global memory in
 // the MFMA B layout (4 rows x 64 contiguous bytes per wave instruction; the whole weight set of a block is <= 0.5 MB
-// and is shared by every workgroup, so it lives in L2 / L1).  46 KB (stride 1, Cin = 96) .. 62 KB (stride 2) of LDS
-// per workgroup: 2-3 workgroups per CU overlap one another's load / depthwise phases with MFMA work.
+// and is shared by every workgroup, so it lives in L2 / L1).  The chunks are software-pipelined over two
+// wave groups (see the kernel); 31 KB (Cin = 24) .. 95 KB (stride 2, Cin = 32) of LDS per workgroup.
 //
 // STEM variant: the "expand" stage is Conv1 (3x3 stride 2, 3 -> 32 channels, K = 27 padded to 28) computed from an
 // im2col tile gathered from the image, followed by expanded_conv's depthwise and its 32 -> 16 projection: stem +
@@ -32,12 +32,33 @@
 // compute (6*10)/(4*8) = 1.9x (stride 1) / (9*17)/(8*16) = 1.2x its algorithmic work.
 #include "conv_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
+// Debug build only (-DRPN_STAMP, scripts/ir_stamp_probe.py): cycle stamps of the pipeline's phases, 64 slots per
+// workgroup for the first 512 workgroups: [0] start, [1] input tile in LDS, then per step it: [2+4it] wave 0 after E,
+// [3+4it] wave 0 after P, [4+4it] wave 4 after D, [5+4it] wave 0 after the barrier.
+#ifdef RPN_STAMP
+__device__ unsigned long long g_ir_stamps[512 * 128];
+#define IR_STAMP(w, k)                                                                                    \
+    do {                                                                                                  \
+        if (threadIdx.x == 64 * (w) && blockIdx.x < 512 && (k) < 128 && a.stamp)                          \
+            g_ir_stamps[blockIdx.x * 128 + (k)] = __builtin_readcyclecounter();                            \
+    } while (0)
+extern "C" int rpn_debug_read_ir_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ir_stamps), (size_t)n * 8);
+}
+#else
+#define IR_STAMP(w, k) ((void)0)
+#endif
+
 namespace rpn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int IR_TH = 4, IR_TW = 8;           // output tile
-constexpr int IR_THREADS = 256;
+constexpr int IR_THREADS = 512;               // waves 0-3: the two GEMMs (one wave per SIMD); waves 4-7: depthwise
 
 struct IrArgs {
     const float *x;       // block input, NHWC float32 (STEM: the image, 3 channels)
@@ -50,38 +71,71 @@ struct IrArgs {
     int OH, OW;           // block output size
     int pad;              // top / left zero padding of the depthwise (STEM: of Conv1; its depthwise pads 1)
     int tiles_x, tiles_y;
+    int stamp;            // -DRPN_STAMP builds: this launch records phase stamps
 };
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
 // KP: reduction length of the expand stage (Cin; STEM: 28); CE: expanded channels per chunk; S: depthwise stride.
+//
+// Software pipeline over the chunks, one workgroup barrier per step.  In step i
+//     waves 0-3 (MFMA):     E(i)   expand chunk i        Xs, WeS[i & 1]          -> Es[i & 1]
+//                           P(i-2) project chunk i-2     Ds[i & 1], WpS[i & 1]   -> accumulators
+//     waves 4-7 (service):  D(i-1) depthwise chunk i-1   Es[(i-1)&1]             -> Ds[(i-1)&1]
+//                           stage  We chunk i+1 -> WeS[(i+1)&1],  Wp chunk i-1 -> WpS[(i-1)&1]  (global -> regs -> LDS),
+//                                  depthwise weights of chunk i -> registers (used by D(i) in step i+1)
+// so every operand the matrix waves touch is already in LDS when a step starts (L2 latency is paid by the service
+// waves, one step ahead, beside their depthwise work) and the depthwise runs beside the GEMMs of the neighbouring
+// chunks.  Measured on the 32x32 blocks (one workgroup per CU): first version (4 waves, weights from L2 inside the
+// k-loop, depthwise between the GEMMs) 24 % MFMA utilisation; see DESIGN.md for the current figures.
+//
+// LDS images (float32; strides chosen for the access that reads or writes them with 4-byte-per-lane instructions):
+//   Xs  [halo px][KP + 2]      A operand of E: 16 px x 2 k per half-wave, stride 2 * odd          -> conflict-free
+//   WeS [2][KP][SWE]           B operand of E: 2 k x 16 n per half-wave, stride = 16 mod 32       -> conflict-free
+//   Es  [2][halo px][CE + 4]   written from the C layout (16 n x 2 row groups 4 px apart: stride = 4 mod 8), read by
+//                              the depthwise with lanes = channels                                -> conflict-free
+//   Ds  [2][32 px][CE + 2]     written with lanes = channels, read as the A operand of P (stride 2 * odd)
+//   WpS [2][CE][SWP]           B operand of P, stride = 16 mod 32
 template <int KP, int CEXP, int CE, int COUT, int S, bool RES, bool STEM>
 __global__ void __launch_bounds__(IR_THREADS)
 ir_block_kernel(IrArgs a)
 {
-    constexpr int SX = KP + 2;                               // Xs row stride: 2 * odd
+    constexpr int SX = KP + 2;
     constexpr int IH = (IR_TH - 1) * S + 3, IW = (IR_TW - 1) * S + 3;
     constexpr int NH = IH * IW;                              // halo pixels
     constexpr int MB = (NH + 15) / 16;                       // M-blocks of the expand GEMM
     constexpr int MH = MB * 16;
     constexpr int MBW = (MB + 3) / 4;                        // M-blocks per wave
-    constexpr int SE = (MH + 31) / 32 * 32 + 4;              // Es row stride = 4 mod 32
+    constexpr int SEP = CE + 4;
     constexpr int NBE = CE / 16;                             // N-blocks of the expand GEMM per chunk
     constexpr int NCHUNK = CEXP / CE;
-    constexpr int SD = CE + 2;                               // Ds row stride: 2 * odd
+    constexpr int SD = CE + 2;
     constexpr int COUTP = (COUT + 15) / 16 * 16;
     constexpr int NBO = COUTP / 16;                          // N-blocks of the projection
     constexpr int NJ = (NBO + 1) / 2;                        // ... per wave (waves split 2 M-blocks x 2 N-block parities)
-    static_assert(KP % 4 == 0 && (SX / 2) % 2 == 1 && (SD / 2) % 2 == 1 && CEXP % CE == 0 && CE % 16 == 0, "layout");
+    constexpr int SWE = CE % 32 == 16 ? CE : CE + 16;
+    constexpr int SWP = COUTP % 32 == 16 ? COUTP : COUTP + 16;
+    constexpr int KS = KP / 4;                               // k-steps of the expand GEMM
+    constexpr int EB = 4;                                    // k-steps per register batch of E operands
+    constexpr int NEB = (KS + EB - 1) / EB;
+    constexpr int PS = CE / 4;                               // k-steps of the projection per chunk
+    constexpr int PB = PS % 6 == 0 ? 6 : 4;                  // k-steps per register batch of P operands
+    constexpr int NPB = PS / PB;
+    constexpr int WE4 = KP * CE / 4, NWE = (WE4 + 255) / 256;         // float4s of a We chunk, per service thread
+    constexpr int WP4 = CE * COUTP / 4, NWP = (WP4 + 255) / 256;
+    static_assert(KP % 4 == 0 && (SX / 2) % 2 == 1 && (SD / 2) % 2 == 1 && CEXP % CE == 0 && CE % 16 == 0 && CE <= 64, "layout");
+    static_assert(SEP % 8 == 4 && SWE % 32 == 16 && SWP % 32 == 16 && PS % PB == 0, "layout");
     static_assert(!RES || (S == 1 && KP == COUT && !STEM), "residual needs stride 1 and Cin == Cout");
 
     __shared__ __attribute__((aligned(16))) float Xs[MH * SX];
-    __shared__ __attribute__((aligned(16))) float Es[CE * SE];
-    __shared__ __attribute__((aligned(16))) float Ds[IR_TH * IR_TW * SD];
-    __shared__ float Wds[10 * CE];
+    __shared__ __attribute__((aligned(16))) float Es[2][MH * SEP];
+    __shared__ __attribute__((aligned(16))) float Ds[2][IR_TH * IR_TW * SD];
+    __shared__ __attribute__((aligned(16))) float WeS[2][KP * SWE];
+    __shared__ __attribute__((aligned(16))) float WpS[2][CE * SWP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
+    const int stid = tid - 256;                              // service thread index (waves 4-7)
     int t = blockIdx.x;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
@@ -90,6 +144,60 @@ ir_block_kernel(IrArgs a)
     const int oy0 = ty * IR_TH, ox0 = tx * IR_TW;
     const int dpad = STEM ? 1 : a.pad;
     const int gy0 = oy0 * S - dpad, gx0 = ox0 * S - dpad;   // halo origin on the depthwise's input grid
+    IR_STAMP(0, 0);
+
+    // ---- service waves: weight staging (global -> registers now, registers -> LDS at the end of the step) ----------
+    f32x4 we_st[NWE], wp_st[NWP];
+    auto we_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i) {
+            const int idx = stid + 256 * i;
+            if (WE4 % 256 == 0 || idx < WE4) {
+                const int k = idx / (CE / 4), q = idx - k * (CE / 4);
+                we_st[i] = *reinterpret_cast<const f32x4 *>(a.we + (size_t)k * CEXP + c * CE + 4 * q);
+            }
+        }
+    };
+    auto we_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i) {
+            const int idx = stid + 256 * i;
+            if (WE4 % 256 == 0 || idx < WE4) {
+                const int k = idx / (CE / 4), q = idx - k * (CE / 4);
+                *reinterpret_cast<f32x4 *>(&WeS[slot][k * SWE + 4 * q]) = we_st[i];
+            }
+        }
+    };
+    auto wp_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int idx = stid + 256 * i;
+            if (WP4 % 256 == 0 || idx < WP4) {
+                const int k = idx / (COUTP / 4), q = idx - k * (COUTP / 4);
+                wp_st[i] = *reinterpret_cast<const f32x4 *>(a.wp + (size_t)(c * CE + k) * COUTP + 4 * q);
+            }
+        }
+    };
+    auto wp_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int idx = stid + 256 * i;
+            if (WP4 % 256 == 0 || idx < WP4) {
+                const int k = idx / (COUTP / 4), q = idx - k * (COUTP / 4);
+                *reinterpret_cast<f32x4 *>(&WpS[slot][k * SWP + 4 * q]) = wp_st[i];
+            }
+        }
+    };
+    // depthwise weights + bias of one chunk, lane = channel
+    float wd_cur[10], wd_nxt[10];
+    auto wd_fetch = [&](int c) __attribute__((always_inline)) {
+        if (lane < CE) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + lane];
+            wd_nxt[9] = a.bd[c * CE + lane];
+        }
+    };
+    if (wave >= 4) we_fetch(0);                              // in flight while the input tile is loaded
 
     // ---- 1. input tile -> LDS ------------------------------------------------------------------------------------
     if constexpr (!STEM) {
@@ -125,105 +233,179 @@ ir_block_kernel(IrArgs a)
     }
     // which of this lane's expand outputs (M-block mbi of the wave, row 4*lk + i) are pixels inside the image
     unsigned vmask = 0;
+    if (wave < 4) {
 #pragma unroll
-    for (int mbi = 0; mbi < MBW; ++mbi)
+        for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = (wave + 4 * mbi) * 16 + 4 * lk + i;
-            const int hy = m / IW, hx = m - hy * IW;
-            const int gy = gy0 + hy, gx = gx0 + hx;
-            if (m < NH && gy >= 0 && gy < a.DH && gx >= 0 && gx < a.DW) vmask |= 1u << (mbi * 4 + i);
-        }
+            for (int i = 0; i < 4; ++i) {
+                const int m = (wave + 4 * mbi) * 16 + 4 * lk + i;
+                const int hy = m / IW, hx = m - hy * IW;
+                const int gy = gy0 + hy, gx = gx0 + hx;
+                if (m < NH && gy >= 0 && gy < a.DH && gx >= 0 && gx < a.DW) vmask |= 1u << (mbi * 4 + i);
+            }
+    } else {
+        we_store(0);
+    }
     __syncthreads();
+    IR_STAMP(0, 1);
 
     f32x4 pacc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int mbp = wave & 1, nbp = wave >> 1;             // projection: this wave's M-block and N-block parity
+    const int mbp = wave & 1, nbp = (wave >> 1) & 1;       // projection: this wave's M-block and N-block parity
+    const bool proj_wave = NBO >= 2 || nbp == 0;
 
-    for (int c = 0; c < NCHUNK; ++c) {
-        // depthwise weights + bias of the chunk -> LDS (read as broadcasts below)
-        for (int i = tid; i < 10 * CE; i += IR_THREADS) {
-            const int r = i / CE, n = i - r * CE;
-            Wds[i] = r < 9 ? a.wd[r * CEXP + c * CE + n] : a.bd[c * CE + n];
-        }
-        // ---- 2a. expand: (halo pixels x KP) * (KP x CE) ---------------------------------------------------------
-        f32x4 eacc[MBW][NBE];
+    for (int it = 0; it < NCHUNK + 2; ++it) {
+        if (wave < 4) {
+            const bool do_e = it < NCHUNK, do_p = it >= 2;
+            if (do_e) {
+                // ---- E(it): (halo pixels x KP) * (KP x CE) -> + bias, ReLU6, zero outside the image -> Es[it & 1] -------
+                float biasv[NBE];
 #pragma unroll
-        for (int mbi = 0; mbi < MBW; ++mbi)
+                for (int nb = 0; nb < NBE; ++nb) biasv[nb] = a.be[it * CE + nb * 16 + lr];
+                const float *wes = WeS[it & 1];
+                float aq[2][EB][MBW], bq[2][EB][NBE];
+                auto ld_e = [&](int b, float (&af)[EB][MBW], float (&bf)[EB][NBE]) {
 #pragma unroll
-            for (int nb = 0; nb < NBE; ++nb) eacc[mbi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *__restrict__ wec = a.we + (size_t)lk * CEXP + c * CE + lr;
+                    for (int k4 = 0; k4 < EB; ++k4) {
+                        const int kk = b * EB + k4;
+                        if (kk < KS) {
 #pragma unroll
-        for (int kk = 0; kk < KP / 4; ++kk) {
-            float bfr[NBE];
+                            for (int mbi = 0; mbi < MBW; ++mbi) {
+                                const int mb = wave + 4 * mbi;
+                                if (MB % 4 == 0 || mb < MB) af[k4][mbi] = Xs[(mb * 16 + lr) * SX + 4 * kk + lk];
+                            }
 #pragma unroll
-            for (int nb = 0; nb < NBE; ++nb) bfr[nb] = wec[(size_t)(4 * kk) * CEXP + nb * 16];
+                            for (int nb = 0; nb < NBE; ++nb) bf[k4][nb] = wes[(4 * kk + lk) * SWE + nb * 16 + lr];
+                        }
+                    }
+                };
+                f32x4 eacc[MBW][NBE];
 #pragma unroll
-            for (int mbi = 0; mbi < MBW; ++mbi) {
-                const int mb = wave + 4 * mbi;
-                if (MB % 4 == 0 || mb < MB) {
-                    const float af = Xs[(mb * 16 + lr) * SX + 4 * kk + lk];
+                for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
-                    for (int nb = 0; nb < NBE; ++nb)
-                        eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr[nb], eacc[mbi][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NBE; ++nb) eacc[mbi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ld_e(0, aq[0], bq[0]);
+#pragma unroll
+                for (int b = 0; b < NEB; ++b) {
+                    // the operands of batch b+1 are requested BEFORE the MFMAs of batch b; without the scheduling
+                    // barriers the compiler sinks every LDS read to its use (shortest live range) and each pair of
+                    // MFMAs waits for a fresh LDS round trip (measured: 71 instead of 32 cycles per MFMA)
+                    if (b + 1 < NEB) ld_e(b + 1, aq[(b + 1) & 1], bq[(b + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k4 = 0; k4 < EB; ++k4) {
+                        if (b * EB + k4 < KS) {
+#pragma unroll
+                            for (int mbi = 0; mbi < MBW; ++mbi) {
+                                const int mb = wave + 4 * mbi;
+                                if (MB % 4 == 0 || mb < MB) {
+#pragma unroll
+                                    for (int nb = 0; nb < NBE; ++nb)
+                                        eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                            aq[b & 1][k4][mbi], bq[b & 1][k4][nb], eacc[mbi][nb], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-        }
+                float *es = Es[it & 1];
 #pragma unroll
-        for (int mbi = 0; mbi < MBW; ++mbi) {
-            const int mb = wave + 4 * mbi;
-            if (MB % 4 == 0 || mb < MB) {
+                for (int mbi = 0; mbi < MBW; ++mbi) {
+                    const int mb = wave + 4 * mbi;
+                    if (MB % 4 == 0 || mb < MB) {
 #pragma unroll
-                for (int nb = 0; nb < NBE; ++nb) {
-                    const int n = nb * 16 + lr;
-                    const float bias = a.be[c * CE + n];
-                    f32x4 v;
+                        for (int nb = 0; nb < NBE; ++nb)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[i] = ((vmask >> (mbi * 4 + i)) & 1u) ? relu6f(eacc[mbi][nb][i] + bias) : 0.0f;
-                    *reinterpret_cast<f32x4 *>(&Es[n * SE + mb * 16 + 4 * lk]) = v;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 2b. depthwise 3x3 on the chunk: lanes = the 32 output pixels, 2 channels per wave and step ----------
-        {
-            const int p = lane & 31, py = p >> 3, px = p & 7;
-            const int base = (py * S) * IW + px * S;
-#pragma unroll
-            for (int it = 0; it < CE / 8; ++it) {
-                const int n = wave * 2 + (lane >> 5) + 8 * it;
-                const float *e = &Es[n * SE + base];
-                float acc = Wds[9 * CE + n];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) acc = fmaf(e[r * IW + q], Wds[(r * 3 + q) * CE + n], acc);
-                Ds[p * SD + n] = relu6f(acc);
-            }
-        }
-        __syncthreads();
-        // ---- 2c. projection: acc (32 px x COUT) += D (32 x CE) * Wp[chunk] --------------------------------------
-        if (NBO >= 2 || nbp == 0) {
-            const float *__restrict__ wpc = a.wp + (size_t)(c * CE + lk) * COUTP + lr;
-#pragma unroll
-            for (int kk = 0; kk < CE / 4; ++kk) {
-                const float af = Ds[(mbp * 16 + lr) * SD + 4 * kk + lk];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int nb = nbp + 2 * j;
-                    if (NBO % 2 == 0 || nb < NBO) {
-                        const float bf = wpc[(size_t)(4 * kk) * COUTP + nb * 16];
-                        pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, pacc[j], 0, 0, 0);
+                            for (int i = 0; i < 4; ++i)
+                                es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
+                                    ((vmask >> (mbi * 4 + i)) & 1u) ? relu6f(eacc[mbi][nb][i] + biasv[nb]) : 0.0f;
                     }
                 }
             }
+            IR_STAMP(0, 2 + 4 * it);
+            if (do_p && proj_wave) {
+                // ---- P(it-2): acc (32 px x COUT) += D (32 x CE) * Wp[chunk it-2]; D = Ds[it & 1], Wp = WpS[it & 1] ------
+                const float *ds = Ds[it & 1];
+                const float *wps = WpS[it & 1];
+                float pa[2][PB], pb[2][PB][NJ];
+                auto ld_p = [&](int b, float (&af)[PB], float (&bf)[PB][NJ]) {
+#pragma unroll
+                    for (int k4 = 0; k4 < PB; ++k4) {
+                        const int kk = b * PB + k4;
+                        af[k4] = ds[(mbp * 16 + lr) * SD + 4 * kk + lk];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int nb = nbp + 2 * j;
+                            if (NBO % 2 == 0 || nb < NBO) bf[k4][j] = wps[(4 * kk + lk) * SWP + nb * 16 + lr];
+                        }
+                    }
+                };
+                ld_p(0, pa[0], pb[0]);
+#pragma unroll
+                for (int b = 0; b < NPB; ++b) {
+                    if (b + 1 < NPB) ld_p(b + 1, pa[(b + 1) & 1], pb[(b + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k4 = 0; k4 < PB; ++k4)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int nb = nbp + 2 * j;
+                            if (NBO % 2 == 0 || nb < NBO)
+                                pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[b & 1][k4], pb[b & 1][k4][j], pacc[j], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            IR_STAMP(0, 3 + 4 * it);
+        } else {
+            // ---- service waves --------------------------------------------------------------------------------------------
+            const bool st_we = it + 1 < NCHUNK, st_wp = it >= 1 && it <= NCHUNK;
+            if (it >= 1 && it <= NCHUNK && lane < CE) {
+                // D(it-1): depthwise 3x3 + bias + ReLU6 on chunk it-1.  wave - 4 = output row, lane = channel; the
+                // 3 x IW input window of the row is read once (30 / 51 LDS reads for 8 outputs), then 72 FMAs
+                const int c = it - 1;
+                const float *es = Es[c & 1] + lane;
+                float *ds = Ds[c & 1] + lane;
+                const int py = wave - 4;
+                float win[3][IW];                       // the 3 input rows of this output row, one channel per lane
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < IW; ++x) win[r][x] = es[((py * S + r) * IW + x) * SEP];
+                __builtin_amdgcn_sched_barrier(0);
+                IR_STAMP(4, 64 + 4 * it);
+#pragma unroll
+                for (int px = 0; px < IR_TW; ++px) {
+                    float acc = wd_cur[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_cur[r * 3 + q], acc);
+                    ds[(py * IR_TW + px) * SD] = relu6f(acc);
+                }
+            }
+            IR_STAMP(4, 4 + 4 * it);
+            // weight staging AFTER the depthwise: the service waves have slack (their step is shorter than the matrix
+            // waves'), and with the loads issued first the compiler parks a vmcnt(0) in front of the depthwise
+            __builtin_amdgcn_sched_barrier(0);
+            if (st_we) we_fetch(it + 1);
+            if (st_wp) wp_fetch(it - 1);
+            if (it < NCHUNK) wd_fetch(it);
+            IR_STAMP(4, 65 + 4 * it);
+            if (st_we) we_store((it + 1) & 1);
+            if (st_wp) wp_store((it - 1) & 1);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
+            IR_STAMP(4, 66 + 4 * it);
         }
+        __syncthreads();
+        IR_STAMP(0, 5 + 4 * it);
     }
 
     // ---- 3. + bias (+ residual from the input tile) -> NHWC ----------------------------------------------------------
-    if (NBO >= 2 || nbp == 0) {
+    if (wave < 4 && proj_wave) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int nb = nbp + 2 * j;
@@ -274,6 +456,11 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
     a.tiles_y = (OH + IR_TH - 1) / IR_TH;
     const long long nblocks = (long long)a.tiles_x * a.tiles_y * B;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    {   // RPN_IR_STAMP_OP="cin,stride" selects the block that records stamps in a -DRPN_STAMP build ("3,1": the stem)
+        const char *sel = getenv("RPN_IR_STAMP_OP");
+        int sc = -1, ss = -1;
+        a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == stride && (cin != 64 || cout == 64);
+    }
 #define RPN_IR(KP_, CEXP_, CE_, COUT_, S_, RES_, STEM_)                                                              \
     hipLaunchKernelGGL((ir_block_kernel<KP_, CEXP_, CE_, COUT_, S_, RES_, STEM_>), dim3((unsigned)nblocks),          \
                        dim3(IR_THREADS), 0, s, a)
@@ -282,10 +469,10 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
         RPN_IR(28, 32, 32, 16, 1, false, true);
     } else if (!ir_block_supported(cin, cexp, cout, stride, residual)) {
         return hipErrorInvalidValue;
-    } else if (cin == 16) RPN_IR(16, 96, 48, 24, 2, false, false);
+    } else if (cin == 16) RPN_IR(16, 96, 16, 24, 2, false, false);
     else if (cin == 24 && stride == 1) RPN_IR(24, 144, 48, 24, 1, true, false);
-    else if (cin == 24) RPN_IR(24, 144, 48, 32, 2, false, false);
-    else if (cin == 32 && stride == 1) RPN_IR(32, 192, 48, 32, 1, true, false);
+    else if (cin == 24) RPN_IR(24, 144, 16, 32, 2, false, false);
+    else if (cin == 32 && stride == 1) RPN_IR(32, 192, 32, 32, 1, true, false);
     else if (cin == 32) RPN_IR(32, 192, 48, 64, 2, false, false);
     else if (cin == 64 && cout == 64) RPN_IR(64, 384, 48, 64, 1, true, false);
     else if (cin == 64) RPN_IR(64, 384, 48, 96, 1, false, false);

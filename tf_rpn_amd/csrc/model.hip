@@ -58,6 +58,7 @@ struct Op {
     bool split = false;                // runs on the x3-split 16-bit MFMA kernel (SPLIT16 input)
     bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
+    bool f32_out_split = false;        // float32 implicit-GEMM conv writing SPLIT16 directly (its consumer is a split conv)
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
     // OP_IRBLOCK (one fused MobileNetV2 block; Cin / Cout = block input / output channels, stride = the depthwise's):
     int cexp = 0;                      // expanded channels
@@ -141,6 +142,13 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     const bool split = m->use_split && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && residual < 0 &&
                        act != ACT_SIGMOID &&
                        m->tensors[in].C % 16 == 0 && Cout % 16 == 0 && !m->tensors[in].external;
+    if (split && !m->tensors[in].split_fmt && !m->keep_all && !m->ops.empty() && m->ops.back().out == in &&
+        m->ops.back().kind == OP_CONV && !m->ops.back().split && !m->ops.back().cin3 && m->ops.back().residual < 0 &&
+        m->ops.back().Cout % 32 == 0 && m->ops.back().act != ACT_SIGMOID) {
+        // the float32 producer (MobileNetV2: block_13_expand) writes SPLIT16 from its own epilogue: no conversion pass
+        m->ops.back().f32_out_split = true;
+        m->tensors[in].split_fmt = true;
+    }
     if (split && !m->tensors[in].split_fmt) {          // float32 producer -> SPLIT16 copy for the split kernel
         const Tensor tsrc = m->tensors[in];
         Op cv;
@@ -770,6 +778,8 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             } else {
                 a.out = tensor_ptr(m, op.out, d_imgs); a.ld1 = op.Cout; a.act = op.act; a.split = op.Cout;
                 a.out2 = nullptr; a.ld2 = 0; a.act2 = ACT_LINEAR;
+                a.out_split = op.f32_out_split ? (m->f16 ? 2 : 1) : 0;
+                a.status = op.f32_out_split && m->f16 ? m->d_status : nullptr;
             }
             e = launch_conv_f32(a, s);
         } else if (op.kind == OP_IRBLOCK) {
