@@ -397,7 +397,9 @@ def test_load_weights_from_keras_h5(tmp_path, backbone, strings):
         ok = False
     if not ok:
         pytest.skip("no interpreter with h5py on this machine to write the file")
-    hp, weights, model, imgs = _model_case(backbone, 64, 2)
+    hp, weights, _layerwise, imgs = _model_case(backbone, 64, 2)
+    model = RPNModel(backbone, hp, max_batch=2)            # the same (production) graph as `loaded` below
+    model.set_weights(weights)
     npz, h5 = str(tmp_path / "w.npz"), str(tmp_path / "w.h5")
     RPNModel.save_weights(weights, npz)
     r = subprocess.run([H5PY_PYTHON, os.path.join(here, "golden", "npz_to_keras_h5.py"), npz, h5, strings],
