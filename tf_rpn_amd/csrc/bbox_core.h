@@ -65,12 +65,15 @@ __device__ __forceinline__ float4 encode_box(const Box &bb, const Box &gt)
 // generate_iou_map -- utils/bbox_utils.py:138-150 for one (bbox, gt) pair
 __device__ __forceinline__ float iou_map_pair(const Box &b, float b_area, const Box &g, float g_area)
 {
-    const float xt = b.x1 > g.x1 ? b.x1 : g.x1;                  // :141
-    const float yt = b.y1 > g.y1 ? b.y1 : g.y1;                  // :142
-    const float xb = b.x2 < g.x2 ? b.x2 : g.x2;                  // :143
-    const float yb = b.y2 < g.y2 ? b.y2 : g.y2;                  // :144
+    // fmaxf / fminf = one v_max_f32 / v_min_f32 each (a compare + select pair otherwise).  They differ from tf.maximum only
+    // in which operand survives a NaN, and a NaN coordinate makes its box's area -- hence the union and the result -- NaN
+    // under either rule.
+    const float xt = fmaxf(b.x1, g.x1);                          // :141
+    const float yt = fmaxf(b.y1, g.y1);                          // :142
+    const float xb = fminf(b.x2, g.x2);                          // :143
+    const float yb = fminf(b.y2, g.y2);                          // :144
     const float dx = xb - xt, dy = yb - yt;
-    const float inter = (dx > 0.0f ? dx : 0.0f) * (dy > 0.0f ? dy : 0.0f);   // :146
+    const float inter = fmaxf(dx, 0.0f) * fmaxf(dy, 0.0f);       // :146
     const float uni = b_area + g_area - inter;                   // :148
     return inter / uni;                                          // :150 (no epsilon)
 }
