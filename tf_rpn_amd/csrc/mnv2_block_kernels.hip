@@ -127,7 +127,12 @@ ir_block_kernel(IrArgs a)
     static_assert(SEP % 8 == 4 && SWE % 32 == 16 && SWP % 32 == 16 && PS % PB == 0, "layout");
     static_assert(!RES || (S == 1 && KP == COUT && !STEM), "residual needs stride 1 and Cin == Cout");
 
-    __shared__ __attribute__((aligned(16))) float Xs[MH * SX];
+    // STEM: Xs is the raw image patch ((2(IH-1)+3) rows x (2(IW-1)+3) pixels x 3 channels, row stride PSTR) and the A
+    // operand of Conv1 is read straight from it: im2col entry (pixel (hy, hx), k = (r*3+q)*3+c) = patch[(2hy + r)*PSTR +
+    // (2hx + q)*3 + c] = base(pixel) + off(k) -- no im2col tile is ever built
+    constexpr int PR = 2 * (IH - 1) + 3, PC = (2 * (IW - 1) + 3) * 3, PSTR = PC + 2;
+    constexpr int XS_FLOATS = STEM ? PR * PSTR : MH * SX;
+    __shared__ __attribute__((aligned(16))) float Xs[XS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Es[2][MH * SEP];
     __shared__ __attribute__((aligned(16))) float Ds[2][IR_TH * IR_TW * SD];
     __shared__ __attribute__((aligned(16))) float WeS[2][KP * SWE];
@@ -188,13 +193,16 @@ ir_block_kernel(IrArgs a)
             }
         }
     };
-    // depthwise weights + bias of one chunk, lane = channel
+    // depthwise: lane = (channel dn, pixel group dg); weights + bias of one chunk per lane
+    constexpr int PG = CE <= 16 ? 4 : (CE <= 32 ? 2 : 1);   // pixel groups per output row
+    constexpr int PXG = IR_TW / PG;                          // output pixels per lane
+    const int dn = lane % (64 / PG), dg = lane / (64 / PG);
     float wd_cur[10], wd_nxt[10];
     auto wd_fetch = [&](int c) __attribute__((always_inline)) {
-        if (lane < CE) {
+        if (dn < CE) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + lane];
-            wd_nxt[9] = a.bd[c * CE + lane];
+            for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
+            wd_nxt[9] = a.bd[c * CE + dn];
         }
     };
     if (wave >= 4) we_fetch(0);                              // in flight while the input tile is loaded
@@ -215,20 +223,15 @@ ir_block_kernel(IrArgs a)
             dst[1] = make_float2(v.z, v.w);
         }
     } else {
-        // im2col of Conv1: row m = pixel (gy, gx) of Conv1's output, column k = (r*3 + q)*3 + c <- image pixel
-        // (2*gy - pad + r, 2*gx - pad + q), channel c; zero outside the image (ZeroPadding2D) and for k = 27
+        // raw patch: image rows 2*gy0 - pad .. + PR, columns (2*gx0 - pad) .. + PC/3, zero outside the image (ZeroPadding2D)
         const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * 3;
-        for (int idx = tid; idx < MH * KP; idx += IR_THREADS) {
-            const int m = idx / KP, k = idx - m * KP;
-            const int hy = m / IW, hx = m - hy * IW;
-            const int gy = gy0 + hy, gx = gx0 + hx;
+        const int iy0 = 2 * gy0 - a.pad, ix0 = 2 * gx0 - a.pad;
+        for (int idx = tid; idx < PR * PC; idx += IR_THREADS) {
+            const int pr = idx / PC, pc = idx - pr * PC;
+            const int iy = iy0 + pr, ixc = ix0 * 3 + pc;                    // ixc = column * 3 + channel
             float v = 0.0f;
-            if (m < NH && k < 27 && gy >= 0 && gy < a.DH && gx >= 0 && gx < a.DW) {
-                const int r = k / 9, q = (k / 3) % 3, c = k % 3;
-                const int iy = 2 * gy - a.pad + r, ix = 2 * gx - a.pad + q;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = xin[((size_t)iy * a.W + ix) * 3 + c];
-            }
-            Xs[m * SX + k] = v;
+            if (iy >= 0 && iy < a.H && ixc >= 0 && ixc < a.W * 3) v = xin[(size_t)iy * a.W * 3 + ixc];
+            Xs[pr * PSTR + pc] = v;
         }
     }
     // which of this lane's expand outputs (M-block mbi of the wave, row 4*lk + i) are pixels inside the image
@@ -249,9 +252,28 @@ ir_block_kernel(IrArgs a)
     __syncthreads();
     IR_STAMP(0, 1);
 
+    // STEM: per-lane patch offsets of the A fragments: base of the lane's pixel (per M-block), offset of its k per k-step
+    int xbase[MBW], xoff[KS];
+    if constexpr (STEM) {
+#pragma unroll
+        for (int mbi = 0; mbi < MBW; ++mbi) {
+            const int m = min((wave & 3) * 16 + 64 * mbi + lr, NH - 1);     // rows >= NH are masked out: any valid address
+            const int hy = m / IW, hx = m - hy * IW;
+            xbase[mbi] = 2 * hy * PSTR + 6 * hx;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int k = 4 * kk + lk;                                     // k = 27: zero weight row, any valid address
+            const int r = k / 9, q = (k / 3) % 3, c = k % 3;
+            xoff[kk] = k < 27 ? r * PSTR + q * 3 + c : 0;
+        }
+    }
     f32x4 pacc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias_nxt[NBE];                                     // expand bias of the next chunk (matrix waves)
+#pragma unroll
+    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[nb * 16 + lr];
     const int mbp = wave & 1, nbp = (wave >> 1) & 1;       // projection: this wave's M-block and N-block parity
     const bool proj_wave = NBO >= 2 || nbp == 0;
 
@@ -260,9 +282,13 @@ ir_block_kernel(IrArgs a)
             const bool do_e = it < NCHUNK, do_p = it >= 2;
             if (do_e) {
                 // ---- E(it): (halo pixels x KP) * (KP x CE) -> + bias, ReLU6, zero outside the image -> Es[it & 1] -------
-                float biasv[NBE];
+                float biasv[NBE];                        // loaded one step ahead (bias_nxt): no L2 round trip inside E
 #pragma unroll
-                for (int nb = 0; nb < NBE; ++nb) biasv[nb] = a.be[it * CE + nb * 16 + lr];
+                for (int nb = 0; nb < NBE; ++nb) biasv[nb] = bias_nxt[nb];
+                if (it + 1 < NCHUNK) {
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[(it + 1) * CE + nb * 16 + lr];
+                }
                 const float *wes = WeS[it & 1];
                 float aq[2][EB][MBW], bq[2][EB][NBE];
                 auto ld_e = [&](int b, float (&af)[EB][MBW], float (&bf)[EB][NBE]) {
@@ -273,7 +299,8 @@ ir_block_kernel(IrArgs a)
 #pragma unroll
                             for (int mbi = 0; mbi < MBW; ++mbi) {
                                 const int mb = wave + 4 * mbi;
-                                if (MB % 4 == 0 || mb < MB) af[k4][mbi] = Xs[(mb * 16 + lr) * SX + 4 * kk + lk];
+                                if (MB % 4 == 0 || mb < MB)
+                                    af[k4][mbi] = STEM ? Xs[xbase[mbi] + xoff[kk]] : Xs[(mb * 16 + lr) * SX + 4 * kk + lk];
                             }
 #pragma unroll
                             for (int nb = 0; nb < NBE; ++nb) bf[k4][nb] = wes[(4 * kk + lk) * SWE + nb * 16 + lr];
@@ -362,28 +389,31 @@ ir_block_kernel(IrArgs a)
         } else {
             // ---- service waves --------------------------------------------------------------------------------------------
             const bool st_we = it + 1 < NCHUNK, st_wp = it >= 1 && it <= NCHUNK;
-            if (it >= 1 && it <= NCHUNK && lane < CE) {
-                // D(it-1): depthwise 3x3 + bias + ReLU6 on chunk it-1.  wave - 4 = output row, lane = channel; the
-                // 3 x IW input window of the row is read once (30 / 51 LDS reads for 8 outputs), then 72 FMAs
+            if (it >= 1 && it <= NCHUNK && dn < CE) {
+                // D(it-1): depthwise 3x3 + bias + ReLU6 on chunk it-1.  wave - 4 = output row; lane = (channel dn, pixel
+                // group dg): PXG consecutive output pixels of the row per lane (8 for CE > 32, 4 for CE = 32, 2 for CE = 16,
+                // so that small chunks still use all 64 lanes).  The lane's 3 x ((PXG-1)*S + 3) input window is read
+                // once, then 9 FMAs per output.
                 const int c = it - 1;
-                const float *es = Es[c & 1] + lane;
-                float *ds = Ds[c & 1] + lane;
+                const float *es = Es[c & 1] + dn;
+                float *ds = Ds[c & 1] + dn;
                 const int py = wave - 4;
-                float win[3][IW];                       // the 3 input rows of this output row, one channel per lane
+                constexpr int WW = (PXG - 1) * S + 3;
+                float win[3][WW];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int x = 0; x < IW; ++x) win[r][x] = es[((py * S + r) * IW + x) * SEP];
+                    for (int x = 0; x < WW; ++x) win[r][x] = es[((py * S + r) * IW + dg * PXG * S + x) * SEP];
                 __builtin_amdgcn_sched_barrier(0);
                 IR_STAMP(4, 64 + 4 * it);
 #pragma unroll
-                for (int px = 0; px < IR_TW; ++px) {
+                for (int px = 0; px < PXG; ++px) {
                     float acc = wd_cur[9];
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_cur[r * 3 + q], acc);
-                    ds[(py * IR_TW + px) * SD] = relu6f(acc);
+                    ds[(py * IR_TW + dg * PXG + px) * SD] = relu6f(acc);
                 }
             }
             IR_STAMP(4, 4 + 4 * it);
