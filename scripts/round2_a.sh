@@ -22,5 +22,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stat
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/c3_write -o c3 -- python $GRAFT_REPO_ROOT/scripts/bench_bbox.py > /dev/null 2> $OUT/c3_write.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/c3_fetch -o c3 -- python $GRAFT_REPO_ROOT/scripts/bench_bbox.py > /dev/null 2> $OUT/c3_fetch.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mn8_stats -o mn8 -- python $GRAFT_REPO_ROOT/bench.py --backbone mobilenet_v2 --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > $OUT/mn8_stats.json 2> $OUT/mn8_stats.log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/mn8_write -o mn8 -- python $GRAFT_REPO_ROOT/bench.py --backbone mobilenet_v2 --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $OUT/mn8_write.log
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/mn8_fetch -o mn8 -- python $GRAFT_REPO_ROOT/bench.py --backbone mobilenet_v2 --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $OUT/mn8_fetch.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o c5 -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > $OUT/c5_stats.json 2> $OUT/c5_stats.log
 cd $GRAFT_REPO_ROOT
 grep -E "passed|failed|error" $OUT/pytest.log | tail -3; tail -2 $OUT/smoke.log; cat $OUT/bench_default.json; cat $OUT/bench_c4.json $OUT/bench_c5.json $OUT/bench_mn8.json
