@@ -110,6 +110,27 @@ __device__ __forceinline__ float nms_iou(const CBox &i, const CBox &j)
     return inter / (i.area + j.area - inter);
 }
 
+// nms_iou(i, j) > thr, bit for bit, without the IEEE divide except within 2^-18 (relative) of the threshold:
+// inter > thr_hi * uni  =>  fl(inter / uni) > thr;   inter < thr_lo * uni  =>  fl(inter / uni) < thr
+// (thr_hi / thr_lo = thr * (1 +- 2^-18); one rounding of the product and one of the quotient are 2^-24 each).  The host
+// passes thr_hi = +inf, thr_lo = -inf when thr is not a positive finite number: both shortcuts are then never taken.
+__device__ __forceinline__ bool nms_suppresses(const CBox &i, const CBox &j, float thr, float thr_lo, float thr_hi)
+{
+    if (i.area <= 0.0f || j.area <= 0.0f) return 0.0f > thr;
+    // v_max_f32 / v_min_f32 instead of TF's std::max / std::min (compare + select): identical on non-NaN operands; a NaN
+    // corner makes that box's area NaN (canonical() keeps TF's operand order), so `uni` is NaN, both shortcuts below are
+    // skipped and the quotient is NaN: "not suppressed" under either rule
+    const float iymin = fmaxf(i.ymin, j.ymin), ixmin = fmaxf(i.xmin, j.xmin);
+    const float iymax = fminf(i.ymax, j.ymax), ixmax = fminf(i.xmax, j.xmax);
+    const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
+    const float uni = i.area + j.area - inter;
+    if (uni >= 1e-30f) {                       // products below stay normal
+        if (inter > thr_hi * uni) return true;
+        if (inter < thr_lo * uni) return false;
+    }
+    return inter / uni > thr;
+}
+
 // monotone map float -> uint32 (descending float order == descending uint order);
 // -0.0 is folded onto +0.0 so that equal scores tie exactly as a float compare would.
 __device__ __forceinline__ unsigned orderable(float s)

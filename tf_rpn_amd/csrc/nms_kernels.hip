@@ -37,9 +37,13 @@ namespace rpn {
 constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
 constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
-constexpr int kBins = kRsBins;         // radix-select histogram (radix_select.h)
+constexpr int kBins = kRsHistWords;    // radix-select histogram words (radix_select.h)
 constexpr int kChunk = 256;
 constexpr int kChunkWords = kChunk / 64;
+// Chunk boxes are stored at slot(j) = (j % 16) * 16 + j / 16: the threads that build one suppression row read 16
+// candidates 16 apart (j = 16 * piece + jj, piece = lane % 16) -- consecutive slots, conflict-free; in natural order
+// those reads are 8-way bank conflicts (measured: 8 us per 64-row group).
+__device__ __forceinline__ int cslot(int j) { return ((j & 15) << 4) | (j >> 4); }
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct NmsArgs {
@@ -52,6 +56,7 @@ struct NmsArgs {
     int max_sel;             // min(max_per_class, [C==1: max_total])
     int max_total;
     float iou_thr, score_thr;
+    float iou_lo, iou_hi;    // iou_thr * (1 -+ 2^-18) (nms_suppresses); -inf / +inf when iou_thr is not positive and finite
     int clip;
     // final outputs (written directly when C == 1)
     float *out_boxes, *out_scores, *out_classes;
@@ -81,6 +86,35 @@ __device__ void bitonic_sort_desc(unsigned long long *keys, int n)
             __syncthreads();
         }
     }
+}
+
+// Descending bitonic sort of 1024 64-bit keys, one per thread (pad with 0): compare-exchange distances below 64 stay
+// inside a wave (two 32-bit shuffles, no barrier), only the 10 steps with distance >= 64 go through LDS.  The generic
+// network above spends 0.4 us per step on its workgroup barrier (55 steps for 1024 keys).  Returns the key that ends up
+// at position tid; `keys` (1024 entries of LDS) is scratch.
+__device__ __forceinline__ unsigned long long bitonic1024_desc(unsigned long long mine, unsigned long long *keys)
+{
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long other;
+            if (j >= 64) {
+                keys[tid] = mine;
+                __syncthreads();
+                other = keys[tid ^ j];
+                __syncthreads();
+            } else {
+                const unsigned lo = __shfl_xor((unsigned)mine, j, 64);
+                const unsigned hi = __shfl_xor((unsigned)(mine >> 32), j, 64);
+                other = ((unsigned long long)hi << 32) | lo;
+            }
+            const bool lower = (tid & j) == 0;                 // this thread holds the lower index of the pair
+            const bool desc = (tid & k) == 0;                  // direction of this pair's block (k = 1024: always descending)
+            const bool keep_max = lower == desc;
+            mine = keep_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+        }
+    }
+    return mine;
 }
 
 template <bool DECODE>
@@ -124,8 +158,8 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
     l.hist = o;    o = align16(o + (size_t)4 * kBins);
     l.sel_c = o;   o = align16(o + (size_t)20 * max_sel);               // canonical selected boxes [5][max_sel]
     l.sel_idx = o; o = align16(o + (size_t)4 * max_sel);
-    l.cbox = o;    o = align16(o + (size_t)20 * kChunk);                // canonical chunk boxes [5][kChunk]
-    l.mask = o;    o = align16(o + (size_t)8 * kChunk * kChunkWords);   // [kChunk][4] u64
+    l.cbox = o;    o = align16(o + (size_t)20 * kChunk);                // canonical chunk boxes: float4 [kChunk] + area [kChunk]
+    l.mask = o;    o = align16(o + (size_t)8 * 64 * kChunkWords);       // [64 rows of the current group][4] u64
     l.dead = o;    o = align16(o + (size_t)8 * kChunkWords);            // 4 u64 words
     l.picked = o;  o = align16(o + (size_t)4 * kChunk);
     l.ctl = o;     o = align16(o + 64);
@@ -134,7 +168,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
 }
 
 // ctl words
-enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by radix_select */ };
+enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by radix_select */, CTL_LOW = 8 /* u64 */ };
 
 template <bool DECODE>
 __global__ void __launch_bounds__(kNmsThreads)
@@ -147,10 +181,10 @@ nms_kernel(NmsArgs p)
     unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
     float *sel_c = reinterpret_cast<float *>(smem + L.sel_c);
     int *sel_idx = reinterpret_cast<int *>(smem + L.sel_idx);
-    float *cbox = reinterpret_cast<float *>(smem + L.cbox);
+    float4 *cbox4 = reinterpret_cast<float4 *>(smem + L.cbox);               // canonical chunk boxes (ymin, xmin, ymax, xmax)
+    float *carea = reinterpret_cast<float *>(smem + L.cbox) + 4 * kChunk;    // ... and their areas
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem + L.mask);
     unsigned long long *deadw = reinterpret_cast<unsigned long long *>(smem + L.dead);
-    int *picked = reinterpret_cast<int *>(smem + L.picked);
     int *ctl = reinterpret_cast<int *>(smem + L.ctl);
 
     const int tid = threadIdx.x;
@@ -170,32 +204,64 @@ nms_kernel(NmsArgs p)
     while (true) {
         // ================= 1. pick the next band: keys in [thr, hi_bound) ==========================
         int band_expected = 0;
+        // band size: a few times the number of boxes still wanted (most images finish inside the first band), so that
+        // the sort below is a 1024-key rank sort instead of a 4096-key bitonic network
+        const int want_left = max_sel - ctl[CTL_NSEL];
+        const int band_target = min(kBandTarget, max(512, 2 * want_left));
+        const int band_cap = band_target <= 768 ? 1024 : kBandCap;
         const unsigned long long thr = radix_select<kNmsThreads>(
-            [&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound, kBandTarget, kBandCap, hist,
+            [&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound, band_target, band_cap, hist,
             ctl + CTL_SEL, &band_expected);
         if (thr == 0ull) break;              // nothing left
+        if (p.stop_after == 1) return;
 
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
         if (tid == 0) ctl[CTL_BANDN] = 0;
         __syncthreads();
-        for (int i = tid; i < N; i += kNmsThreads) {
-            const unsigned long long key = make_key(sc[(size_t)i * C], p.score_thr, i);
-            if (key >= thr && key < hi_bound && key != 0ull) {
-                const int slot = atomicAdd(&ctl[CTL_BANDN], 1);
-                if (slot < kBandCap) band[slot] = key;
+        for (int base = tid; base < N; base += 8 * kNmsThreads) {       // loads batched as in radix_select
+            unsigned long long kb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * kNmsThreads;
+                kb[u] = i < N ? make_key(sc[(size_t)i * C], p.score_thr, i) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long key = kb[u];
+                const bool in = key >= thr && key < hi_bound && key != 0ull;
+                // one LDS atomic per wave: slots handed out by ballot rank (the band is sorted afterwards, so the order
+                // of the slots is irrelevant)
+                const unsigned long long bal = __ballot(in);
+                if (bal) {
+                    int slot0 = 0;
+                    if (lane == __ffsll((long long)bal) - 1) slot0 = atomicAdd(&ctl[CTL_BANDN], __popcll(bal));
+                    slot0 = __shfl(slot0, __ffsll((long long)bal) - 1, 64);
+                    const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (in && slot < kBandCap) band[slot] = key;
+                }
             }
         }
         __syncthreads();
+        if (p.stop_after == 3) return;
         int band_n = ctl[CTL_BANDN];
         if (band_n > kBandCap) band_n = kBandCap;    // cannot happen: the select guarantees <= kBandCap
         if (band_n == 0) break;
-        int n_sort = 2;
-        while (n_sort < band_n) n_sort <<= 1;
-        for (int i = band_n + tid; i < n_sort; i += kNmsThreads) band[i] = 0ull;
-        __syncthreads();
-        bitonic_sort_desc(band, n_sort);
-        if (p.stop_after == 2) return;
-        {   // keys -> 32-bit box indices, in place (read all, barrier, write)
+        if (band_n <= kNmsThreads) {
+            // one key per thread; keys -> box indices in place (order aliases band: every key is in a register first)
+            const unsigned long long sorted = bitonic1024_desc(tid < band_n ? band[tid] : 0ull, band);
+            if (p.stop_after == 2) return;
+            if (tid < band_n) order[tid] = 0xFFFFFFFFu - (unsigned)(sorted & 0xFFFFFFFFull);
+            if (tid == band_n - 1) *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW) = sorted;
+            __syncthreads();
+            hi_bound = *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW);     // the next band continues strictly below
+        } else {
+            int n_sort = 2;
+            while (n_sort < band_n) n_sort <<= 1;
+            for (int i = band_n + tid; i < n_sort; i += kNmsThreads) band[i] = 0ull;
+            __syncthreads();
+            bitonic_sort_desc(band, n_sort);
+            if (p.stop_after == 2) return;
+            // keys -> 32-bit box indices, in place (read all, barrier, write)
             unsigned idx_reg[kBandCap / kNmsThreads];
 #pragma unroll
             for (int j = 0; j < kBandCap / kNmsThreads; ++j) {
@@ -223,93 +289,132 @@ nms_kernel(NmsArgs p)
 
             if (tid < kChunk && tid < T) {           // chunk boxes -> canonical form in LDS
                 const CBox cb = canonical(fetch_box<DECODE>(p, b, (int)order[pos + tid], qc));
-                cbox[0 * kChunk + tid] = cb.ymin;
-                cbox[1 * kChunk + tid] = cb.xmin;
-                cbox[2 * kChunk + tid] = cb.ymax;
-                cbox[3 * kChunk + tid] = cb.xmax;
-                cbox[4 * kChunk + tid] = cb.area;
+                const int st = cslot(tid);
+                cbox4[st] = make_float4(cb.ymin, cb.xmin, cb.ymax, cb.xmax);
+                carea[st] = cb.area;
             }
             if (tid < kChunkWords) deadw[tid] = 0ull;
             __syncthreads();
 
-            // (A) chunk candidate t vs selected boxes j = part, part+4, ...  (4 waves per part; every lane of
-            //     a wave reads the same selected box: LDS broadcast); dead bits gathered with one ballot per wave
-            {
-                const int t = tid & (kChunk - 1);
-                const int part = tid >> 8;
-                bool hit = t >= T;                                      // slots past the band end count as dead
-                if (t < T && nsel > 0) {
-                    const CBox ci{cbox[0 * kChunk + t], cbox[1 * kChunk + t], cbox[2 * kChunk + t],
-                                  cbox[3 * kChunk + t], cbox[4 * kChunk + t]};
-                    for (int j = part; j < nsel; j += 4) {
-                        const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
-                                      sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
-                        hit |= nms_iou(ci, sj) > p.iou_thr;
-                    }
-                }
-                const unsigned long long bal = __ballot(hit);
-                if (lane == 0 && bal) atomicOr(&deadw[(tid >> 6) & (kChunkWords - 1)], bal);
+            if (tid < kChunkWords) {                 // slots past the band end count as dead
+                const int lo = tid * 64;
+                if (T < lo + 64) deadw[tid] = T <= lo ? ~0ull : (~0ull << (T - lo));
             }
             __syncthreads();
+            if (p.stop_after == 4) return;
 
-            // (B) intra-chunk suppression bits for live pairs only: mask[i][w] bit jj set iff live candidate
-            //     j = 64w+jj (j > i) would be suppressed by live candidate i
-            {
-                const int i = tid >> 2;
-                const int w = tid & 3;
-                unsigned long long bits = 0ull;
-                const bool i_dead = (deadw[i >> 6] >> (i & 63)) & 1ull;
-                if (!i_dead && (w * 64 + 63) > i) {
-                    const CBox si{cbox[0 * kChunk + i], cbox[1 * kChunk + i], cbox[2 * kChunk + i],
-                                  cbox[3 * kChunk + i], cbox[4 * kChunk + i]};
-                    unsigned long long todo = ~deadw[w];
-                    if ((i >> 6) == w) todo &= (~0ull << (i & 63)) << 1;       // only j > i
-                    while (todo) {
-                        const int jj = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1ull;
-                        const int j = w * 64 + jj;
-                        const CBox cj{cbox[0 * kChunk + j], cbox[1 * kChunk + j], cbox[2 * kChunk + j],
-                                      cbox[3 * kChunk + j], cbox[4 * kChunk + j]};
-                        if (nms_iou(cj, si) > p.iou_thr) bits |= (1ull << jj);
+            // The chunk is walked in 4 groups of 64 candidates (one 64-bit word of the live mask).  Per group:
+            // (B) all 16 waves build the suppression rows of the group's LIVE candidates against the live candidates after
+            //     them: thread (i = tid / 16, piece = tid % 16) produces 16 bits of row i.  Rows of later groups are only
+            //     built if the walk gets there (a chunk that fills the output early costs one group, not a 256 x 256 matrix).
+            // (C) wave 0 walks the group.  Lane l holds row l's own-group word in registers, the live word lives in scalar
+            //     registers: one selection = find-first-set + two v_readlane (the selected row) + and-not, no LDS round
+            //     trip (the first version read the row from LDS per selection: 245 cycles each, 30 us per full chunk).
+            //     Selected lanes then OR the rest of their rows into the dead words of the later groups and append
+            //     themselves to the selected list at position nsel + (rank among the group's selected).
+            int cur = nsel;                                          // uniform: re-read from LDS after every group
+            for (int gw = 0; gw < kChunkWords && gw * 64 < T && cur < max_sel; ++gw) {
+                // (A) the group's candidates against the boxes selected in EARLIER chunks (this chunk's selections reach
+                //     later groups through the row ORs below): thread (candidate = tid / 16, part = tid % 16) tests selected
+                //     boxes part, part + 16, ... (LDS broadcast within a part).  Done per group, so a chunk that completes
+                //     the output after one group tests 64 x nsel pairs, not 256 x nsel.
+                if (nsel > 0) {
+                    const int il = tid >> 4, part = tid & 15;
+                    const int t = gw * 64 + il;
+                    bool hit = false;
+                    if (t < T) {
+                        const int st = cslot(t);
+                        const float4 c4 = cbox4[st];
+                        const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
+                        for (int j = part; j < nsel; j += 16) {
+                            const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
+                                          sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
+                            hit |= nms_suppresses(ci, sj, p.iou_thr, p.iou_lo, p.iou_hi);
+                        }
                     }
-                }
-                mask[i * kChunkWords + w] = bits;
-            }
-            __syncthreads();
-
-            // (C) serial walk by wave 0: lane w < 4 owns live-mask word w; per selected box one LDS round trip
-            if (tid < 64) {
-                unsigned long long rem = (lane < kChunkWords) ? deadw[lane] : ~0ull;
-                int cur = nsel;
-                while (cur < max_sel) {
-                    const unsigned long long avail = ~rem;
-                    const int mine = avail ? (lane * 64 + __ffsll((long long)avail) - 1) : (1 << 30);
-                    int first = __builtin_amdgcn_readlane(mine, 0);
-                    first = min(first, __builtin_amdgcn_readlane(mine, 1));
-                    first = min(first, __builtin_amdgcn_readlane(mine, 2));
-                    first = min(first, __builtin_amdgcn_readlane(mine, 3));
-                    if (first >= T) break;
-                    if (lane == 0) picked[cur - nsel] = first;
-                    ++cur;
-                    if (lane < kChunkWords) {
-                        rem |= mask[first * kChunkWords + lane];
-                        if ((first >> 6) == lane) rem |= 1ull << (first & 63);
-                    }
-                }
-                // copy the picked boxes to the selected list (all 64 lanes)
-                const int npick = cur - nsel;
-                for (int t = lane; t < npick; t += 64) {
-                    const int i = picked[t];
+                    // lanes 16q .. 16q+15 of a wave belong to candidate 4 * wave + q
+                    const unsigned long long bal = __ballot(hit);
+                    if (lane == 0 && bal) {
+                        unsigned long long bits = 0ull;
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) sel_c[k * max_sel + nsel + t] = cbox[k * kChunk + i];
-                    sel_idx[nsel + t] = (int)order[pos + i];
+                        for (int q = 0; q < 4; ++q)
+                            if ((bal >> (16 * q)) & 0xFFFFull) bits |= 1ull << (4 * (tid >> 6) + q);
+                        atomicOr(&deadw[gw], bits);
+                    }
+                    __syncthreads();
                 }
-                if (lane == 0) {
-                    ctl[CTL_NSEL] = cur;
-                    ctl[CTL_POS] = pos + T;
+                {
+                    const int il = tid >> 4, piece = tid & 15;
+                    const int i = gw * 64 + il;
+                    unsigned bits = 0u;
+                    const bool i_dead = (deadw[gw] >> il) & 1ull;
+                    const int j0 = piece * 16;
+                    if (!i_dead && j0 + 15 > i) {
+                        const int is = cslot(i);
+                        const float4 s4 = cbox4[is];
+                        const CBox si{s4.x, s4.y, s4.z, s4.w, carea[is]};
+                        unsigned todo = (unsigned)(~deadw[piece >> 2] >> ((piece & 3) * 16)) & 0xFFFFu;
+                        if (j0 <= i) todo &= (0xFFFFu << (i - j0)) << 1;        // only j > i
+                        // all 16 candidates of the piece, unconditionally (one 16-byte + one 4-byte conflict-free LDS read
+                        // each, no find-first-set loop); the bits of dead candidates are masked off afterwards
+#pragma unroll 4
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const int js = (jj << 4) | piece;               // cslot(j0 + jj)
+                            const float4 q4 = cbox4[js];
+                            const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
+                            if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                        }
+                        bits &= todo;
+                    }
+                    reinterpret_cast<unsigned short *>(mask)[il * 16 + piece] = (unsigned short)bits;
                 }
+                __syncthreads();
+                if (p.stop_after == 5) return;
+                if (tid < 64) {
+                    const unsigned long long own = mask[lane * kChunkWords + gw];
+                    const unsigned own_lo = (unsigned)own, own_hi = (unsigned)(own >> 32);
+                    const unsigned long long dead0 = deadw[gw];
+                    // live candidates of the group, uniform (scalar registers); slots past the band end are dead already
+                    // (the builtins return int: widen through unsigned, or bit 31 sign-extends over the upper word)
+                    unsigned long long avail =
+                        ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dead0 >> 32)) << 32) |
+                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dead0));
+                    unsigned long long selmask = 0ull;
+                    int c2 = cur;
+                    while (avail != 0ull && c2 < max_sel) {
+                        const int i = __ffsll((long long)avail) - 1;
+                        selmask |= 1ull << i;
+                        ++c2;
+                        const unsigned long long row =
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)own_hi, i) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)own_lo, i);
+                        avail &= ~(row | (1ull << i));
+                    }
+                    const bool picked_me = (selmask >> lane) & 1ull;
+                    if (picked_me) {
+                        const int slot = cur + __popcll(selmask & ((1ull << lane) - 1ull));
+                        const int i = gw * 64 + lane;
+                        const float4 b4 = cbox4[cslot(i)];
+                        sel_c[0 * max_sel + slot] = b4.x;
+                        sel_c[1 * max_sel + slot] = b4.y;
+                        sel_c[2 * max_sel + slot] = b4.z;
+                        sel_c[3 * max_sel + slot] = b4.w;
+                        sel_c[4 * max_sel + slot] = carea[cslot(i)];
+                        sel_idx[slot] = (int)order[pos + i];
+                        for (int w = gw + 1; w < kChunkWords; ++w) {
+                            const unsigned long long r = mask[lane * kChunkWords + w];
+                            if (r) atomicOr(&deadw[w], r);
+                        }
+                    }
+                    if (lane == 0) ctl[CTL_NSEL] = c2;
+                }
+                __syncthreads();
+                cur = ctl[CTL_NSEL];
+                if (p.stop_after == 6) return;
             }
+            if (tid == 0) ctl[CTL_POS] = pos + T;
             __syncthreads();
+            if (p.stop_after == 7) return;
         }
         if (ctl[CTL_NSEL] >= max_sel) break;
         __syncthreads();
@@ -317,6 +422,7 @@ nms_kernel(NmsArgs p)
     __syncthreads();
 
     // ================= 3. outputs =================================================================
+    if (p.stop_after == 8) return;
     const int nsel = ctl[CTL_NSEL];
     if (p.C == 1) {
         const int M = p.max_total;
@@ -429,6 +535,13 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
 {
     static const int stop = getenv("RPN_NMS_STOP") ? atoi(getenv("RPN_NMS_STOP")) : 0;
     p.stop_after = stop;
+    if (p.iou_thr > 0.0f && p.iou_thr < INFINITY) {
+        p.iou_lo = p.iou_thr * (1.0f - 0x1p-18f);
+        p.iou_hi = p.iou_thr * (1.0f + 0x1p-18f);
+    } else {
+        p.iou_lo = -INFINITY;
+        p.iou_hi = INFINITY;
+    }
     const LdsLayout L = lds_layout(p.max_sel);
     if (L.total > kLdsLimit)
         return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,

@@ -88,7 +88,7 @@ iou_argmax_kernel(TargetArgs p)
 __global__ void __launch_bounds__(kTgtThreads)
 target_select_kernel(TargetArgs p)
 {
-    __shared__ unsigned hist[kRsBins];
+    __shared__ unsigned hist[kRsHistWords];
     __shared__ int ctl[8];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
