@@ -11,7 +11,7 @@ raw = ctypes.CDLL(L.LIB_PATH)
 raw.rpn_debug_read_ir_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 hp = dict(bo.get_hyper_params("mobilenet_v2"))
 B = 8
-m = RPNModel("mobilenet_v2", hp, precision="f32", max_batch=B)
+m = RPNModel("mobilenet_v2", hp, precision=os.environ.get("RPN_PROBE_PRECISION", "f32"), max_batch=B)
 m.set_weights(synthetic_weights("mobilenet_v2", hp, seed=1))
 x = torch.rand((B, 500, 500, 3), device="cuda")
 F, K = m.feature_map_shape, m.anchor_count
@@ -35,8 +35,8 @@ print("  tile load: %d cycles" % med(s[:, 1] - s[:, 0]))
 prev = s[:, 1]
 for it in range(nit):
     e, p, d, b = s[:, 2 + 4 * it], s[:, 3 + 4 * it], s[:, 4 + 4 * it], s[:, 5 + 4 * it]
-    x = [s[:, 64 + 4 * it + j] for j in range(3)]
+    x = [s[:, 64 + 4 * it + j] for j in range(4)]
     xs = " ".join("%6d" % (med(v - prev) if (v > 0).all() else -1) for v in x)
-    print("  step %2d: E done +%6d  P done +%6d  D done +%6d  barrier +%6d   | service: window read, fetch issued, staged+copied: %s" % (it, med(e - prev) if (e > 0).all() else -1, med(p - prev), med(d - prev) if (d > 0).all() else -1, med(b - prev), xs))
+    print("  step %2d: E done +%6d  P done +%6d  D done +%6d  barrier +%6d   | service: window read, fetch issued, copied, stored: %s" % (it, med(e - prev) if (e > 0).all() else -1, med(p - prev), med(d - prev) if (d > 0).all() else -1, med(b - prev), xs))
     prev = b
 print("  total %d cycles" % med(prev - s[:, 0]))

@@ -66,6 +66,16 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
                            bool stem, int pad, int OH, int OW, const float *we, const float *be, const float *wd,
                            const float *bd, const float *wp, const float *bp, float *out, hipStream_t s);
 
+// f16x3 variant for the low-resolution blocks (Cin = 64 / 96, stride 1; precision F16X3 only): both GEMMs on the 16-bit
+// MFMA with hi + lo float16 operands.  we / wp: fragment-major images from pack_ir_x3_expand / _project (same byte
+// counts as the float32 matrices), scale = 2^-shift of their power-of-two pre-scale.
+bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual);
+void pack_ir_x3_expand(const float *w, int K, int CEXP, int shift, unsigned short *dst);
+void pack_ir_x3_project(const float *w, int CEXP, int COUT, int shift, unsigned short *dst);
+hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int cexp, int cout, bool residual,
+                              const void *we, const float *be, const float *wd, const float *bd, const void *wp,
+                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, hipStream_t s);
+
 // Device word into which the split-format writers launched from THIS host thread flag float16 range violations
 // (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.
 void set_range_status(unsigned *p);

@@ -32,8 +32,10 @@
 // compute (6*10)/(4*8) = 1.9x (stride 1) / (9*17)/(8*16) = 1.2x its algorithmic work.
 #include "conv_kernels.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 // Debug build only (-DRPN_STAMP, scripts/ir_stamp_probe.py): cycle stamps of the pipeline's phases, 64 slots per
 // workgroup for the first 512 workgroups: [0] start, [1] input tile in LDS, then per step it: [2+4it] wave 0 after E,
@@ -150,6 +152,9 @@ ir_block_kernel(IrArgs a)
     const int dpad = STEM ? 1 : a.pad;
     const int gy0 = oy0 * S - dpad, gx0 = ox0 * S - dpad;   // halo origin on the depthwise's input grid
     IR_STAMP(0, 0);
+    // Issue arbitration between the two waves of a SIMD is by priority, then age: the service waves (4-7) are the younger
+    // ones and would only get the slots the matrix waves leave (measured: their step started when the matrix waves' ended).
+    if (wave >= 4) __builtin_amdgcn_s_setprio(2);
 
     // ---- service waves: weight staging (global -> registers now, registers -> LDS at the end of the step) ----------
     f32x4 we_st[NWE], wp_st[NWP];
@@ -197,13 +202,12 @@ ir_block_kernel(IrArgs a)
     constexpr int PG = CE <= 16 ? 4 : (CE <= 32 ? 2 : 1);   // pixel groups per output row
     constexpr int PXG = IR_TW / PG;                          // output pixels per lane
     const int dn = lane % (64 / PG), dg = lane / (64 / PG);
+    const int dnc = dn < CE ? dn : CE - 1;                  // lanes beyond the chunk repeat its last channel (no predicates)
     float wd_cur[10], wd_nxt[10];
     auto wd_fetch = [&](int c) __attribute__((always_inline)) {
-        if (dn < CE) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
-            wd_nxt[9] = a.bd[c * CE + dn];
-        }
+        for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dnc];
+        wd_nxt[9] = a.bd[c * CE + dnc];
     };
     if (wave >= 4) we_fetch(0);                              // in flight while the input tile is loaded
 
@@ -248,6 +252,7 @@ ir_block_kernel(IrArgs a)
             }
     } else {
         we_store(0);
+        if (NCHUNK > 1) we_fetch(1);                         // put in place at the start of step 0
     }
     __syncthreads();
     IR_STAMP(0, 1);
@@ -388,15 +393,27 @@ ir_block_kernel(IrArgs a)
             IR_STAMP(0, 3 + 4 * it);
         } else {
             // ---- service waves --------------------------------------------------------------------------------------------
-            const bool st_we = it + 1 < NCHUNK, st_wp = it >= 1 && it <= NCHUNK;
-            if (it >= 1 && it <= NCHUNK && dn < CE) {
+            // Staging runs one step ahead of its use AND one step behind its loads: what was requested at the start of the
+            // previous step (We(it+1), Wp(it-1), the depthwise weights of chunk it-1) has had a whole step to arrive and
+            // is put in place now; then the requests for the next step go out; then the depthwise.  (No lane predicates
+            // on these loads: with exec-masked loads in flight the compiler parks a vmcnt(0) in front of the depthwise.)
+#pragma unroll
+            for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
+            if (it + 1 < NCHUNK) we_store((it + 1) & 1);
+            if (it >= 1 && it <= NCHUNK) wp_store((it - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < NCHUNK) we_fetch(it + 2);
+            if (it < NCHUNK) wp_fetch(it);
+            if (it < NCHUNK) wd_fetch(it);
+            IR_STAMP(4, 65 + 4 * it);
+            if (it >= 1 && it <= NCHUNK) {
                 // D(it-1): depthwise 3x3 + bias + ReLU6 on chunk it-1.  wave - 4 = output row; lane = (channel dn, pixel
                 // group dg): PXG consecutive output pixels of the row per lane (8 for CE > 32, 4 for CE = 32, 2 for CE = 16,
                 // so that small chunks still use all 64 lanes).  The lane's 3 x ((PXG-1)*S + 3) input window is read
-                // once, then 9 FMAs per output.
+                // once, then 9 FMAs per output.  Lanes beyond CE (CE = 48) compute channel CE-1 again and do not store.
                 const int c = it - 1;
-                const float *es = Es[c & 1] + dn;
-                float *ds = Ds[c & 1] + dn;
+                const float *es = Es[c & 1] + dnc;
+                float *ds = Ds[c & 1] + dnc;
                 const int py = wave - 4;
                 constexpr int WW = (PXG - 1) * S + 3;
                 float win[3][WW];
@@ -413,22 +430,10 @@ ir_block_kernel(IrArgs a)
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_cur[r * 3 + q], acc);
-                    ds[(py * IR_TW + dg * PXG + px) * SD] = relu6f(acc);
+                    if (dn < CE) ds[(py * IR_TW + dg * PXG + px) * SD] = relu6f(acc);
                 }
             }
             IR_STAMP(4, 4 + 4 * it);
-            // weight staging AFTER the depthwise: the service waves have slack (their step is shorter than the matrix
-            // waves'), and with the loads issued first the compiler parks a vmcnt(0) in front of the depthwise
-            __builtin_amdgcn_sched_barrier(0);
-            if (st_we) we_fetch(it + 1);
-            if (st_wp) wp_fetch(it - 1);
-            if (it < NCHUNK) wd_fetch(it);
-            IR_STAMP(4, 65 + 4 * it);
-            if (st_we) we_store((it + 1) & 1);
-            if (st_wp) wp_store((it - 1) & 1);
-#pragma unroll
-            for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
-            IR_STAMP(4, 66 + 4 * it);
         }
         __syncthreads();
         IR_STAMP(0, 5 + 4 * it);
@@ -456,6 +461,368 @@ ir_block_kernel(IrArgs a)
             }
         }
     }
+}
+
+// ---- f16x3 variant for the low-resolution blocks (Cin = 64 / 96, stride 1) -----------------------------------------
+// Same pipeline (E / D / P over two wave groups, one barrier per step), but the two GEMMs run on
+// v_mfma_f32_16x16x32_f16 with every float32 operand carried as hi + lo float16 halves and each product formed as
+// lo*hi + hi*lo + hi*hi with float32 accumulation (product error ~2^-21, the arithmetic the f16x3 mode
+// already uses in the 3x3 layers).  Why only here: the float32 MFMA runs at 1/16 of the 16-bit rate AND shares the
+// SIMD's issue port with the vector ALU, so on these blocks (one workgroup per CU, 72 + 36 f32 MFMAs per wave and
+// step) the matrix work was the whole step; on the 16-bit MFMA it is 27 + 18 instructions of 16 cycles on the separate
+// matrix pipe and the step becomes the service waves' vector work.  The high-resolution blocks (Cin <= 32) are bound by
+// that vector work already and keep the exact-f32 kernel.
+// Operand images in LDS are FRAGMENT-MAJOR: one 1 KB block per (16-row block, 32-deep k-step, hi | lo) holding the 64
+// lanes' 16-byte fragments in lane order (lane = 16 * (k / 8 % 4) + row), so every MFMA operand read is one linear,
+// conflict-free ds_read_b128.  Weights are packed that way on the host (per chunk of 32 expanded channels), so staging
+// them is a linear copy.  CE = 32.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+struct IrX3Args {
+    const float *x;
+    float *out;
+    const u32x4 *we;      // [chunk][nb 2][ks K/32][hi|lo][64 lanes] fragments of the expand weights * 2^shift_e
+    const u32x4 *wp;      // [chunk][nb COUT/16][hi|lo][64 lanes] fragments of the projection weights * 2^shift_p
+    const float *be, *wd, *bd, *bp;
+    float scale_e, scale_p;    // 2^-shift
+    int B, H, W, tiles_x, tiles_y;
+    unsigned *status;     // float16 range flag (block input beyond 65504), or null
+    int stamp;
+};
+
+__device__ __forceinline__ f32x4 mfma_x3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 blo, f32x4 c)
+{
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, alo), __builtin_bit_cast(f16x8, bhi), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ahi), __builtin_bit_cast(f16x8, blo), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ahi), __builtin_bit_cast(f16x8, bhi), c, 0, 0, 0);
+}
+
+template <int KP, int CEXP, int COUT, bool RES>
+__global__ void __launch_bounds__(IR_THREADS)
+ir_block_x3_kernel(IrX3Args a)
+{
+    constexpr int S = 1, CE = 32;
+    constexpr int IH = IR_TH + 2, IW = IR_TW + 2, NH = IH * IW;           // 6 x 10 halo pixels
+    constexpr int MB = 4, MH = 64;                                        // expand M-blocks: one per matrix wave
+    constexpr int KS = KP / 32;                                           // k-steps of the expand GEMM
+    constexpr int NBE = CE / 16, NCHUNK = CEXP / CE;
+    constexpr int SEP = CE + 4;
+    constexpr int NBO = COUT / 16, NJ = NBO / 2;                          // projection N-blocks, per wave
+    constexpr int WE_P = NBE * KS * 2 * 64, WP_P = NBO * 2 * 64;          // 16-byte pieces per chunk of We / Wp
+    constexpr int NWE = (WE_P + 255) / 256, NWP = (WP_P + 255) / 256;
+    static_assert(KP % 32 == 0 && CEXP % CE == 0 && COUT % 32 == 0 && (!RES || KP == COUT), "shape");
+
+    __shared__ u32x4 XsF[MB * KS * 2 * 64];                               // [mb][ks][hi|lo][lane]
+    __shared__ __attribute__((aligned(16))) float Es[2][MH * SEP];
+    __shared__ u32x4 DsF[2][2 * 2 * 64];                                  // [slot][mb 2][hi|lo][lane]  (K = CE = one k-step)
+    __shared__ u32x4 WeS[2][WE_P];
+    __shared__ u32x4 WpS[2][WP_P];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int stid = tid;                                     // weight staging is done by the MATRIX waves here (they have the slack)
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int img = t / a.tiles_y;
+    const int oy0 = ty * IR_TH, ox0 = tx * IR_TW;
+    const int gy0 = oy0 - 1, gx0 = ox0 - 1;
+    IR_STAMP(0, 0);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(2);            // (see ir_block_kernel)
+
+    u32x4 we_st[NWE], wp_st[NWP];
+    auto we_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i)
+            if (WE_P % 256 == 0 || stid + 256 * i < WE_P) we_st[i] = a.we[(size_t)c * WE_P + stid + 256 * i];
+    };
+    auto we_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i)
+            if (WE_P % 256 == 0 || stid + 256 * i < WE_P) WeS[slot][stid + 256 * i] = we_st[i];
+    };
+    auto wp_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            if (WP_P % 256 == 0 || stid + 256 * i < WP_P) wp_st[i] = a.wp[(size_t)c * WP_P + stid + 256 * i];
+    };
+    auto wp_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            if (WP_P % 256 == 0 || stid + 256 * i < WP_P) WpS[slot][stid + 256 * i] = wp_st[i];
+    };
+    constexpr int PG = 2, PXG = IR_TW / PG;                              // depthwise: lane = (channel dn, pixel group dg)
+    const int dn = lane & 31, dg = lane >> 5;
+    float wd_cur[10], wd_nxt[10];
+    auto wd_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
+        wd_nxt[9] = a.bd[c * CE + dn];
+    };
+    if (wave < 4) we_fetch(0);
+
+    // ---- 1. input tile: float32 NHWC -> hi / lo float16, fragment-major ---------------------------------------------
+    {
+        constexpr int CQ = KP / 4;
+        const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * KP;
+        _Float16 *xh = reinterpret_cast<_Float16 *>(XsF);
+        for (int idx = tid; idx < MH * CQ; idx += IR_THREADS) {
+            const int m = idx / CQ, cq = idx - m * CQ;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const float4 *>(xin + ((size_t)gy * a.W + gx) * KP + 4 * cq);
+            if (a.status && !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65504.0f))
+                atomicOr(a.status, 1u);
+            const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const f16x4 lo = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                              (_Float16)(v.w - (float)hi[3])};
+            const int c0 = 4 * cq, ks = c0 >> 5, kq = (c0 >> 3) & 3, j0 = c0 & 7;
+            const int blk = ((m >> 4) * KS + ks) * 2;                     // hi block; lo block = blk + 1
+            const int off = ((kq * 16 + (m & 15)) * 8 + j0);             // halves inside the 1 KB block
+            *reinterpret_cast<f16x4 *>(xh + (size_t)blk * 512 + off) = hi;
+            *reinterpret_cast<f16x4 *>(xh + (size_t)(blk + 1) * 512 + off) = lo;
+        }
+    }
+    unsigned vmask = 0;
+    if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = wave * 16 + 4 * lk + i;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) vmask |= 1u << i;
+        }
+        we_store(0);
+        if (NCHUNK > 1) we_fetch(1);                         // put in place at the start of step 0
+    }
+    __syncthreads();
+    IR_STAMP(0, 1);
+
+    f32x4 pacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias_nxt[NBE];
+#pragma unroll
+    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[nb * 16 + lr];
+    const int mbp = wave & 1, nbp = (wave >> 1) & 1;
+
+    for (int it = 0; it < NCHUNK + 2; ++it) {
+        if (wave < 4) {
+            // Weight staging, one step ahead of its use and one step behind its loads: what was requested at the start of
+            // the previous step (We(it+1), Wp(it-1)) has had a whole step to arrive and is put in place now, then the next
+            // requests go out.  Done by the matrix waves: on the 16-bit MFMA their step is shorter than the service waves'.
+            if (it + 1 < NCHUNK) we_store((it + 1) & 1);
+            if (it >= 1 && it <= NCHUNK) wp_store((it - 1) & 1);
+            // the expand bias of the NEXT chunk is requested BEFORE the weight fragments: vmcnt retires loads in order, and
+            // the register copy that hands it to the next step sits at the end of E -- behind the weight requests it would
+            // wait for all of them (measured: +1.1 k cycles per step)
+            float biasv[NBE];
+#pragma unroll
+            for (int nb = 0; nb < NBE; ++nb) biasv[nb] = bias_nxt[nb];
+            if (it + 1 < NCHUNK) {
+#pragma unroll
+                for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[(it + 1) * CE + nb * 16 + lr];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < NCHUNK) we_fetch(it + 2);
+            if (it < NCHUNK) wp_fetch(it);
+            // operands of P(it-2) first: they are ready when the step starts, and their LDS latency then hides behind E
+            u32x4 dhi, dlo, pb[NJ][2];
+            if (it >= 2) {
+                const u32x4 *dsf = DsF[it & 1];
+                const u32x4 *wps = WpS[it & 1];
+                dhi = dsf[(mbp * 2 + 0) * 64 + lane];
+                dlo = dsf[(mbp * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int nb = nbp + 2 * j;
+                    pb[j][0] = wps[(nb * 2 + 0) * 64 + lane];
+                    pb[j][1] = wps[(nb * 2 + 1) * 64 + lane];
+                }
+            }
+            if (it < NCHUNK) {
+                // ---- E(it): one M-block (16 halo pixels) x 2 N-blocks x KS k-steps x 3 MFMAs ---------------------------
+                const u32x4 *wes = WeS[it & 1];
+                u32x4 xa[KS][2], wb[KS][NBE][2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    xa[ks][0] = XsF[((wave * KS + ks) * 2 + 0) * 64 + lane];
+                    xa[ks][1] = XsF[((wave * KS + ks) * 2 + 1) * 64 + lane];
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb) {
+                        wb[ks][nb][0] = wes[((nb * KS + ks) * 2 + 0) * 64 + lane];
+                        wb[ks][nb][1] = wes[((nb * KS + ks) * 2 + 1) * 64 + lane];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 eacc[NBE];
+#pragma unroll
+                for (int nb = 0; nb < NBE; ++nb) eacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb) eacc[nb] = mfma_x3(xa[ks][0], xa[ks][1], wb[ks][nb][0], wb[ks][nb][1], eacc[nb]);
+                float *es = Es[it & 1];
+#pragma unroll
+                for (int nb = 0; nb < NBE; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        es[(wave * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
+                            ((vmask >> i) & 1u) ? relu6f(eacc[nb][i] * a.scale_e + biasv[nb]) : 0.0f;
+            }
+            IR_STAMP(0, 2 + 4 * it);
+            if (it >= 2) {
+                // ---- P(it-2): acc (32 px x COUT) += D (32 x 32) * Wp[chunk it-2] ---------------------------------------------
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) pacc[j] = mfma_x3(dhi, dlo, pb[j][0], pb[j][1], pacc[j]);
+            }
+            IR_STAMP(0, 3 + 4 * it);
+        } else {
+            // Staging runs one step ahead of its use AND one step behind its loads: what was requested at the start of the
+            // previous step (We(it+1), Wp(it-1), the depthwise weights of chunk it-1) has had a whole step to arrive and
+            // is put in place now; then the requests for the next step go out; then the depthwise.
+#pragma unroll
+            for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
+            IR_STAMP(4, 66 + 4 * it);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < NCHUNK) wd_fetch(it);
+            IR_STAMP(4, 65 + 4 * it);
+            if (it >= 1 && it <= NCHUNK) {
+                // ---- D(it-1): depthwise 3x3 + bias + ReLU6, then hi / lo float16 into P's A-operand image ----------------
+                const int c = it - 1;
+                const float *es = Es[c & 1] + dn;
+                const int py = wave - 4;
+                constexpr int WW = (PXG - 1) * S + 3;
+                float win[3][WW];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < WW; ++x) win[r][x] = es[((py * S + r) * IW + dg * PXG * S + x) * SEP];
+                __builtin_amdgcn_sched_barrier(0);
+                IR_STAMP(4, 64 + 4 * it);
+                unsigned *dw32 = reinterpret_cast<unsigned *>(DsF[c & 1]);
+                const int kq = dn >> 3, jp = (dn & 7) >> 1, odd = dn & 1;
+#pragma unroll
+                for (int px = 0; px < PXG; ++px) {
+                    float acc = wd_cur[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_cur[r * 3 + q], acc);
+                    const float v = relu6f(acc);
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const unsigned hu = __builtin_bit_cast(unsigned short, h), lu = __builtin_bit_cast(unsigned short, l);
+                    // lanes (2t, 2t+1) = channels (2t, 2t+1): the even lane writes the pair's hi dword, the odd lane its lo dword
+                    // (neighbour exchange as a DPP quad permutation [1,0,3,2]: one vector instruction; __shfl_xor is a
+                    // ds_bpermute with an LDS round trip behind each of the 4 outputs)
+                    const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
+                    const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
+                    const int p = py * IR_TW + dg * PXG + px;
+                    const int blk = (p >> 4) * 2 + odd;                  // [mb][hi|lo]
+                    dw32[blk * 256 + (kq * 16 + (p & 15)) * 4 + jp] = word;
+                }
+            }
+            IR_STAMP(4, 4 + 4 * it);
+        }
+        __syncthreads();
+        IR_STAMP(0, 5 + 4 * it);
+    }
+
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co = (nbp + 2 * j) * 16 + lr;
+            const float bias = a.bp[co];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = mbp * 16 + 4 * lk + i;
+                const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
+                if (oy < a.H && ox < a.W) {
+                    const size_t pix = ((size_t)img * a.H + oy) * a.W + ox;
+                    float v = pacc[j][i] * a.scale_p + bias;
+                    if constexpr (RES) v += a.x[pix * KP + co];           // the block input (L2-hot: this tile just read it)
+                    a.out[pix * COUT + co] = v;
+                }
+            }
+        }
+    }
+}
+
+bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual)
+{
+    if (stride != 1 || cexp != 6 * cin) return false;
+    return (cin == 64 && cout == 64 && residual) || (cin == 64 && cout == 96 && !residual) ||
+           (cin == 96 && cout == 96 && residual);
+}
+
+// Host packing of one 1x1 weight matrix W[k][n] (row-major, ld = n_total) into the fragment-major hi / lo images the
+// kernel stages: chunked over `chunk_n` columns when `by_n` (expand: chunks of expanded channels = columns), else over
+// `chunk_k` rows (projection: chunks of expanded channels = rows).
+void pack_ir_x3_expand(const float *w /* [K][CEXP] */, int K, int CEXP, int shift, unsigned short *dst)
+{
+    const int CE = 32, KS = K / 32, NBE = 2;
+    const float mul = ldexpf(1.0f, shift);
+    for (int c = 0; c < CEXP / CE; ++c)
+        for (int nb = 0; nb < NBE; ++nb)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * ks + 8 * (ln >> 4) + j, n = c * CE + nb * 16 + (ln & 15);
+                        const float v = w[(size_t)k * CEXP + n] * mul;
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)(v - (float)h);
+                        const size_t blk = ((size_t)(c * NBE + nb) * KS + ks) * 2;
+                        memcpy(dst + (blk * 64 + ln) * 8 + j, &h, 2);
+                        memcpy(dst + ((blk + 1) * 64 + ln) * 8 + j, &l, 2);
+                    }
+}
+
+void pack_ir_x3_project(const float *w /* [CEXP][COUT] */, int CEXP, int COUT, int shift, unsigned short *dst)
+{
+    const int CE = 32, NBO = COUT / 16;
+    const float mul = ldexpf(1.0f, shift);
+    for (int c = 0; c < CEXP / CE; ++c)
+        for (int nb = 0; nb < NBO; ++nb)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = c * CE + 8 * (ln >> 4) + j, n = nb * 16 + (ln & 15);
+                    const float v = w[(size_t)k * COUT + n] * mul;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const size_t blk = ((size_t)c * NBO + nb) * 2;
+                    memcpy(dst + (blk * 64 + ln) * 8 + j, &h, 2);
+                    memcpy(dst + ((blk + 1) * 64 + ln) * 8 + j, &l, 2);
+                }
+}
+
+hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int cexp, int cout, bool residual,
+                              const void *we, const float *be, const float *wd, const float *bd, const void *wp,
+                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, hipStream_t s)
+{
+    if (!ir_block_x3_supported(cin, cexp, cout, 1, residual)) return hipErrorInvalidValue;
+    IrX3Args a{};
+    a.x = x; a.out = out; a.we = reinterpret_cast<const u32x4 *>(we); a.wp = reinterpret_cast<const u32x4 *>(wp);
+    a.be = be; a.wd = wd; a.bd = bd; a.bp = bp; a.scale_e = scale_e; a.scale_p = scale_p;
+    a.B = B; a.H = H; a.W = W; a.status = status;
+    a.tiles_x = (W + IR_TW - 1) / IR_TW;
+    a.tiles_y = (H + IR_TH - 1) / IR_TH;
+    const long long nblocks = (long long)a.tiles_x * a.tiles_y * B;
+    if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    {
+        const char *sel = getenv("RPN_IR_STAMP_OP");
+        int sc = -1, ss = -1;
+        a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == 1 && (cin != 64 || cout == 64);
+    }
+    if (cin == 64 && cout == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 64, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
+    else if (cin == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 96, false>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ir_block_x3_kernel<96, 576, 96, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
+    return hipGetLastError();
 }
 
 bool ir_block_supported(int cin, int cexp, int cout, int stride, bool residual)

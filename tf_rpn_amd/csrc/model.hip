@@ -66,6 +66,8 @@ struct Op {
     bool ir_res = false;               // + block input
     int ir_pad = 0;                    // top/left padding of the depthwise (stem: of Conv1)
     size_t ir_off[6] = {0, 0, 0, 0, 0, 0};   // we, be, wd, bd, wp, bp (floats into the weight blob)
+    bool ir_x3 = false;                // F16X3 only: the block's two GEMMs on the 16-bit MFMA (hi + lo float16 operands)
+    float ir_scale[2] = {1.0f, 1.0f};  // ... 2^-shift of the pre-scaled expand / projection weights
 };
 
 }  // namespace rpn
@@ -264,6 +266,8 @@ static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, 
     op.Cin = ti.C; op.Cout = cout; op.cexp = cexp; op.stride = stride; op.ir_pad = pad; op.ir_res = res; op.ir_stem = stem;
     op.R = op.S = 3;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = ACT_LINEAR;
+    op.ir_x3 = m->f16 && !stem && ir_block_x3_supported(ti.C, cexp, cout, stride, res) &&
+               !(getenv("RPN_MN_X3") && atoi(getenv("RPN_MN_X3")) == 0);
     op.out = add_tensor(m, name, OH, OW, cout);
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
@@ -607,6 +611,13 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             w.resize(rows * p.Cout);
             for (size_t k = 0; k < rows; ++k)
                 for (int n = 0; n < p.Cout; ++n) w[k * p.Cout + n] = kernel[k * p.Cout + n] * scale[n];
+            if (op.ir_x3) {                                // hi + lo float16 fragments, same byte count
+                const int sh = split_weight_shift(w.data(), w.size(), true);
+                std::vector<float> packed(w.size());
+                pack_ir_x3_expand(w.data(), p.Cin, p.Cout, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                w.swap(packed);
+                op.ir_scale[0] = ldexpf(1.0f, -sh);
+            }
             w_at = op.ir_off[0]; b_at = op.ir_off[1]; nb = (size_t)p.Cout;
         } else if (role == 1) {                            // (3,3,C,1) == [9][C]
             w.resize((size_t)9 * p.Cin);
@@ -618,6 +629,13 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             w.assign((size_t)p.Cin * coutp, 0.0f);
             for (int k = 0; k < p.Cin; ++k)
                 for (int n = 0; n < p.Cout; ++n) w[(size_t)k * coutp + n] = kernel[(size_t)k * p.Cout + n] * scale[n];
+            if (op.ir_x3) {                                // (Cout % 16 == 0 for these blocks: coutp == Cout)
+                const int sh = split_weight_shift(w.data(), w.size(), true);
+                std::vector<float> packed(w.size());
+                pack_ir_x3_project(w.data(), p.Cin, p.Cout, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                w.swap(packed);
+                op.ir_scale[1] = ldexpf(1.0f, -sh);
+            }
             w_at = op.ir_off[4]; b_at = op.ir_off[5]; nb = (size_t)p.Cout;
         }
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + w_at, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -784,6 +802,12 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             e = launch_conv_f32(a, s);
         } else if (op.kind == OP_IRBLOCK) {
             const float *wb = m->d_weights;
+            if (op.ir_x3)
+                e = launch_ir_block_x3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.ir_res, wb + op.ir_off[0],
+                                       wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3], wb + op.ir_off[4],
+                                       wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1], tensor_ptr(m, op.out, d_imgs),
+                                       m->d_status, s);
+            else
             e = launch_ir_block(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_stem, op.ir_pad,
                                 op.OH, op.OW, wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
                                 wb + op.ir_off[4], wb + op.ir_off[5], tensor_ptr(m, op.out, d_imgs), s);
@@ -897,7 +921,8 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         by = in_b + out_b + 4.0 * (kin * op.cexp + 10.0 * op.cexp + (double)op.cexp * op.Cout + op.Cout);
         static thread_local char kir[64];
         if (op.ir_stem) snprintf(kir, sizeof kir, "ir_block<stem,32,16,s1>");
-        else snprintf(kir, sizeof kir, "ir_block<%d,%d,%d,s%d%s>", op.Cin, op.cexp, op.Cout, op.stride, op.ir_res ? ",res" : "");
+        else snprintf(kir, sizeof kir, "ir_block%s<%d,%d,%d,s%d%s>", op.ir_x3 ? "_f16x3" : "", op.Cin, op.cexp, op.Cout, op.stride,
+                      op.ir_res ? ",res" : "");
         k = kir;
     } else if (op.kind == OP_DWCONV) {
         fl = 2.0 * op.OH * op.OW * op.Cin * 9;
