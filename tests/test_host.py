@@ -90,7 +90,10 @@ def test_graph_builder_shapes_and_flops(lib, backbone, img, K, F, gflops, nlayer
     else:
         assert m.layers[0]["bn_name"] == "bn_Conv1" and m.layers[1]["kind"] == 2
         assert m.activation_shape("block_13_expand")[1:] == (F, F, 576)
-        sides = [m.activation_shape(n)[1] for n in ("Conv1", "block_1_depthwise", "block_3_depthwise", "block_6_depthwise")]
+        # the intermediate tensors of a block exist only on the layer-by-layer graph (fused blocks keep them on chip)
+        mk = RPNModel(backbone, {"img_size": img, "anchor_count": K}, max_batch=2, keep_activations=True)
+        sides = [mk.activation_shape(n)[1] for n in ("Conv1", "block_1_depthwise", "block_3_depthwise", "block_6_depthwise")]
+        assert len(m.ops()) == 16 and len(mk.ops()) > 40     # one launch per block
         assert sides == ([250, 125, 63, 32] if img == 500 else [512, 256, 128, 64])
     w_bytes, arena_bytes = m.memory_bytes()
     assert w_bytes > 0 and arena_bytes > 0
