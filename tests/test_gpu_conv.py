@@ -298,6 +298,65 @@ def test_model_forward_split_full_size(precision):
         assert np.abs(outs[precision][i] - outs["f32"][i]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("img,B", [(96, 2), (150, 1), (203, 2), (500, 1)])
+def test_vgg16_block1_one_launch(img, B):
+    """f16x3 runs VGG16 block 1 (block1_conv1 -> block1_conv2 -> block1_pool) as ONE launch: the first layer is
+    computed into the halo tile of the second, the 64-channel full-resolution tensors never reach HBM.  Same results as
+    the layer-by-layer graph (keep_activations=True: one kernel per layer) and as the float64 oracle; image sizes that
+    are not multiples of the 8 x 32 tile exercise the zero halo at the right / bottom edge; image 0 alone gives the same
+    bits (no cross-image coupling)."""
+    hp = bo.get_hyper_params("vgg16", img_size=img, feature_map_shape=None)
+    weights = synthetic_weights("vgg16", hp, seed=6)
+    for w in weights.values():                                  # non-zero biases: the halo outside the image must be 0,
+        if "bias" in w:                                         # not relu(bias)
+            w["bias"] = np.random.RandomState(len(w["bias"])).uniform(0.05, 0.2, size=w["bias"].shape).astype(np.float32)
+    imgs = np.random.RandomState(7).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+    fused = RPNModel("vgg16", hp, precision="f16x3", max_batch=B)
+    fused.set_weights(weights)
+    kernels = [op["kernel"] for op in fused.ops()]
+    assert kernels[0] == "vgg_block1<f16x3>" and not any(k.startswith("conv_cin3") for k in kernels)
+    reg, cls = fused.predict_on_batch(imgs)
+    feat = fused.get_activation(fused.tap_layer, batch=B).cpu().numpy()
+    layerwise = RPNModel("vgg16", hp, precision="f16x3", max_batch=B, keep_activations=True)
+    layerwise.set_weights(weights)
+    assert layerwise.ops()[0]["kernel"].startswith("conv_cin3")
+    reg_l, cls_l = layerwise.predict_on_batch(imgs)
+    feat_l = layerwise.get_activation(layerwise.tap_layer, batch=B).cpu().numpy()
+    fscale = max(1.0, float(np.abs(feat_l).max()))
+    assert np.abs(feat - feat_l).max() <= 2e-5 * fscale
+    assert np.abs(reg - reg_l).max() <= 2e-5 and np.abs(cls - cls_l).max() <= 2e-5
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
+    assert not fused.status()["f16_range"]
+    r1, c1 = fused.predict_on_batch(imgs[:1])
+    assert np.array_equal(r1[0], reg[0]) and np.array_equal(c1[0], cls[0])
+
+
+def test_vgg16_block1_one_launch_flags_f16_overflow():
+    """block1_conv1's activations pushed past 65504 inside the fused launch (they exist only in LDS there): the device
+    flag is raised all the same."""
+    hp = bo.get_hyper_params("vgg16", img_size=96, feature_map_shape=6)
+    base = synthetic_weights("vgg16", hp, seed=1)
+    for w in base.values():
+        if "bias" in w:
+            w["bias"] = np.full_like(w["bias"], 0.1)
+    # ReLU is positively homogeneous: conv1 (kernel, bias) x s and conv2's kernel / s change only conv1's output
+    weights = {k: dict(v) for k, v in base.items()}
+    s = np.float32(2.0 ** 20)
+    weights["block1_conv1"]["kernel"] = base["block1_conv1"]["kernel"] * s
+    weights["block1_conv1"]["bias"] = base["block1_conv1"]["bias"] * s
+    weights["block1_conv2"]["kernel"] = base["block1_conv2"]["kernel"] / s
+    x = torch.from_numpy(np.random.RandomState(0).uniform(0, 1, size=(1, 96, 96, 3)).astype(np.float32)).cuda()
+    model = RPNModel("vgg16", hp, precision="f16x3", max_batch=1)
+    model.set_weights(weights)
+    assert model.ops()[0]["kernel"] == "vgg_block1<f16x3>"
+    model.predict_on_batch(x)
+    assert model.status(reset=True)["f16_range"]
+    model.set_weights(base)
+    model.predict_on_batch(x)
+    assert not model.status()["f16_range"]
+
+
 def test_split_round_trip_and_pool():
     """SPLIT16 carries hi + lo: float32 -> split -> float32 is within 2^-16 (bf16) / 2^-21 (f16) relative,
     and pooling in split form equals pooling the joined values."""

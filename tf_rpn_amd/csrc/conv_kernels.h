@@ -106,6 +106,11 @@ hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
                                 bool pool, hipStream_t s);
 
+// VGG16 block 1 (block1_conv1 + block1_conv2 + block1_pool) in one launch: the 64-channel full-resolution tensor stays
+// on chip.  w1 = pack_weights_cin3_mfma_host records, w2 = pack_weights_split_host records; out: SPLIT16 (B,H/2,W/2,64).
+hipError_t launch_vgg_block1(const float *img, const void *w1, const float *b1, float scale1, const void *w2,
+                             const float *b2, float scale2, void *out, int B, int H, int W, bool f16, hipStream_t s);
+
 // first layer (Cin = 3, 3x3): direct conv on the vector ALU; w (27,Cout) float32; out_fmt 0 = float32 NHWC,
 // 1 = SPLIT16.  Cout % 16 == 0.
 hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, void *out, int B, int H, int W,

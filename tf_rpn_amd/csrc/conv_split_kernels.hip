@@ -149,6 +149,19 @@ __device__ __forceinline__ float join(unsigned short hi, unsigned short lo)
     return (float)__builtin_bit_cast(E, hi) + (float)__builtin_bit_cast(E, lo);
 }
 
+// v_mfma_f32_16x16x32: A row = lane & 15, k = 8 * (lane >> 4) .. + 7; B column = lane & 15, same k; C/D column = lane & 15,
+// row = 4 * (lane >> 4) + reg
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ int xcd_remap_s(int bid, int nwg)
 {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -165,6 +178,11 @@ struct SplitConvArgs {
     int act, out_f32;
     unsigned *sched;      // persistent kernel: 17 zero-initialised counters (per XCD label: tile queue, exits; labels done), or null
     unsigned *status;     // float16 range flag of the owning model (split_piece), or null
+    // B1 instantiation only (VGG16 block 1 in one launch: block1_conv1 computed into the halo tile, x unused):
+    const float *img;     // float32 NHWC image (B, H, W, 3)
+    const uint4 *w1;      // first-layer weights [64][8 pieces] (pack_weights_cin3_mfma_host)
+    const float *b1;      // first-layer bias (64)
+    float scale1;         // 2^-s of the pre-scaled first-layer weights
 };
 
 // TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64).
@@ -172,7 +190,17 @@ struct SplitConvArgs {
 // wave between barriers, and the LDS fragment reads of tap s+1 overlap the MFMAs of tap s.
 // BBUF: weight-tile buffers in LDS (2 = double buffered, one barrier per step; 1 = single buffered with a
 // second barrier, used where two buffers would not leave room for two workgroups per CU).
-template <int TH, int WN, int BBUF, int NW, bool F16, bool POOL>
+//
+// B1 (VGG16 block 1 in ONE launch: block1_conv1 -> block1_conv2 -> block1_pool, models/rpn_vgg16.py:16): the input is
+// the float32 image, and the halo tile of each 16-channel slice of block1_conv1's output is COMPUTED into LDS instead of
+// being staged from HBM -- the 64-channel full-resolution tensor (512 MB at batch 8: written once, read 1.1 times) never
+// exists.  Per tile the (TH+4) x 36 x 3 image patch is staged once; every wave builds the im2col operand (K = 27 -> 32)
+// of its share of the 340 halo pixels once, as hi/lo fragments in registers (B operand of v_mfma_16x16x32, so that a
+// lane's 4 results are 4 consecutive CHANNELS of one pixel = one 8-byte run of the pixel's LDS record), and per slice
+// multiplies them with that slice's 16 x 32 weight fragment: 3 MFMAs + bias/ReLU/split + 2 ds_write_b64 per 16 pixels,
+// two such blocks per barrier interval, written to the halo buffer the loop is not reading.  Halo pixels outside the
+// image are zeros (block1_conv2 pads block1_conv1's OUTPUT).  +8 % MFMA work on block1_conv2 (halo recompute included).
+template <int TH, int WN, int BBUF, int NW, bool F16, bool POOL, bool B1 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -190,9 +218,12 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     static_assert(MI * WM == TH && B_PIECES % NT == 0, "tile shape");
     constexpr int STAGE_LD = 64 + kStagePad;                         // floats per staged row
     constexpr int ABUF = HP * 4 + 4;                                 // one halo buffer + a dummy slot for idle lanes
+    constexpr int PW = TWS + 4;                                      // B1: image patch columns (halo of the halo)
+    constexpr int PATCH_F = B1 ? (TH + 4) * PW * 3 : 0;              // B1: floats of the image patch
+    static_assert(!B1 || (WN == 1 && POOL && BBUF == 2), "B1: the 64 -> 64 pooled instantiations only");
     constexpr int LDS_PIPE = 2 * ABUF + BBUF * B_PIECES;             // uint4 units
     constexpr int LDS_STAGE = (NW * 32 * STAGE_LD * 4 + 15) / 16;    // uint4 units (NW waves x 32 rows)
-    constexpr int LDS_UINT4 = LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE;
+    constexpr int LDS_UINT4 = (LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE) + (PATCH_F + 3) / 4;
 
     __shared__ uint4 lds[LDS_UINT4];
     // native vector type for everything staged: struct copies of HIP's uint4 lower to memcpy, which keeps the
@@ -230,7 +261,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int chunks = a.Cin >> 4;
     const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)chunks * 4;                     // uint4 per input pixel
-    const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
+    const uint4 *__restrict__ xin = B1 ? nullptr : a.x + (size_t)img * a.H * a.W * in_pix_stride;
 
     // ---- global -> register staging: every per-thread address is loop-invariant ----------------------
     // Halo pieces go through a raw buffer descriptor over THIS image: an out-of-image piece gets an offset
@@ -244,7 +275,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     unsigned a_goff[A_SLOTS];          // byte offset of this thread's piece of slice 0 (or kOob)
     int a_loff[A_SLOTS];               // uint4 index inside one halo buffer (dummy slot HP*4 when unused)
 #pragma unroll
-    for (int R = 0; R < A_SLOTS; ++R) {
+    for (int R = 0; R < (B1 ? 0 : A_SLOTS); ++R) {
         const int e = R * NT + tid;
         const int pix = e >> 2, pc = e & 3;
         const int hy = pix / HW, hx = pix - hy * HW;
@@ -278,6 +309,64 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #define RPN_LOAD_A(CHUNK, R) \
     __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 64, 0))
 
+    // ---- B1: first-layer state (all dead code otherwise) ------------------------------------------------------
+    constexpr int NBLK = (HP + 15) / 16;                              // 16-pixel blocks of the halo tile
+    constexpr int QB = B1 ? (NBLK + NW - 1) / NW : 1;                 // blocks per wave: block = wave + NW * q
+    constexpr int QPS = (QB + 2) / 3;                                 // blocks computed per barrier interval
+    float *patchf = reinterpret_cast<float *>(lds + (LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE));
+    const int lr = lane & 15, kg = lane >> 4;
+    u32x4 phi[QB], plo[QB];            // im2col fragments (8 of the 32 k of pixel lr): hi / lo halves
+    int pdst[QB];                      // byte offset of this lane's 8-byte run inside a halo buffer (< 0: no pixel)
+    unsigned pin = 0;                  // bit q: the pixel is inside the image
+    u32x4 w1hi = {0, 0, 0, 0}, w1lo = {0, 0, 0, 0};
+    f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
+    (void)patchf; (void)lr; (void)kg; (void)pin; (void)phi; (void)plo; (void)pdst; (void)w1hi; (void)w1lo; (void)b1v;
+#define RPN_B1_LOADW(CHUNK)                                                                            \
+    {                                                                                                  \
+        const u32x4 *w1_ = reinterpret_cast<const u32x4 *>(a.w1) + ((CHUNK) * 16 + lr) * 8 + kg;       \
+        w1hi = w1_[0];                                                                                 \
+        w1lo = w1_[4];                                                                                 \
+        b1v = *reinterpret_cast<const f32x4 *>(a.b1 + (CHUNK) * 16 + 4 * kg);                          \
+    }
+    // block Q of the slice whose weights are in w1hi / w1lo -> halo buffer BUF
+#define RPN_B1_BLOCK(Q, BUF)                                                                           \
+    if (wave + NW * (Q) < NBLK) {                                                                      \
+        f32x4 c_ = {0.f, 0.f, 0.f, 0.f};                                                               \
+        c_ = mfma16<F16>(w1lo, phi[Q], c_);                                                            \
+        c_ = mfma16<F16>(w1hi, plo[Q], c_);                                                            \
+        c_ = mfma16<F16>(w1hi, phi[Q], c_);                                                            \
+        using E_ = typename Half<F16>::elem;                                                           \
+        using h4_ = __attribute__((ext_vector_type(4))) E_;                                            \
+        const bool in_ = (pin >> (Q)) & 1u;                                                            \
+        h4_ hv_, lv_;                                                                                  \
+        float mx_ = 0.0f;                                                                              \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                             \
+            float v_ = fmaxf(c_[r_] * a.scale1 + b1v[r_], 0.0f);                                       \
+            v_ = in_ ? v_ : 0.0f;                                                                      \
+            mx_ = fmaxf(mx_, v_);                                                                      \
+            const E_ h_ = (E_)v_;                                                                      \
+            hv_[r_] = h_;                                                                              \
+            lv_[r_] = (E_)(v_ - (float)h_);                                                            \
+        }                                                                                              \
+        if constexpr (F16) {                                                                           \
+            if (a.status && !(mx_ <= 65504.0f)) atomicOr(a.status, 1u /* RPN_STATUS_F16_RANGE */);     \
+        }                                                                                              \
+        if (pdst[Q] >= 0) {                                                                            \
+            char *d_ = reinterpret_cast<char *>(As + (BUF) * ABUF);                                    \
+            *reinterpret_cast<uint2 *>(d_ + pdst[Q]) = __builtin_bit_cast(uint2, hv_);                 \
+            *reinterpret_cast<uint2 *>(d_ + (pdst[Q] ^ 16)) = __builtin_bit_cast(uint2, lv_);          \
+        }                                                                                              \
+    }
+    if constexpr (B1) {
+        // image patch: rows oy0 - 2 .. oy0 + TH + 1, columns ox0 - 2 .. ox0 + 33, zero outside the image
+        const float *ximg = a.img + (size_t)img * a.H * a.W * 3;
+        for (int e = tid; e < PATCH_F; e += NT) {
+            const int pr = e / (PW * 3), rem = e - pr * (PW * 3);
+            const int iy = oy0 - 2 + pr, ix = ox0 - 2 + rem / 3;
+            patchf[e] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ximg[((size_t)iy * a.W + ix) * 3 + rem % 3] : 0.0f;
+        }
+    }
+
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -298,10 +387,43 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
 
     // ---- prologue: halo of slice 0, weights of step 0 -------------------------------------------
+    if constexpr (B1) {
+        RPN_LOAD_B(0);
+        RPN_B1_LOADW(0);
+        RPN_STORE_B(0);
+        __syncthreads();                                   // the patch is complete
+        // k = 8 kg + j = (r * 3 + s) * 3 + c  ->  offset inside the patch relative to the pixel's top-left input
+        int koff[8];
 #pragma unroll
-    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN_LOAD_A(0, R);
-    RPN_LOAD_B(0);
-    RPN_STORE_B(0);
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * kg + j;
+            koff[j] = k < 27 ? (k / 9) * (PW * 3) + (k % 9) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int p = (wave + NW * q) * 16 + lr;
+            const bool valid = p < HP;
+            const int pp = valid ? p : HP - 1;
+            const int hy = pp / HW, hx = pp - hy * HW;
+            const int base = (hy * PW + hx) * 3;
+            float xs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = koff[j] >= 0 ? patchf[base + koff[j]] : 0.0f;
+            phi[q] = __builtin_bit_cast(u32x4, split_piece<F16>(xs, false));
+            plo[q] = __builtin_bit_cast(u32x4, split_piece<F16>(xs, true));
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) pin |= 1u << q;
+            // channels 4 kg .. 4 kg + 3 of the slice: hi piece 2 * (kg >> 1), its half (kg & 1); lo piece = hi piece ^ 1
+            pdst[q] = valid ? (pp * 4 + ((2 * (kg >> 1)) ^ ((hx >> 2) & 3))) * 16 + (kg & 1) * 8 : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) RPN_B1_BLOCK(q, 0);
+    } else {
+#pragma unroll
+        for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN_LOAD_A(0, R);
+        RPN_LOAD_B(0);
+        RPN_STORE_B(0);
+    }
     __syncthreads();
 
     int abuf = 0, bbuf = 0;
@@ -314,8 +436,12 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         for (int row = 0; row < 3; ++row) {              // unrolled: halo slot indices are compile-time
             const int step = chunk * 3 + row;
             RPN_LOAD_B(step + 1 < steps ? step + 1 : step);
+            if constexpr (B1) {
+                if (row == 0) RPN_B1_LOADW(next_chunk);      // first-layer weights of the slice computed below
+            } else {
 #pragma unroll
-            for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN_LOAD_A(next_chunk, row * A_RPS + q);
+                for (int q = 0; q < A_RPS; ++q) a_reg[q] = RPN_LOAD_A(next_chunk, row * A_RPS + q);
+            }
             if constexpr (NW == 4) RPN_PIN_LOADS();          // (the 8-wave variant has 128 VGPRs: pinned, it spills)
 
             const u32x4 *arow = As + (abuf * ABUF + (wm * MI + row) * HW * 4);
@@ -344,8 +470,15 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 
             if (BBUF == 1) __syncthreads();              // every wave is done reading the single weight buffer
             RPN_STORE_B(BBUF == 2 ? (bbuf ^ 1) : 0);
+            if constexpr (B1) {
+                if (chunk + 1 < chunks) {                    // the next slice's halo tile: QPS blocks per interval
 #pragma unroll
-            for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
+                    for (int q = row * QPS; q < (row + 1) * QPS && q < QB; ++q) RPN_B1_BLOCK(q, abuf ^ 1);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
+            }
             __syncthreads();
             if (BBUF == 2) bbuf ^= 1;
         }
@@ -355,6 +488,8 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #undef RPN_LOAD_B
 #undef RPN_STORE_B
 #undef RPN_LOAD_A
+#undef RPN_B1_LOADW
+#undef RPN_B1_BLOCK
     // ---- epilogue: scale + bias + activation (+ fused 2x2 max-pool), transpose through LDS, 16-byte stores --
     float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
     float bias_v[NI];
@@ -451,16 +586,6 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 // LDS rows hold 8 pieces [hi k0-7, hi k8-15, hi k16-23, hi k24-31, lo ...] XOR-swizzled by (column >> 1) & 7
 // (resp. (n >> 1) & 7): every ds_read_b128 fragment read is conflict-free.  Weights use the "split32" packing
 // [Cin/32][9][cout_pad][128 B] in that piece order; activations stay SPLIT16 in HBM (pieces re-ordered on staging).
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
-{
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // Timing experiment only (-DRPN_NOSTORE): every epilogue store of a lane goes to one 16-byte slot per lane, so the
 // instruction stream is unchanged but no output traffic reaches HBM.
@@ -1884,6 +2009,32 @@ hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias,
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
     if (pool) return f16 ? launch_split_tiles<true, true>(a, s) : launch_split_tiles<false, true>(a, s);
     return f16 ? launch_split_tiles<true, false>(a, s) : launch_split_tiles<false, false>(a, s);
+}
+
+// VGG16 block 1 in one launch: block1_conv1 (3 -> 64) + ReLU -> block1_conv2 (64 -> 64) + ReLU -> 2x2 max-pool
+// (models/rpn_vgg16.py:16, keras-applications VGG16).  img: float32 NHWC (B,H,W,3); w1: pack_weights_cin3_mfma_host
+// records of block1_conv1; w2: pack_weights_split_host records of block1_conv2; out: SPLIT16 (B,H/2,W/2,64).
+hipError_t launch_vgg_block1(const float *img, const void *w1, const float *b1, float scale1, const void *w2,
+                             const float *b2, float scale2, void *out, int B, int H, int W, bool f16, hipStream_t s)
+{
+    if (B < 1 || H < 2 || W < 2) return hipErrorInvalidValue;
+    SplitConvArgs a{};
+    a.status = range_status();
+    a.x = nullptr; a.w = (const uint4 *)w2; a.bias = b2; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = 64; a.Cout = 64; a.cout_pad = 64;
+    a.out_scale = scale2; a.act = ACT_RELU; a.out_f32 = 0;
+    a.img = img; a.w1 = (const uint4 *)w1; a.b1 = b1; a.scale1 = scale1;
+    const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8;
+    const long long m_tiles = (long long)tiles_x * tiles_y * B;
+    const long long nblocks = 8ll * ((m_tiles + 7) / 8);           // n_tiles = 1: XN = 1, XM = 8 (the kernel's tile order)
+    if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (f16)
+        hipLaunchKernelGGL((conv3x3_split_kernel<8, 1, 2, 4, true, true, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a,
+                           tiles_x, tiles_y, 1);
+    else
+        hipLaunchKernelGGL((conv3x3_split_kernel<8, 1, 2, 4, false, true, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a,
+                           tiles_x, tiles_y, 1);
+    return hipGetLastError();
 }
 
 }  // namespace rpn

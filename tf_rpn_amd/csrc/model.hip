@@ -22,7 +22,7 @@ namespace rpn {
 
 constexpr float kBnEps = 1e-3f;
 
-enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3, OP_TOSPLIT = 4, OP_IRBLOCK = 5 };
+enum OpKind { OP_CONV = 0, OP_DWCONV = 1, OP_POOL = 2, OP_HEAD = 3, OP_TOSPLIT = 4, OP_IRBLOCK = 5, OP_VGGB1 = 6 };
 
 struct Tensor {
     std::string name;
@@ -68,6 +68,7 @@ struct Op {
     size_t ir_off[6] = {0, 0, 0, 0, 0, 0};   // we, be, wd, bd, wp, bp (floats into the weight blob)
     bool ir_x3 = false;                // F16X3 only: the block's two GEMMs on the 16-bit MFMA (hi + lo float16 operands)
     float ir_scale[2] = {1.0f, 1.0f};  // ... 2^-shift of the pre-scaled expand / projection weights
+    // OP_VGGB1 (VGG16 block 1 in one launch) reuses ir_off[0..3] = w1, b1, w2, b2 and ir_scale[0..1] = the two 2^-shift
 };
 
 }  // namespace rpn
@@ -232,11 +233,33 @@ static void add_head(rpn_model *m, int feat)
     m->flops += 2.0 * tf.H * tf.W * 5 * m->K * 512;
 }
 
+// VGG16 block 1 as one launch (f16x3 only; the layer-by-layer graph when every activation must exist, RPN_B1_FUSE=0):
+// block1_conv1 + block1_conv2 + block1_pool, the 64-channel full-resolution tensors never reach HBM.
+static int add_vgg_block1(rpn_model *m, int in)
+{
+    const Tensor ti = m->tensors[in];
+    Op op;
+    op.kind = OP_VGGB1; op.name = "block1_pool"; op.in = in;
+    op.Cin = 3; op.Cout = 64; op.R = op.S = 3; op.stride = 1; op.pad_t = op.pad_l = 1;
+    op.H = ti.H; op.W = ti.W; op.OH = ti.H / 2; op.OW = ti.W / 2; op.act = ACT_RELU;
+    op.out = add_tensor(m, "block1_pool", op.OH, op.OW, 64);
+    m->tensors[op.out].split_fmt = true;
+    m->ops.push_back(op);
+    const int oi = (int)m->ops.size() - 1;
+    add_param(m, oi, "block1_conv1", "", 0, 3, 3, 3, 64);
+    add_param(m, oi, "block1_conv2", "", 0, 3, 3, 64, 64);
+    m->flops += 2.0 * ti.H * ti.W * 64 * 9.0 * (3 + 64);
+    return op.out;
+}
+
 static void build_vgg16(rpn_model *m)
 {
     int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
     const int cfg[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
-    for (int blk = 0; blk < 5; ++blk) {
+    const bool fuse_b1 = m->use_split && m->f16 && !m->keep_all &&
+                         !(getenv("RPN_B1_FUSE") && atoi(getenv("RPN_B1_FUSE")) == 0);
+    if (fuse_b1) t = add_vgg_block1(m, t);
+    for (int blk = fuse_b1 ? 1 : 0; blk < 5; ++blk) {
         for (int c = 0; c < cfg[blk][0]; ++c) {
             char name[64];
             snprintf(name, sizeof name, "block%d_conv%d", blk + 1, c + 1);
@@ -440,6 +463,13 @@ static void plan_weights(rpn_model *m)
             off += ((size_t)9 * op.Cin + 63) & ~(size_t)63;
             op.b_off = off;
             off += ((size_t)op.Cin + 63) & ~(size_t)63;
+        } else if (op.kind == OP_VGGB1) {
+            const size_t sizes[4] = {(size_t)32 * 64, 64, split_weight_bytes(64, 64) / sizeof(float), 64};
+            op.w_off = off;
+            for (int i = 0; i < 4; ++i) {
+                op.ir_off[i] = off;
+                off += (sizes[i] + 63) & ~(size_t)63;
+            }
         } else if (op.kind == OP_IRBLOCK) {
             const size_t kp = op.ir_stem ? 28 : (size_t)op.Cin, coutp = ((size_t)op.Cout + 15) / 16 * 16;
             const size_t sizes[6] = {kp * op.cexp, (size_t)op.cexp, (size_t)9 * op.cexp, (size_t)op.cexp,
@@ -599,7 +629,20 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
     if (bias)
         for (int n = 0; n < p.Cout; ++n) shift[n] += has_bn ? bias[n] * scale[n] : bias[n];
 
-    if (op.kind == OP_IRBLOCK) {
+    if (op.kind == OP_VGGB1) {
+        // parameter 0 = block1_conv1 (one-MFMA-step records), 1 = block1_conv2 (split records); no BatchNorm in VGG16
+        const bool first = op.params[0] == pi;
+        const size_t count = (size_t)9 * p.Cin * p.Cout;
+        const int wshift = split_weight_shift(kernel, count, m->f16);
+        std::vector<unsigned short> packed(first ? (size_t)64 * 64 : split_weight_bytes(64, 64) / sizeof(unsigned short));
+        if (first) pack_weights_cin3_mfma_host(kernel, nullptr, 64, 64, m->f16, wshift, packed.data());
+        else pack_weights_split_host(kernel, nullptr, 64, 64, 64, m->f16, wshift, packed.data());
+        op.ir_scale[first ? 0 : 1] = ldexpf(1.0f, -wshift);
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.ir_off[first ? 0 : 2], packed.data(), packed.size() * sizeof(unsigned short),
+                                hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.ir_off[first ? 1 : 3], shift.data(), (size_t)64 * sizeof(float),
+                                hipMemcpyHostToDevice));
+    } else if (op.kind == OP_IRBLOCK) {
         // role = position among the op's parameters: 0 expand / Conv1, 1 depthwise, 2 project.  Zero padding (the stem's
         // 28th im2col row, projection columns beyond Cout) comes from the memset of the weight blob.
         int role = 0;
@@ -800,6 +843,10 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 a.status = op.f32_out_split && m->f16 ? m->d_status : nullptr;
             }
             e = launch_conv_f32(a, s);
+        } else if (op.kind == OP_VGGB1) {
+            const float *wb = m->d_weights;
+            e = launch_vgg_block1(x, wb + op.ir_off[0], wb + op.ir_off[1], op.ir_scale[0], wb + op.ir_off[2],
+                                  wb + op.ir_off[3], op.ir_scale[1], tensor_ptr(m, op.out, d_imgs), B, op.H, op.W, m->f16, s);
         } else if (op.kind == OP_IRBLOCK) {
             const float *wb = m->d_weights;
             if (op.ir_x3)
@@ -914,6 +961,12 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
                  op.ps.generic ? ",generic" : "");
         k = kname32;
+    } else if (op.kind == OP_VGGB1) {
+        fl = 2.0 * op.H * op.W * 64 * 9.0 * (3 + 64);
+        by = in_b + out_b + 4.0 * 9 * (3 + 64) * 64;
+        static thread_local char kb1[64];
+        snprintf(kb1, sizeof kb1, "vgg_block1<%s>", m->f16 ? "f16x3" : "bf16x3");
+        k = kb1;
     } else if (op.kind == OP_IRBLOCK) {
         const int DH = op.ir_stem ? (op.H + op.ir_pad + 1 - 3) / 2 + 1 : op.H, DW = op.ir_stem ? (op.W + op.ir_pad + 1 - 3) / 2 + 1 : op.W;
         const double kin = op.ir_stem ? 27.0 : (double)op.Cin;

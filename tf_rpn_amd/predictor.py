@@ -59,7 +59,16 @@ class Proposer(object):
         # proposal buffers are double buffered; ordering is by HIP events only (no host synchronisation).
         self.overlap_nms = bool(overlap_nms)
         if self.overlap_nms:
+            import os
             self._nms_stream = torch.cuda.Stream()
+            # "go" handshake (speed only; RPN_NMS_HANDSHAKE=0 turns it off for A/B runs): the conv stack of batch k+1
+            # is ordered behind the side stream's WAIT for batch k's head outputs, so that the NMS workgroups (1024
+            # threads x 127 VGPRs: each needs a CU to itself) are dispatched at the kernel boundary, while the CUs are
+            # empty.  Without it the first conv kernel of batch k+1 wins that race, fills every CU, and the NMS only
+            # gets in at the NEXT boundary -- beside a persistent conv layer whose statically scheduled workgroups then
+            # wait for "their" CU (block2_conv1: 0.21 -> 0.31 ms).  A higher stream priority alone does not help.
+            self._nms_handshake = int(os.environ.get("RPN_NMS_HANDSHAKE", "1")) != 0
+            self._nms_go = None
             self._slot = 0
             self._bufs = []
             for _ in range(2):
@@ -118,11 +127,18 @@ class Proposer(object):
         if buf["used"]:
             main.wait_event(buf["nms_done"])          # the NMS that last read this slot's head outputs is done
         reg, cls = buf["reg"][:B], buf["cls"][:B]
+        if self._nms_go is not None:
+            main.wait_event(self._nms_go)
         self.rpn_model.forward_into(imgs, reg, cls)
         buf["conv_done"].record(main)
         ob, osc, oi, ov = buf["boxes"][:B], buf["scores"][:B], buf["idx"][:B], buf["valid"][:B]
         with torch.cuda.stream(self._nms_stream):
             self._nms_stream.wait_event(buf["conv_done"])
+            if self._nms_handshake:
+                if "go" not in buf:
+                    buf["go"] = torch.cuda.Event()
+                buf["go"].record(self._nms_stream)
+                self._nms_go = buf["go"]
             st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(reg.view(B, -1, 4)), self._vptr,
                                         L.ptr(cls.view(B, -1)), B, self.total_anchors, self.topn, self.iou_threshold,
                                         self.score_threshold, 1, L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0,
