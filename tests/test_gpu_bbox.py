@@ -131,6 +131,45 @@ def test_iou_map_chunked_kernel_alignment_cases(B, A, G, batched):
     assert got.shape == (B, A, G) and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("G", [1, 2, 6, 9, 21, 42])
+def test_iou_map_rows_kernel_divide_is_exact_everywhere(G):
+    """The row kernel forms the quotient with the bare arithmetic of the IEEE divide (reciprocal + fma chain, packed two
+    pairs per instruction) and falls back to the plain divide when an operand leaves [2^-60, 2^60].  Boxes that sit on
+    and beyond those limits -- tiny, huge, zero-area, flipped (negative areas), denormal coordinates, NaN and inf rows,
+    exact duplicates (IoU == 1) -- mixed into ordinary ones, anchors A not a multiple of 64, odd G: every float equal to
+    the C restatement's, NaN for NaN."""
+    rng = np.random.RandomState(100 + G)
+    B, A = 5, 64 * 7 + 13
+    boxes = cases.random_boxes(rng, (A,)).astype(np.float32)
+    gt = cases.gt_boxes(rng, B, G=G, n_valid=G).astype(np.float32)
+    def tiny(n, scale):                                      # boxes of side `scale` at random places
+        p = rng.uniform(0, 1, size=(n, 2)).astype(np.float32)
+        return np.concatenate([p, p + np.float32(scale)], axis=1).astype(np.float32)
+    specials = [tiny(8, 1e-9), tiny(8, 1e-19), tiny(4, 1e-30) * np.float32(1e-8), tiny(6, 1.0) * np.float32(1e12),
+                tiny(4, 1.0) * np.float32(3e18), np.zeros((3, 4), np.float32),
+                np.float32([[0.6, 0.6, 0.2, 0.2], [0.1, 0.9, 0.5, 0.3]]),            # flipped corners
+                np.float32([[np.nan, 0.1, 0.5, 0.5], [0.1, 0.1, np.inf, 0.5], [-np.inf, 0, 1, 1]]),
+                np.float32([[1e-42, 1e-42, 3e-42, 5e-42], [0, 0, 1e-45, 1]])]          # denormal coordinates
+    sp = np.concatenate(specials, axis=0)
+    at = rng.choice(A, size=len(sp), replace=False)
+    boxes[at] = sp
+    for b in range(B):                                       # the same specials among the gt rows of some images
+        if G >= 2 and b % 2 == 0:
+            k = min(G // 2, len(sp))
+            gt[b, rng.choice(G, size=k, replace=False)] = sp[rng.choice(len(sp), size=k, replace=False)]
+    gt[1, 0] = boxes[5]                                      # an exact duplicate: IoU == 1
+    got = bbox_utils.generate_iou_map(boxes, gt)
+    want = co.iou_map(boxes, gt)
+    assert got.shape == want.shape == (B, A, G)
+    assert np.array_equal(got.view(np.uint32) & 0x7fc00000 == 0x7fc00000, np.isnan(want))        # NaN exactly where the oracle has one
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+    # and the ordinary rows alone (no special anywhere): the fast path's own results, bit for bit
+    plain = cases.random_boxes(rng, (A,)).astype(np.float32)
+    gtp = cases.gt_boxes(rng, B, G=G, n_valid=G).astype(np.float32)
+    assert np.array_equal(bbox_utils.generate_iou_map(plain, gtp).view(np.uint32), co.iou_map(plain, gtp).view(np.uint32))
+
+
 # ---- NMS: integer outputs bit-exact -------------------------------------------------------------
 def _check_nms(boxes, scores, **kw):
     ref = co.combined_nms(boxes, scores, **kw)

@@ -222,41 +222,180 @@ iou_map_chunk_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A
 // one contiguous run of the output; they are written into a wave-private LDS tile at [lane*G + g] (+ the run's
 // misalignment q, so that LDS and global 16-byte boundaries coincide) and streamed out with 16-byte nontemporal stores.
 // LDS write stride G words: gcd(G, 32)-way bank conflicts -- the launcher picks this kernel only for gcd <= 2 (free).
-template <bool NT, int WAVES>
+// FAST: the arithmetic of TWO gt boxes per trip on the packed-float32 pipe (v_pk_add / v_pk_mul / v_pk_fma_f32: two IEEE
+// operations per issue slot), and the IEEE quotient without its range scaffolding: hipcc lowers `a / b` to v_div_scale x2,
+// v_rcp, 4 fma + 1 mul, v_div_fmas, v_div_fixup; when neither operand needs rescaling (v_div_scale returns them
+// unchanged) v_div_fmas IS an fma and v_div_fixup returns its input, so the seven arithmetic instructions alone give the
+// same bits.  That holds while a == 0 or 2^-60 <= a <= 2^60 and 2^-60 <= b <= 2^60 (quotient and every intermediate far
+// from the subnormal and overflow ranges, no NaN / inf / negative operand): each lane tracks the unsigned minimum and
+// maximum of the operands' bit patterns (3 instructions per pair, v_min3_u32 / v_max3_u32), and a wave in which any lane
+// ever left that range recomputes its rows with the plain `/` (never on real boxes; covered by the adversarial test).
+// Per (anchor, gt) pair ~17 issue slots instead of ~26; gt areas come from one v_readlane each (lane g holds gt g's).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// v_max_f32 / v_min_f32 of a per-lane value and a wave-uniform one (SGPR operand).  fmaxf / fminf would first
+// canonicalise the loaded gt coordinates (one extra v_max_f32 x, x each: 8 of them per gt pair); the bare instruction
+// differs only in how a signalling NaN is passed on, and any NaN operand sends the wave to the plain-divide path.
+__device__ __forceinline__ float vmax_vs(float v, float s)
+{
+    float r;
+    asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(v), "s"(s));
+    return r;
+}
+__device__ __forceinline__ float vmin_vs(float v, float s)
+{
+    float r;
+    asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(v), "s"(s));
+    return r;
+}
+
+__device__ __forceinline__ float vmax_vv(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin_vv(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+// a / b for two pairs, correctly rounded under the range condition above (the instruction sequence of the IEEE divide)
+__device__ __forceinline__ f32x2_t div2_in_range(f32x2_t a, f32x2_t b)
+{
+    const f32x2_t y0 = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const f32x2_t nb = -b, one = {1.0f, 1.0f};
+    const f32x2_t e0 = fma2(nb, y0, one);
+    const f32x2_t y1 = fma2(e0, y0, y0);
+    const f32x2_t q0 = a * y1;
+    const f32x2_t r0 = fma2(nb, q0, a);
+    const f32x2_t q1 = fma2(r0, y1, q0);
+    const f32x2_t r1 = fma2(nb, q1, a);
+    return fma2(r1, y1, q1);
+}
+
+// one gt pair on the packed pipe; r = the two quotients, (mn2, mx2) the range trackers
+#define RPN_IOU_PAIR(G0, G1, GA0, GA1, R, MN, MX)                                                             \
+    {                                                                                                  \
+        const f32x2_t lo0_ = {vmax_vv(bb.x1, (G0)[1]), vmax_vv(bb.y1, (G0)[0])};     /* :141-142 */    \
+        const f32x2_t hi0_ = {vmin_vv(bb.x2, (G0)[3]), vmin_vv(bb.y2, (G0)[2])};     /* :143-144 */    \
+        const f32x2_t lo1_ = {vmax_vv(bb.x1, (G1)[1]), vmax_vv(bb.y1, (G1)[0])};                       \
+        const f32x2_t hi1_ = {vmin_vv(bb.x2, (G1)[3]), vmin_vv(bb.y2, (G1)[2])};                       \
+        const f32x2_t d0_ = hi0_ - lo0_, d1_ = hi1_ - lo1_;                           /* (dx, dy) */    \
+        const f32x2_t mxs_ = {fmaxf(d0_.x, 0.0f), fmaxf(d1_.x, 0.0f)};                                 \
+        const f32x2_t mys_ = {fmaxf(d0_.y, 0.0f), fmaxf(d1_.y, 0.0f)};                                 \
+        const f32x2_t inter_ = mxs_ * mys_;                                           /* :146 */        \
+        const f32x2_t ga_ = {(GA0), (GA1)};                                                            \
+        const f32x2_t uni_ = (barea2 + ga_) - inter_;                                 /* :148 */        \
+        (R) = div2_in_range(inter_, uni_);                                            /* :150 */        \
+        const u32x2_t ua_ = __builtin_bit_cast(u32x2_t, inter_), ub_ = __builtin_bit_cast(u32x2_t, uni_);   \
+        MN = __builtin_elementwise_min(MN, __builtin_elementwise_min(ua_ - 1u, ub_));     /* a == 0 wraps: ignored */ \
+        MX = __builtin_elementwise_max(MX, __builtin_elementwise_max(ua_, ub_));                       \
+    }
+
+// Per-wave LDS: the result tile (64 * G + 4 floats, rounded up to 4) followed by the image's gt boxes (GP x 4 floats)
+// and their areas (GP floats), GP = G rounded up to 4.  The gt operands are read back with one address for the whole
+// wave (LDS broadcast): they arrive in vector registers without occupying a vector-ALU issue slot, several reads in
+// flight, where wave-uniform scalar loads made the wave wait out the scalar-cache latency on every trip
+// (rocprofv3: waves parked 35 % of their 15 k cycles in s_waitcnt, 12 waves per CU -- the kernel was bound by
+// per-wave latency x occupancy, not by its stores).
+__host__ __device__ inline int iou_rows_wave_floats(int G) { return ((64 * G + 4 + 3) & ~3) + 5 * ((G + 3) & ~3); }
+
+// RPN_IOU_PERSIST=1 (off by default: measured slower, 28.2 vs 26.6 us at C3) makes the waves walk several tiles.
+template <bool NT, int WAVES, bool FAST>
 __global__ void __launch_bounds__(64 * WAVES)
 iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt, int G,
-                    float *__restrict__ out)
+                    float *__restrict__ out, int tiles_per_img, int n_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) float iou_tile[];       // 4 waves x (64 * G + 4) floats
+    extern __shared__ __attribute__((aligned(16))) float iou_tile[];       // WAVES x iou_rows_wave_floats(G)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int a_base = blockIdx.x * (64 * WAVES) + wave * 64;
-    if (a_base >= A) return;                                  // whole wave (the tile is wave-private: no workgroup barrier)
+    const int GP = (G + 3) & ~3;
+    float *wt = iou_tile + wave * iou_rows_wave_floats(G);
+    f32x4_t *gbox_t = reinterpret_cast<f32x4_t *>(wt + ((64 * G + 4 + 3) & ~3));       // [GP]
+    float *garea_t = reinterpret_cast<float *>(gbox_t + GP);                            // [GP]
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    const int b = tile / tiles_per_img;
+    const int a_base = (tile - b * tiles_per_img) * 64;
     const int rows = min(64, A - a_base);
     const int a = min(a_base + lane, A - 1);                  // idle lanes recompute the last anchor, results unused
+    const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
     const Box bb = load_box(bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a);
+    if constexpr (FAST) {                                     // lane g stages gt box g and its area (G <= 64)
+        if (lane < GP) {
+            const Box gl = load_box(gtb + 4 * min(lane, G - 1));
+            gbox_t[lane] = f32x4_t{gl.y1, gl.x1, gl.y2, gl.x2};
+            garea_t[lane] = box_area_plain(gl);
+        }
+    }
     const float barea = box_area_plain(bb);                   // :139
     const long long s = ((long long)b * A + a_base) * G;      // first float of this wave's run
     const int q = (int)(s & 3);
-    float *wt = iou_tile + wave * ((64 * G + 4 + 3) & ~3);
-    const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
     float *row = wt + q + lane * G;
-    // 4 independent pairs per trip: one pair is a ~20-deep dependent chain (max/min, products, an IEEE divide) and a
-    // wave alone issues a dependent instruction only every 4-8 cycles
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        float r4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const Box gg = load_box(gtb + 4 * (g + j));       // wave-uniform address
-            r4[j] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+    bool exact_needed = !FAST;
+    if constexpr (FAST) {
+        constexpr unsigned kLo = 0x21800000u, kHi = 0x5D800000u;            // bits of 2^-60, 2^60
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x2_t mn2 = {0xFFFFFFFFu, 0xFFFFFFFFu}, mx2 = {0u, 0u}, mn2b = mn2, mx2b = mx2;     // one tracker pair per chain
+        const f32x2_t barea2 = {barea, barea};
+        // 4 gt boxes (two packed pairs = two independent dependency chains) per trip; the next trip's operands are
+        // requested before this trip's arithmetic
+        const int G4 = G & ~3;
+        f32x4_t c0 = gbox_t[0], c1 = gbox_t[1], c2 = gbox_t[2], c3 = gbox_t[3];
+        f32x4_t ca = *reinterpret_cast<const f32x4_t *>(garea_t);
+        for (int g = 0; g < G4; g += 4) {
+            const int gn = g + 4 < GP ? g + 4 : g;            // (GP is a multiple of 4: in bounds; clamped on the last trip)
+            const f32x4_t n0 = gbox_t[gn], n1 = gbox_t[gn + 1], n2 = gbox_t[gn + 2], n3 = gbox_t[gn + 3];
+            const f32x4_t na = *reinterpret_cast<const f32x4_t *>(garea_t + gn);
+            f32x2_t r01, r23;
+            RPN_IOU_PAIR(c0, c1, ca[0], ca[1], r01, mn2, mx2);
+            RPN_IOU_PAIR(c2, c3, ca[2], ca[3], r23, mn2b, mx2b);
+            row[g] = r01.x;
+            row[g + 1] = r01.y;
+            row[g + 2] = r23.x;
+            row[g + 3] = r23.y;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; ca = na;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) row[g + j] = r4[j];
+        if (G4 + 2 <= G) {                                     // c0.. hold gt G4 .. G4+3 (staged rows beyond G repeat G-1)
+            f32x2_t r01;
+            RPN_IOU_PAIR(c0, c1, ca[0], ca[1], r01, mn2, mx2);
+            row[G4] = r01.x;
+            row[G4 + 1] = r01.y;
+            if (G4 + 3 == G) {                                 // odd G: the last gt box alone, plain divide
+                const Box gg = load_box(gtb + 4 * (G - 1));
+                row[G - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+            }
+        } else if (G4 < G) {
+            const Box gg = load_box(gtb + 4 * (G - 1));
+            row[G - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+        }
+        const unsigned mn = min(min(mn2.x, mn2.y), min(mn2b.x, mn2b.y)), mx = max(max(mx2.x, mx2.y), max(mx2b.x, mx2b.y));
+        exact_needed = __any(mn < kLo - 1u || mx > kHi) != 0;
     }
-    for (; g < G; ++g) {
-        const Box gg = load_box(gtb + 4 * g);
-        row[g] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+    if (exact_needed) {
+        // 4 independent pairs per trip: one pair is a ~20-deep dependent chain (max/min, products, an IEEE divide) and a
+        // wave alone issues a dependent instruction only every 4-8 cycles
+        int g = 0;
+        for (; g + 4 <= G; g += 4) {
+            float r4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Box gg = load_box(gtb + 4 * (g + j));       // wave-uniform address
+                r4[j] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row[g + j] = r4[j];
+        }
+        for (; g < G; ++g) {
+            const Box gg = load_box(gtb + 4 * g);
+            row[g] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -264,7 +403,19 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
     const int n = rows * G;                                   // valid floats: LDS [q, q + n)
     float *gbase = out + (s - q);                             // 16-byte aligned; LDS index i <-> gbase[i]
     const int v0 = (q + 3) >> 2, v1 = (q + n) >> 2;           // whole vectors [v0, v1)
-    for (int v = v0 + lane; v < v1; v += 64) {
+    int v = v0 + lane;
+    for (; v + 192 < v1; v += 256) {                          // 4 reads in flight, then their 4 stores
+        f32x4_t val[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = *reinterpret_cast<const f32x4_t *>(wt + 4 * (v + 64 * j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4_t *dst = reinterpret_cast<f32x4_t *>(gbase + 4 * (v + 64 * j));
+            if constexpr (NT) __builtin_nontemporal_store(val[j], dst);
+            else *dst = val[j];
+        }
+    }
+    for (; v < v1; v += 64) {
         const f32x4_t val = *reinterpret_cast<const f32x4_t *>(wt + 4 * v);
         f32x4_t *dst = reinterpret_cast<f32x4_t *>(gbase + 4 * v);
         if constexpr (NT) __builtin_nontemporal_store(val, dst);
@@ -275,7 +426,13 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
     if (lane < head_end - q) gbase[q + lane] = wt[q + lane];
     const int tail0 = max(4 * v1, head_end);
     if (lane < q + n - tail0) gbase[tail0 + lane] = wt[tail0 + lane];
+    // (the next tile's LDS writes stay behind these reads: a wave's LDS operations execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
+#undef RPN_IOU_PAIR
 
 // normalize_bboxes / denormalize_bboxes (utils/bbox_utils.py:152-182): per-coordinate divide / multiply by the
 // image height (y) or width (x); denormalize rounds half-to-even like tf.round (rintf in the default mode)
@@ -432,16 +589,35 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     static const int nt = getenv("RPN_IOU_NT") ? atoi(getenv("RPN_IOU_NT")) : 1;
     static const int rowsk = getenv("RPN_IOU_ROWS") ? atoi(getenv("RPN_IOU_ROWS")) : 1;
     const int g32 = (G % 4 == 0) ? 4 : (G % 2 == 0 ? 2 : 1);          // >= gcd(G, 32) capped at 4
-    const size_t wave_lds = (size_t)((64 * G + 4 + 3) & ~3) * sizeof(float);
+    const size_t wave_lds = (size_t)iou_rows_wave_floats(G) * sizeof(float);
     if (rowsk && G >= 1 && g32 <= 2 && wave_lds <= 12 * 1024 && A >= 64) {
-        // 4 waves per workgroup (single-wave workgroups measured 30.4 vs 26.5 us at C3)
-        const dim3 grid((unsigned)((A + 255) / 256), (unsigned)B);
-        if (nt_rows())
-            hipLaunchKernelGGL((iou_map_rows_kernel<true, 4>), grid, dim3(256), 4 * wave_lds, as_stream(stream), d_bboxes,
-                               bboxes_batched, A, d_gt, G, d_iou);
-        else
-            hipLaunchKernelGGL((iou_map_rows_kernel<false, 4>), grid, dim3(256), 4 * wave_lds, as_stream(stream), d_bboxes,
-                               bboxes_batched, A, d_gt, G, d_iou);
+        // one tile (64 anchors x G) per wave, 4 waves per workgroup (single-wave workgroups measured 30.4 vs 26.5 us at C3).
+        // RPN_IOU_PERSIST=1: as many workgroups as stay resident, every wave walking the same number of tiles
+        const int tiles_per_img = (A + 63) / 64;
+        const long long n_tiles = (long long)tiles_per_img * B;
+        RPN_REQUIRE(n_tiles <= 0x7fffffffll, "rpn_iou_map: too many tiles");
+        static const int persist = getenv("RPN_IOU_PERSIST") ? atoi(getenv("RPN_IOU_PERSIST")) : 0;
+        static const int fast = getenv("RPN_IOU_FAST") ? atoi(getenv("RPN_IOU_FAST")) : 1;
+        static const int wv = getenv("RPN_IOU_WAVES") ? atoi(getenv("RPN_IOU_WAVES")) : 4;     // waves per workgroup: 4 | 2
+        const int W = wv == 2 ? 2 : 4;
+        long long wgs = (n_tiles + W - 1) / W;
+        if (persist) {
+            const long long resident = 256ll * (long long)((160 * 1024) / (W * wave_lds));
+            if (wgs > resident) {
+                const long long rounds = (n_tiles + W * resident - 1) / (W * resident);
+                wgs = ((n_tiles + rounds - 1) / rounds + W - 1) / W;
+            }
+        }
+        const dim3 grid((unsigned)wgs);
+        const int nt_i = (int)n_tiles;
+#define RPN_IOU_ROWS(NT_, W_, FAST_)                                                                                  \
+    hipLaunchKernelGGL((iou_map_rows_kernel<NT_, W_, FAST_>), grid, dim3(64 * W_), W_ * wave_lds, as_stream(stream), d_bboxes, \
+                       bboxes_batched, A, d_gt, G, d_iou, tiles_per_img, nt_i)
+        if (!nt_rows()) RPN_IOU_ROWS(false, 4, true);
+        else if (!fast) RPN_IOU_ROWS(true, 4, false);
+        else if (W == 2) RPN_IOU_ROWS(true, 2, true);
+        else RPN_IOU_ROWS(true, 4, true);
+#undef RPN_IOU_ROWS
     } else if (chunked && G >= 4 && G <= 2048 && per_img >= kIouChunk && total < (1ll << 40)) {
         const long long chunks = (total + kIouChunk - 1) / kIouChunk;
         RPN_REQUIRE(chunks <= 0x7fffffffll, "rpn_iou_map: too many chunks");
