@@ -248,6 +248,40 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=5, warmup
                          "launches_per_step": tot[dom][2], "avg_launch_ms": round(tot[dom][0] / tot[dom][2], 4)}}
 
 
+def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmup=3):
+    """One of the other BASELINE.json configs at its per-GPU batch, in this same run: whole hot path (conv stack ->
+    head -> decode -> NMS(300), NMS of step k overlapped with the convs of step k+1), synthetic images and weights of
+    that config's shape, `steps` timed steps bracketed by synchronize()."""
+    import torch
+
+    from tf_rpn_amd.models._rpn_model import synthetic_weights
+    from tf_rpn_amd.predictor import Proposer
+    weights = synthetic_weights(backbone, hp, seed=1)
+    prop = Proposer(backbone, hyper_params=hp, weights=weights, precision=precision, max_batch=B,
+                    iou_threshold=iou_threshold, overlap_nms=True)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0)
+    imgs = torch.rand((B, hp["img_size"], hp["img_size"], 3), generator=gen, device="cuda", dtype=torch.float32)
+    for _ in range(warmup):
+        prop.propose_async(imgs)
+    prop.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prop.propose_async(imgs)
+    prop.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_launches = len(prop.rpn_model.ops())
+    del prop, imgs
+    torch.cuda.empty_cache()
+    return {"workload": "%s: %s, %dx%d, %d anchors/cell, batch %d per GPU" % (label, backbone, hp["img_size"], hp["img_size"],
+                                                                             hp["anchor_count"], B),
+            "value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4),
+            "ms_per_image": round(1e3 * dt / steps / B, 4), "steps": steps, "dtype": precision,
+            "conv_launches_per_step": n_launches}
+
+
 def c3_leg(hp, n=30):
     """BASELINE.json configs[2]: batch 64, box path only (no backbone) -- the metric's "NMS boxes/sec".  Inputs as
     SURVEY.md 8(d): deltas ~ N(0,1) (x variances inside the kernel), scores = a seeded permutation of (i + 0.5) / A per
@@ -555,6 +589,20 @@ def main():
             out["nms_boxes_per_sec_note"] = "configs[2] (B=64), fused decode+NMS(300), iou 0.7; `c3` has iou 0.5 and the GB/s"
             if args.precision != "f32":
                 out["exact_f32"] = exact_f32_leg(args.backbone, hp, weights, B, args.iou_threshold, imgs)
+            if args.config == "c2" and args.backbone == "vgg16" and B == 8:
+                # the other BASELINE.json configs (per-GPU shapes), so that every config has a driver-run figure
+                hp_mn = dict(train_utils.get_hyper_params("mobilenet_v2"))
+                hp_c5 = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                                          anchor_ratios=[1., 2., 1. / 2., 3., 1. / 3.]))
+                out["other_configs"] = {
+                    "c1": config_leg("configs[0]", "mobilenet_v2", hp_mn, 1, args.precision, args.iou_threshold, steps=20),
+                    "c4": config_leg("configs[3] (batch 256 on 8 GPUs)", "vgg16", hp, 32, args.precision, args.iou_threshold,
+                                     steps=5, warmup=2),
+                    "c5": config_leg("configs[4] (batch 8 on 8 GPUs)", "mobilenet_v2", hp_c5, 1, args.precision,
+                                     args.iou_threshold, steps=20),
+                    "mobilenet_v2_b8": config_leg("configs[0] shape at batch 8", "mobilenet_v2", hp_mn, 8, args.precision,
+                                                  args.iou_threshold, steps=20),
+                }
         else:
             out["nms_boxes_per_sec"] = round(B * prop.total_anchors / (nms_ms * 1e-3), 1)
             out["nms_boxes_per_sec_note"] = "this run's own decode+NMS at its per-GPU batch (%d images)" % B

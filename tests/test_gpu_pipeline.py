@@ -232,5 +232,10 @@ def test_bench_prints_one_json_line(extra):
     assert d["nms_boxes_per_sec"] == c3["decode_nms_iou0.7"]["boxes_per_sec"] > 1e8
     f32 = d["exact_f32"]
     assert f32["dtype"] == "f32" and 100 < f32["value"] < d["value"] and 0.2 < f32["roofline"]["frac"] < 1.0
+    # ... and one figure per other BASELINE.json config (per-GPU shapes)
+    oc = d["other_configs"]
+    assert set(oc) == {"c1", "c4", "c5", "mobilenet_v2_b8"}
+    assert oc["c4"]["value"] > 100 and "batch 32" in oc["c4"]["workload"] and "1024x1024, 15 anchors" in oc["c5"]["workload"]
+    assert all(v["unit"] == "images/s" and v["value"] > 0 and v["conv_launches_per_step"] <= 20 for v in oc.values())
     if "--force-dist" in extra:
         assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0
