@@ -206,7 +206,7 @@ def test_predictor_cli_on_a_folder_of_images(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--force-dist"], ["--serial-nms", "--steps", "4"]])
+@pytest.mark.parametrize("extra", [[], ["--force-dist", "--no-extra-legs"], ["--serial-nms", "--steps", "4", "--no-extra-legs"]])
 def test_bench_prints_one_json_line(extra):
     """The driver's contract: rank 0 prints ONE JSON line on stdout (RCCL's version banner must not land there), with the
     roofline object; `--force-dist` runs the N > 1 code path on a world-size-1 RCCL group."""
@@ -226,6 +226,11 @@ def test_bench_prints_one_json_line(extra):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "conv3x3_split16_dma" in rf["kernel"] and 0.2 < rf["frac"] < 1.0
     assert d["rccl_ranks"] == 1 and "traffic_source" in rf
+    if "--force-dist" in extra:
+        assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0
+    if "--no-extra-legs" in extra:
+        assert "c3" not in d and d["nms_boxes_per_sec"] > 1e7
+        return
     # the N = 1 line carries the box-path leg (configs[2], the metric's "NMS boxes/sec") and the exact-f32 leg
     c3 = d["c3"]
     assert c3["B"] == 64 and c3["iou_map"]["GBps"] > 100 and c3["decode"]["GBps"] > 100
@@ -237,5 +242,3 @@ def test_bench_prints_one_json_line(extra):
     assert set(oc) == {"c1", "c4", "c5", "mobilenet_v2_b8"}
     assert oc["c4"]["value"] > 100 and "batch 32" in oc["c4"]["workload"] and "1024x1024, 15 anchors" in oc["c5"]["workload"]
     assert all(v["unit"] == "images/s" and v["value"] > 0 and v["conv_launches_per_step"] <= 20 for v in oc.values())
-    if "--force-dist" in extra:
-        assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0

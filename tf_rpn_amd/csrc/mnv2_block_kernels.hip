@@ -463,6 +463,171 @@ ir_block_kernel(IrArgs a)
     }
 }
 
+// ---- stem + expanded_conv block, 8 x 16 output tiles ---------------------------------------------------------------
+// Conv1 (3x3 stride 2, 3 -> 32, BN, ReLU6) -> expanded_conv depthwise 3x3 (BN, ReLU6) -> project 1x1 32 -> 16 (BN), the
+// first launch of the MobileNetV2 graph.  In ir_block_kernel<STEM> this is a single chunk: nothing for the E / D / P
+// pipeline to overlap, three barrier-separated phases on a 32-pixel tile with half the workgroup idle in each, 45 KB of
+// LDS -- 3 tiles of 32 pixels in flight per CU, every one a chain of L2 / LDS round trips: 100 us at batch 8 / 500 x 500
+// against ~10 us for either roof (1.66 GFLOP on the f32 MFMA; 56 MB of input + output).  Here a 256-thread workgroup
+// owns 8 x 16 output pixels (halo 10 x 18: 1.4x instead of 1.9x redundant Conv1 work), all four waves work in every
+// phase, and the weights live in registers (loaded once, before the image patch arrives):
+//   E  Conv1 on the 180 halo pixels: A gathered from the raw image patch in LDS (im2col entry = base(pixel) + off(k)),
+//      12 M-blocks x 2 N-blocks x 7 k-steps of v_mfma_f32_16x16x4_f32 (exact f32), 3 M-blocks per wave;
+//      + bias, ReLU6, zero outside Conv1's grid (the depthwise pads the EXPANDED tensor) -> Es
+//   D  depthwise: thread = (channel, output row half): 16 outputs from a 3 x 18 window read once -> Ds (overlays the patch)
+//   P  (128 px x 32) * (32 x 16) on the MFMA, 2 M-blocks per wave, + bias -> NHWC
+constexpr int ST_TH = 8, ST_TW = 16, ST_THREADS = 256;
+
+__global__ void __launch_bounds__(ST_THREADS)
+stem_block_kernel(IrArgs a)
+{
+    constexpr int IH = ST_TH + 2, IW = ST_TW + 2, NH = IH * IW;          // halo on Conv1's grid: 10 x 18 = 180 pixels
+    constexpr int MB = (NH + 15) / 16;                                    // 12 M-blocks
+    constexpr int MBW = MB / 4;                                           // 3 per wave
+    constexpr int PR = 2 * (IH - 1) + 3, PC = (2 * (IW - 1) + 3) * 3, PSTR = PC + 2;   // image patch: 21 rows x 111 floats
+    constexpr int SEP = 36, SD = 34;                                      // row strides of Es / Ds (see ir_block_kernel)
+    constexpr int KS = 7;                                                 // k-steps of Conv1 (K = 27 -> 28)
+    static_assert(MB % 4 == 0, "M-blocks per wave");
+    constexpr int XD_FLOATS = PR * PSTR > ST_TH * ST_TW * SD ? PR * PSTR : ST_TH * ST_TW * SD;
+    __shared__ __attribute__((aligned(16))) float XD[XD_FLOATS];          // the image patch, then Ds
+    __shared__ __attribute__((aligned(16))) float Es[MB * 16 * SEP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int img = t / a.tiles_y;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int gy0 = oy0 - 1, gx0 = ox0 - 1;                               // halo origin on Conv1's grid
+
+    // weights -> registers (in flight while the patch is loaded)
+    float we_r[KS][2], wp_r[8], wd_r[10];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) we_r[kk][nb] = a.we[(4 * kk + lk) * 32 + nb * 16 + lr];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wp_r[kk] = a.wp[(4 * kk + lk) * 16 + lr];
+    const int dc = tid & 31, dg = tid >> 5;                               // depthwise: channel, output row
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd_r[k] = a.wd[k * 32 + dc];
+    wd_r[9] = a.bd[dc];
+    const float be0 = a.be[lr], be1 = a.be[16 + lr], bpv = a.bp[lr];
+
+    // ---- image patch: rows 2 gy0 - pad .. + 21, columns (2 gx0 - pad) .. + 37, zero outside the image (ZeroPadding2D)
+    {
+        const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * 3;
+        const int iy0 = 2 * gy0 - a.pad, ixc0 = (2 * gx0 - a.pad) * 3;
+        for (int idx = tid; idx < PR * PC; idx += ST_THREADS) {
+            const int pr = idx / PC, pc = idx - pr * PC;
+            const int iy = iy0 + pr, ixc = ixc0 + pc;                      // ixc = column * 3 + channel
+            float v = 0.0f;
+            if (iy >= 0 && iy < a.H && ixc >= 0 && ixc < a.W * 3) v = xin[(size_t)iy * a.W * 3 + ixc];
+            XD[pr * PSTR + pc] = v;
+        }
+    }
+    // which of this lane's Conv1 outputs (M-block wave + 4 mbi, row 4 lk + i) lie inside Conv1's grid
+    unsigned vmask = 0;
+    int xbase[MBW], xoff[KS];
+#pragma unroll
+    for (int mbi = 0; mbi < MBW; ++mbi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = (wave + 4 * mbi) * 16 + 4 * lk + i;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            if (m < NH && gy >= 0 && gy < a.DH && gx >= 0 && gx < a.DW) vmask |= 1u << (mbi * 4 + i);
+        }
+        const int m = min((wave + 4 * mbi) * 16 + lr, NH - 1);            // rows >= NH are masked out: any valid address
+        const int hy = m / IW, hx = m - hy * IW;
+        xbase[mbi] = 2 * hy * PSTR + 6 * hx;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int k = 4 * kk + lk;                                       // k = 27: zero weight row, any valid address
+        const int r = k / 9, q = (k / 3) % 3, c = k % 3;
+        xoff[kk] = k < 27 ? r * PSTR + q * 3 + c : 0;
+    }
+    __syncthreads();
+
+    // ---- E: Conv1 ----------------------------------------------------------------------------------------------------
+    {
+        f32x4 eacc[MBW][2];
+#pragma unroll
+        for (int mbi = 0; mbi < MBW; ++mbi)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) eacc[mbi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float av[KS][MBW];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int mbi = 0; mbi < MBW; ++mbi) av[kk][mbi] = XD[xbase[mbi] + xoff[kk]];     // all 21 gathers in flight
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int mbi = 0; mbi < MBW; ++mbi)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][mbi], we_r[kk][nb], eacc[mbi][nb], 0, 0, 0);
+#pragma unroll
+        for (int mbi = 0; mbi < MBW; ++mbi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = (vmask >> (mbi * 4 + i)) & 1u;
+                float *e = &Es[((wave + 4 * mbi) * 16 + 4 * lk + i) * SEP + lr];
+                e[0] = in ? relu6f(eacc[mbi][0][i] + be0) : 0.0f;
+                e[16] = in ? relu6f(eacc[mbi][1][i] + be1) : 0.0f;
+            }
+    }
+    __syncthreads();                                                      // Es complete; the patch is dead
+
+    // ---- D: depthwise 3x3 + bias + ReLU6: thread = (channel dc, output row dg), 16 outputs ----------------------------
+    {
+        const float *es = Es + (dg * IW) * SEP + dc;
+        float *ds = XD + (dg * ST_TW) * SD + dc;
+        float win[3][IW];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int x = 0; x < IW; ++x) win[r][x] = es[(r * IW + x) * SEP];
+#pragma unroll
+        for (int px = 0; px < ST_TW; ++px) {
+            float acc = wd_r[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px + q], wd_r[r * 3 + q], acc);
+            ds[px * SD] = relu6f(acc);
+        }
+    }
+    __syncthreads();
+
+    // ---- P: projection 32 -> 16 + bias -> NHWC -----------------------------------------------------------------------
+    {
+        f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float pa[8][2];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int mbi = 0; mbi < 2; ++mbi) pa[kk][mbi] = XD[((2 * wave + mbi) * 16 + lr) * SD + 4 * kk + lk];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int mbi = 0; mbi < 2; ++mbi)
+                pacc[mbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk][mbi], wp_r[kk], pacc[mbi], 0, 0, 0);
+#pragma unroll
+        for (int mbi = 0; mbi < 2; ++mbi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = (2 * wave + mbi) * 16 + 4 * lk + i;         // = output row 2 wave + mbi, column 4 lk + i
+                const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+                if (oy < a.OH && ox < a.OW) a.out[(((size_t)img * a.OH + oy) * a.OW + ox) * 16 + lr] = pacc[mbi][i] + bpv;
+            }
+    }
+}
+
 // ---- f16x3 variant for the low-resolution blocks (Cin = 64 / 96, stride 1) -----------------------------------------
 // Same pipeline (E / D / P over two wave groups, one barrier per step), but the two GEMMs run on
 // v_mfma_f32_16x16x32_f16 with every float32 operand carried as hi + lo float16 halves and each product formed as
@@ -863,7 +1028,16 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
                        dim3(IR_THREADS), 0, s, a)
     if (stem) {
         if (!(cin == 3 && cexp == 32 && cout == 16 && stride == 1 && !residual)) return hipErrorInvalidValue;
-        RPN_IR(28, 32, 32, 16, 1, false, true);
+        static const int stem8 = getenv("RPN_MN_STEM8") ? atoi(getenv("RPN_MN_STEM8")) : 1;     // 0: the 4 x 8 tile pipeline
+        if (stem8) {
+            a.tiles_x = (OW + ST_TW - 1) / ST_TW;
+            a.tiles_y = (OH + ST_TH - 1) / ST_TH;
+            const long long nb8 = (long long)a.tiles_x * a.tiles_y * B;
+            if (nb8 <= 0 || nb8 > 0x7fffffffll) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(stem_block_kernel, dim3((unsigned)nb8), dim3(ST_THREADS), 0, s, a);
+        } else {
+            RPN_IR(28, 32, 32, 16, 1, false, true);
+        }
     } else if (!ir_block_supported(cin, cexp, cout, stride, residual)) {
         return hipErrorInvalidValue;
     } else if (cin == 16) RPN_IR(16, 96, 16, 24, 2, false, false);
