@@ -11,7 +11,9 @@ def fam(k):
     if m: return "conv3x3_split16_dma<%s,%s>" % (prec(m.group(1)), m.group(3))
     m = re.search(r"conv3x3_split16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", k)
     if m: return "conv3x3_split16<%s,%d>" % (prec(m.group(4)), 64 * int(m.group(2)))
-    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", k)
+    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), true>", k)
+    if m: return "vgg_block1<%s>" % prec(m.group(5))
+    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(, false)?>", k)
     if m: return "conv3x3_split<%s>" % prec(m.group(5))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
     if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
