@@ -49,6 +49,14 @@ struct ConvArgs {
 int conv_f32_tile_n(int B, int OH, int OW, int Cout);   // N tile (128 | 64 | 32) launch_conv_f32 picks for a layer
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream);
 
+// RPN head (rpn_reg | rpn_cls 1x1 convs on a 512-channel float32 NHWC tensor of P pixels) as one split-K launch:
+// w_packed = pack_head_weights_host(matrix [512][ld] whose columns are reg then cls) -- 512 * 16 * ceil(ncols / 16) floats;
+// bias[ncols]; reg (P, n_reg) linear, cls (P, n_cls) sigmoid.  ncols = n_reg + n_cls <= 96.
+bool rpn_head_supported(int Cin, int ncols);
+void pack_head_weights_host(const float *w, int ld, int ncols, float *dst);
+hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
+                           float *reg, float *cls, hipStream_t stream);
+
 // MaxPooling2D(2,2) 'valid' (floors odd sizes), NHWC, C % 4 == 0
 hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
 

@@ -363,6 +363,122 @@ hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream)
     return launch_variant<4, 1, 1, 1>(a, stream);                      // 128 x 32
 }
 
+// ---- RPN head: rpn_reg (linear) | rpn_cls (sigmoid), two 1x1 convs on the 512-channel rpn_conv output ------------------
+// (models/rpn_vgg16.py:19-20 = models/rpn_mobilenet_v2.py:19-20).  As an implicit GEMM this is (B F F) x 512 x 5K with
+// 5K = 45 (75 at 15 anchors): through conv_igemm_f32 it is one 128 x 32 tile walking K = 512 in 32 barrier-separated
+// 16-channel steps, each a global -> LDS round trip -- 32-38 us whatever the batch, for 0.35 GFLOP.  Here a workgroup takes
+// 32 pixels x all columns and its four waves split K (128 channels each): every lane loads its A operand -- 32
+// consecutive channels of one pixel per 16-pixel block, k permuted accordingly: the MFMA does not care which k sits in
+// which slot as long as A and B agree -- straight from global memory with eight 16-byte loads, all in flight at once, and
+// the B operand from a fragment-ordered copy of the weight matrix (pack_head_weights_host).  The four partial sums meet
+// in LDS and are added in wave order (deterministic), + bias, sigmoid on the objectness columns.  Exact f32 MFMA.
+using f32x4_h = __attribute__((ext_vector_type(4))) float;
+
+void pack_head_weights_host(const float *w /* [512][ld] */, int ld, int ncols, float *dst /* [4][NB][64][32] */)
+{
+    const int NB = (ncols + 15) / 16;
+    for (int wv = 0; wv < 4; ++wv)
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int kk = 0; kk < 32; ++kk) {
+                    const int k = 128 * wv + 32 * (lane >> 4) + kk, n = nb * 16 + (lane & 15);
+                    dst[(((size_t)wv * NB + nb) * 64 + lane) * 32 + kk] = n < ncols ? w[(size_t)k * ld + n] : 0.0f;
+                }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256, 1)
+rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restrict__ wp, const float *__restrict__ bias,
+                int n_reg, int n_cls, float *__restrict__ reg, float *__restrict__ cls)
+{
+    __shared__ __attribute__((aligned(16))) float part[4 * 2 * NB * 64 * 4];        // [wave][tile][lane][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const long long p0 = (long long)blockIdx.x * 32;
+    // A: pixel p0 + 16 mb + lr, channels 128 wave + 32 lk .. + 32 (rows beyond P repeat the last pixel; never stored)
+    f32x4_h av[2][8];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        long long px = p0 + 16 * mb + lr;
+        if (px >= P) px = P - 1;
+        const f32x4_h *src = reinterpret_cast<const f32x4_h *>(x + px * 512 + 128 * wave + 32 * lk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[mb][i] = src[i];
+    }
+    f32x4_h acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+    const f32x4_h *wsrc = reinterpret_cast<const f32x4_h *>(wp) + ((size_t)wave * NB * 64 + lane) * 8;
+    f32x4_h bv[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[0][i] = wsrc[i];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (nb + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bv[(nb + 1) & 1][i] = wsrc[(size_t)(nb + 1) * 64 * 8 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][i][e], bv[nb & 1][i][e], acc[mb][nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            *reinterpret_cast<f32x4_h *>(&part[(((wave * 2 + mb) * NB + nb) * 64 + lane) * 4]) = acc[mb][nb];
+    __syncthreads();
+    // tile t = mb * NB + nb is finished by wave t % 4: partial sums added in wave order
+    for (int t = wave; t < 2 * NB; t += 4) {
+        const int mb = t / NB, nb = t - mb * NB;
+        f32x4_h sum = *reinterpret_cast<const f32x4_h *>(&part[(((0 * 2 + mb) * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) {
+            const f32x4_h v = *reinterpret_cast<const f32x4_h *>(&part[(((wv * 2 + mb) * NB + nb) * 64 + lane) * 4]);
+            sum += v;
+        }
+        const int n = nb * 16 + lr;
+        if (n >= n_reg + n_cls) continue;
+        const float b = bias[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long px = p0 + 16 * mb + 4 * lk + i;
+            if (px >= P) continue;
+            const float v = sum[i] + b;
+            if (n < n_reg) reg[px * n_reg + n] = v;
+            else cls[px * n_cls + (n - n_reg)] = 1.0f / (1.0f + expf(-v));
+        }
+    }
+}
+
+bool rpn_head_supported(int Cin, int ncols) { return Cin == 512 && ncols >= 1 && ncols <= 96; }
+
+hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
+                           float *reg, float *cls, hipStream_t stream)
+{
+    const int ncols = n_reg + n_cls;
+    if (!rpn_head_supported(512, ncols) || P <= 0 || (P + 31) / 32 > 0x7fffffffll) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((P + 31) / 32));
+    const int NB = (ncols + 15) / 16;
+#define RPN_HEAD(NB_) hipLaunchKernelGGL(rpn_head_kernel<NB_>, grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls)
+    switch (NB) {
+        case 1: RPN_HEAD(1); break;
+        case 2: RPN_HEAD(2); break;
+        case 3: RPN_HEAD(3); break;
+        case 4: RPN_HEAD(4); break;
+        case 5: RPN_HEAD(5); break;
+        default: RPN_HEAD(6); break;
+    }
+#undef RPN_HEAD
+    return hipGetLastError();
+}
+
 // ---- MaxPooling2D(2,2) 'valid' -----------------------------------------------------------
 __global__ void __launch_bounds__(256)
 maxpool2x2_kernel(const float *__restrict__ x, int H, int W, int C4, int OH, int OW, long long total,

@@ -95,6 +95,7 @@ struct rpn_model {
     int prof_rotate = 0;                    // with a mask: each forward times ONE of the marked ops, round robin
     std::vector<int> prof_timed;            // per kept forward: the op timed in it (-1: every marked op)
     long long profiled_forwards = 0;
+    std::vector<float> head_host;           // host copy of the fused head matrix [512][cout_pad] (source of the fragment-ordered copy)
 };
 
 namespace rpn {
@@ -116,6 +117,13 @@ static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
     if (Cout <= 64 && !(c64 && dma && Cin % 64 == 0)) return false;
     if (dma && Cin % 64 == 0) return true;
     return Cin >= 128;
+}
+
+// RPN_HEAD_SPLITK=0: the head through the generic float32 implicit GEMM (one 128 x 32 tile walking K in 32 steps)
+static bool head_splitk()
+{
+    static const int on = getenv("RPN_HEAD_SPLITK") ? atoi(getenv("RPN_HEAD_SPLITK")) : 1;
+    return on != 0;
 }
 
 static int add_tensor(rpn_model *m, const std::string &name, int H, int W, int C, bool external = false)
@@ -458,6 +466,10 @@ static void plan_weights(rpn_model *m)
             off += (op.ps.floats() + 63) & ~(size_t)63;
             op.b_off = off;
             off += (size_t)op.ps.cout_pad;
+            if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout)) {      // fragment-ordered copy for rpn_head_kernel
+                op.ir_off[0] = off;
+                off += (size_t)512 * 16 * ((op.Cout + 15) / 16);
+            }
         } else if (op.kind == OP_DWCONV) {
             op.w_off = off;
             off += ((size_t)9 * op.Cin + 63) & ~(size_t)63;
@@ -698,6 +710,14 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                   hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off + p.col_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+        if (rpn_head_supported(op.Cin, op.Cout)) {
+            m->head_host.resize((size_t)512 * ps.cout_pad, 0.0f);
+            for (int k = 0; k < 512; ++k)
+                memcpy(&m->head_host[(size_t)k * ps.cout_pad + p.col_off], kernel + (size_t)k * p.Cout, (size_t)p.Cout * sizeof(float));
+            std::vector<float> packed((size_t)512 * 16 * ((op.Cout + 15) / 16));
+            pack_head_weights_host(m->head_host.data(), ps.cout_pad, op.Cout, packed.data());
+            RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.ir_off[0], packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     } else if (op.cin3_mfma) {
         // the power-of-two pre-scale is derived from the FOLDED weights (a BatchNorm scale of 30 on top of a shift
         // chosen for the raw kernel would push the float16 hi halves past 65504)
@@ -824,6 +844,9 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             skip_next = fuse_pool;
         } else if (op.kind == OP_POOL && op.split) {
             e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
+        } else if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout) && head_splitk()) {
+            e = launch_rpn_head(x, (long long)B * op.H * op.W, m->d_weights + op.ir_off[0], m->d_weights + op.b_off, 4 * m->K,
+                                m->K, d_reg, d_cls, s);
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
             a.x = x;
@@ -958,8 +981,11 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         fl = 2.0 * op.OH * op.OW * op.Cout * op.R * op.S * op.Cin;
         by = in_b + out_b + 4.0 * op.R * op.S * op.Cin * op.Cout;
         static thread_local char kname32[64];
-        snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
-                 op.ps.generic ? ",generic" : "");
+        if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout) && head_splitk())
+            snprintf(kname32, sizeof kname32, "rpn_head_splitk<%d>", (op.Cout + 15) / 16);
+        else
+            snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
+                     op.ps.generic ? ",generic" : "");
         k = kname32;
     } else if (op.kind == OP_VGGB1) {
         fl = 2.0 * op.H * op.W * 64 * 9.0 * (3 + 64);
