@@ -411,6 +411,43 @@ def test_split_conv_dynamic_tile_schedule_subprocess():
 
 
 @pytest.mark.gpu
+def test_small_batch_split_k_subprocess():
+    """RPN_KSPLIT=1 (read once per process): at small batches rpn_conv is cut 2 or 4 ways along K, its raw partial sums
+    land in slabs and the head adds them (+ rpn_conv's bias, ReLU) while loading its operand.  Same 1e-4 bound against
+    the float64 oracle for both backbones and both split factors; the default path (one accumulation chain, bit-identical
+    across batch sizes) must differ from it by rounding only; a batch that is too large for the split runs unsplit on the
+    same handle."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from oracle import bbox_oracle as bo, conv_oracle as cv
+        from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+        for backbone, img, B in [("vgg16", 500, 1), ("vgg16", 500, 3), ("mobilenet_v2", 500, 2), ("mobilenet_v2", 1024, 1),
+                                 ("vgg16", 96, 2)]:
+            hp = bo.get_hyper_params(backbone, img_size=img, feature_map_shape=None)
+            w = synthetic_weights(backbone, hp, seed=3)
+            for v in w.values():
+                if "bias" in v:
+                    v["bias"] = np.random.RandomState(len(v["bias"])).uniform(-0.1, 0.1, size=v["bias"].shape).astype(np.float32)
+            imgs = np.random.RandomState(B).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+            m = RPNModel(backbone, hp, precision="f16x3", max_batch=max(B, 4))
+            m.set_weights(w)
+            reg, cls = m.predict_on_batch(imgs)
+            ref = cv.rpn_forward(backbone, imgs, w, dtype=torch.float64)
+            e = max(np.abs(reg - ref[0]).max(), np.abs(cls - ref[1]).max())
+            assert e <= 1e-4, (backbone, img, B, e)
+            r1, c1 = m.predict_on_batch(imgs[:1])                 # another split factor (or none) on the same handle
+            assert np.abs(r1[0] - reg[0]).max() <= 2e-6 and np.abs(c1[0] - cls[0]).max() <= 2e-6
+            print("ksplit ok", backbone, img, B, "%%.2e" %% e)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, RPN_KSPLIT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ksplit ok") == 5
+
+
+@pytest.mark.gpu
 def test_persistent_conv_repeats_bit_identically():
     """Race screen of the LDS-DMA pipeline (scripts/race_screen.py is the long version): a DMA that lands after its
     reader shows up as a rarely different tile, so the same launch repeated -- beside a second stream that perturbs the

@@ -54,8 +54,11 @@ hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream);
 // bias[ncols]; reg (P, n_reg) linear, cls (P, n_cls) sigmoid.  ncols = n_reg + n_cls <= 96.
 bool rpn_head_supported(int Cin, int ncols);
 void pack_head_weights_host(const float *w, int ld, int ncols, float *dst);
+// n_slabs >= 2: x is n_slabs RAW partial-sum slabs of the preceding conv (slab_floats apart); the head adds them in slab
+// order, + conv_bias, ReLU (rpn_conv's epilogue), while it loads its operand.
 hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
-                           float *reg, float *cls, hipStream_t stream);
+                           float *reg, float *cls, hipStream_t stream, int n_slabs = 1, long long slab_floats = 0,
+                           const float *conv_bias = nullptr);
 
 // MaxPooling2D(2,2) 'valid' (floors odd sizes), NHWC, C % 4 == 0
 hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
@@ -107,6 +110,10 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
 // which 16x16x32 kernel launch_conv3x3_split16 picks for a layer: "dma,128" | "dma,64" (persistent LDS-DMA kernel,
 // tile width in channels) or "reg,128" | "reg,64" (register-staged kernels); nullptr: not launchable
 const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int cout_pad, bool pool);
+// split-K for a layer whose consumer adds partial-sum slabs (rpn_conv -> the RPN head): factor (1 = none) and launch
+int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad);
+hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *out, long long slab_floats, int B, int H, int W,
+                                         int Cin, int Cout, int cout_pad, float out_scale, bool f16, int ksplit, hipStream_t s);
 hipError_t launch_f32_to_split(const float *x, long long npix, int C, bool f16, void *out, hipStream_t s);
 hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, float *out, hipStream_t s);
 hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);

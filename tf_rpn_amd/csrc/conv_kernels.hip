@@ -389,7 +389,8 @@ void pack_head_weights_host(const float *w /* [512][ld] */, int ld, int ncols, f
 template <int NB>
 __global__ void __launch_bounds__(256, 1)
 rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restrict__ wp, const float *__restrict__ bias,
-                int n_reg, int n_cls, float *__restrict__ reg, float *__restrict__ cls)
+                int n_reg, int n_cls, float *__restrict__ reg, float *__restrict__ cls, int n_slabs, long long slab_floats,
+                const float *__restrict__ conv_bias)
 {
     __shared__ __attribute__((aligned(16))) float part[4 * 2 * NB * 64 * 4];        // [wave][tile][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,6 +405,20 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
         const f32x4_h *src = reinterpret_cast<const f32x4_h *>(x + px * 512 + 128 * wave + 32 * lk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) av[mb][i] = src[i];
+        if (n_slabs > 1) {              // split-K producer: add the partial sums in slab order, + its bias, ReLU
+            for (int sl = 1; sl < n_slabs; ++sl) {
+                const f32x4_h *ss = reinterpret_cast<const f32x4_h *>(x + (size_t)sl * slab_floats + px * 512 + 128 * wave + 32 * lk);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) av[mb][i] += ss[i];
+            }
+            const f32x4_h *cb = reinterpret_cast<const f32x4_h *>(conv_bias + 128 * wave + 32 * lk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4_h v = av[mb][i] + cb[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[mb][i][e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+        }
     }
     f32x4_h acc[2][NB];
 #pragma unroll
@@ -460,13 +475,16 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
 bool rpn_head_supported(int Cin, int ncols) { return Cin == 512 && ncols >= 1 && ncols <= 96; }
 
 hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
-                           float *reg, float *cls, hipStream_t stream)
+                           float *reg, float *cls, hipStream_t stream, int n_slabs, long long slab_floats, const float *conv_bias)
 {
+    if (n_slabs < 1 || (n_slabs > 1 && !conv_bias)) return hipErrorInvalidValue;
     const int ncols = n_reg + n_cls;
     if (!rpn_head_supported(512, ncols) || P <= 0 || (P + 31) / 32 > 0x7fffffffll) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((P + 31) / 32));
     const int NB = (ncols + 15) / 16;
-#define RPN_HEAD(NB_) hipLaunchKernelGGL(rpn_head_kernel<NB_>, grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls)
+#define RPN_HEAD(NB_)                                                                                                 \
+    hipLaunchKernelGGL(rpn_head_kernel<NB_>, grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls, n_slabs, \
+                       slab_floats, conv_bias)
     switch (NB) {
         case 1: RPN_HEAD(1); break;
         case 2: RPN_HEAD(2); break;

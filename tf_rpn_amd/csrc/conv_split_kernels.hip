@@ -183,6 +183,10 @@ struct SplitConvArgs {
     const uint4 *w1;      // first-layer weights [64][8 pieces] (pack_weights_cin3_mfma_host)
     const float *b1;      // first-layer bias (64)
     float scale1;         // 2^-s of the pre-scaled first-layer weights
+    // conv3x3_split16_kernel only: split-K over gridDim.y workgroups per tile.  Workgroup y accumulates the 32-channel
+    // slices [y * chunks / gridDim.y, (y + 1) * chunks / gridDim.y) and writes its RAW partial sums (x out_scale; no bias,
+    // no activation) as float32 NHWC to slab y of `out` (slab_floats apart); the consumer adds the slabs.
+    long long slab_floats;
 };
 
 // TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64).
@@ -747,7 +751,9 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     RPN_STAMP_VAL(1, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));       // XCC_ID, HW_ID
 
-    const int chunks = a.Cin >> 5;                    // 32-channel slices
+    const int all_chunks = a.Cin >> 5;                // 32-channel slices
+    const int c_begin = (int)((long long)blockIdx.y * all_chunks / gridDim.y);        // split-K: this workgroup's slices
+    const int chunks = (int)((long long)(blockIdx.y + 1) * all_chunks / gridDim.y);   // (one past its last slice)
     const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
     const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
@@ -813,15 +819,15 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
 
 #pragma unroll
-    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN16_LOAD_A(0, R);
-    RPN16_LOAD_B(0);
+    for (int R = 0; R < A_SLOTS; ++R) As[a_loff[R]] = RPN16_LOAD_A(c_begin, R);
+    RPN16_LOAD_B(3 * c_begin);
     RPN16_STORE_B();
     __syncthreads();
     RPN_STAMP_AT(2);
 
     int abuf = 0;
 #pragma unroll 1
-    for (int chunk = 0; chunk < chunks; ++chunk) {
+    for (int chunk = c_begin; chunk < chunks; ++chunk) {
         const int next_chunk = chunk + 1 < chunks ? chunk + 1 : chunk;
 #pragma unroll
         for (int row = 0; row < 3; ++row) {
@@ -868,7 +874,16 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #undef RPN16_STORE_B
 #undef RPN16_LOAD_A
 
-    split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+    if (gridDim.y > 1) {                              // split-K: raw partial sums to this workgroup's slab
+        SplitConvArgs ar = a;
+        ar.bias = nullptr;
+        ar.act = ACT_LINEAR;
+        ar.out_f32 = 1;
+        ar.out = reinterpret_cast<float *>(a.out) + (size_t)blockIdx.y * a.slab_floats;
+        split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), ar, img, oy0, ox0, n0, wave, wm, wn, lane);
+    } else {
+        split16_epilogue<F16, POOL, RW, NW>(acc, reinterpret_cast<float *>(lds), a, img, oy0, ox0, n0, wave, wm, wn, lane);
+    }
     RPN_STAMP_AT(3);
 }
 
@@ -1996,6 +2011,47 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
         if (pool) RPN_L16(8, 2, 8, false, true); else RPN_L16(8, 2, 8, false, false);
     }
 #undef RPN_L16
+    return hipGetLastError();
+}
+
+// Split-K factor for a 3x3 layer whose only consumer can add partial-sum slabs (rpn_conv -> the RPN head): grids of at
+// most a quarter / half of the CUs (batch-1 feature maps) are cut 4 / 2 ways along K so that the layer's time is no longer
+// one workgroup's walk through all of K.  1: no split.
+int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)
+{
+    // Off by default: the partial sums are added in a different order than the one-chain accumulation, so a batch-1 result
+    // would no longer be bit-identical to the same image inside a larger batch (tests/test_gpu_configs.py holds the
+    // path to that).  RPN_KSPLIT=1 is the latency option: MobileNetV2 500 x 500, one image: 0.326 -> 0.292 ms.
+    static const int on = getenv("RPN_KSPLIT") ? atoi(getenv("RPN_KSPLIT")) : 0;
+    const char *v = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, false);
+    if (!on || !v || strcmp(v, "reg,64") != 0) return 1;
+    const long long blocks = (long long)((W + 31) / 32) * ((H + 3) / 4) * B * ((Cout + 63) / 64);
+    const int chunks = Cin / 32;
+    int s = blocks <= 128 ? 4 : (blocks <= 256 ? 2 : 1);          // (2 workgroups of this kernel fit a CU: 512 slots)
+    while (s > 1 && chunks / s < 2) s >>= 1;
+    return s;
+}
+
+// The split-K form of launch_conv3x3_split16 (4 x 32 x 64 register-staged tiles): out = ksplit float32 NHWC slabs of
+// (B,H,W,Cout), slab_floats apart, holding RAW partial sums (no bias, no activation).
+hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *out, long long slab_floats, int B, int H, int W,
+                                         int Cin, int Cout, int cout_pad, float out_scale, bool f16, int ksplit, hipStream_t s)
+{
+    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 128 != 0 || ksplit < 2 || ksplit > Cin / 32) return hipErrorInvalidValue;
+    SplitConvArgs a{};
+    a.status = nullptr;
+    a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = nullptr; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
+    a.out_scale = out_scale; a.act = ACT_LINEAR; a.out_f32 = 1; a.slab_floats = slab_floats;
+    const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 3) / 4;
+    const int n_tiles = (Cout + 63) / 64;
+    const long long m_tiles = (long long)tiles_x * tiles_y * B;
+    const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+    const long long nblocks = 8ll * ((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
+    if (m_tiles <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblocks, (unsigned)ksplit);
+    if (f16) hipLaunchKernelGGL((conv3x3_split16_kernel<4, 1, 4, true, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, n_tiles);
+    else hipLaunchKernelGGL((conv3x3_split16_kernel<4, 1, 4, false, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
 

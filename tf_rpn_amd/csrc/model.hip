@@ -31,7 +31,8 @@ struct Tensor {
     size_t offset = 0;                 // floats per image inside the arena (x max_batch)
     bool external = false;             // input images / head outputs
     bool split_fmt = false;            // SPLIT16 (hi/lo 16-bit records) instead of float32 NHWC; same byte size
-    size_t floats() const { return (size_t)H * W * C; }
+    int slabs = 1;                     // room for this many copies (split-K partial sums of rpn_conv at small batches)
+    size_t floats() const { return (size_t)H * W * C * slabs; }
 };
 
 struct Param {
@@ -228,6 +229,17 @@ static void add_head(rpn_model *m, int feat)
 {
     const Tensor tf = m->tensors[feat];
     const int x = add_conv(m, "rpn_conv", "", feat, 512, 3, 1, 1, 1, tf.H, tf.W, ACT_RELU, -1, true);
+    {   // split-K of rpn_conv at small batches (its partial-sum slabs are added by the head): room for the largest S * B
+        const Op &cv = m->ops.back();
+        if (cv.split && cv.k16 && cv.out_f32 && !m->keep_all && rpn_head_supported(512, 5 * m->K) && head_splitk()) {
+            int cap = m->max_batch;
+            for (int b = 1; b <= m->max_batch; ++b) {
+                const int sk = conv3x3_split16_ksplit(b, cv.H, cv.W, cv.Cin, cv.Cout, split_cout_pad(cv.Cout));
+                if (sk * b > cap) cap = sk * b;
+            }
+            m->tensors[x].slabs = (cap + m->max_batch - 1) / m->max_batch;
+        }
+    }
     Op op;
     op.kind = OP_HEAD; op.name = "rpn_head"; op.in = x;
     op.Cin = 512; op.Cout = 5 * m->K; op.R = op.S = 1; op.stride = 1;
@@ -815,6 +827,8 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     if (evs && want_event(0)) RPN_HIP_CHECK(hipEventRecord(evs[0], s));
     int op_index = 0;
     bool skip_next = false;
+    int head_slabs = 1;                     // > 1: the head's input is that many partial-sum slabs of a split-K rpn_conv
+    size_t head_conv_bias = 0;
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const Op &op = m->ops[oi];
         const float *x = tensor_ptr(m, op.in, d_imgs);
@@ -836,6 +850,18 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             e = launch_conv_cin3(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs), B,
                                  op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
                                  m->tensors[op.out].split_fmt ? 1 : 0, m->f16, s);
+        } else if (op.kind == OP_CONV && op.split && op.k16 && op.out_f32 && !m->keep_all && m->tensors[op.out].slabs >= 1 &&
+                   oi + 1 < m->ops.size() && m->ops[oi + 1].kind == OP_HEAD && m->ops[oi + 1].in == op.out &&
+                   rpn_head_supported(512, 5 * m->K) && head_splitk() &&
+                   conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout)) > 1 &&
+                   (size_t)conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout)) * B <=
+                       (size_t)m->tensors[op.out].slabs * m->max_batch) {
+            // rpn_conv at a small batch: split-K, raw partial sums; the head adds the slabs (+ this layer's bias, ReLU)
+            head_slabs = conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout));
+            head_conv_bias = op.b_off;
+            e = launch_conv3x3_split16_ksplit(x, m->d_weights + op.w_off, tensor_ptr(m, op.out, d_imgs),
+                                              (long long)B * op.H * op.W * op.Cout, B, op.H, op.W, op.Cin, op.Cout,
+                                              split_cout_pad(op.Cout), op.out_scale, m->f16, head_slabs, s);
         } else if (op.kind == OP_CONV && op.split) {
             const int dst = fuse_pool ? m->ops[oi + 1].out : op.out;
             e = (op.k16 ? launch_conv3x3_split16 : launch_conv3x3_split)(
@@ -846,7 +872,9 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
         } else if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout) && head_splitk()) {
             e = launch_rpn_head(x, (long long)B * op.H * op.W, m->d_weights + op.ir_off[0], m->d_weights + op.b_off, 4 * m->K,
-                                m->K, d_reg, d_cls, s);
+                                m->K, d_reg, d_cls, s, head_slabs, (long long)B * op.H * op.W * 512,
+                                head_slabs > 1 ? m->d_weights + head_conv_bias : nullptr);
+            head_slabs = 1;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
             a.x = x;
