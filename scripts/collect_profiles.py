@@ -68,6 +68,7 @@ for cfg in ("c4", "c5", "mn8"):
     copy("bench_%s.json" % cfg, "%s_%s_bench.json" % (tag, cfg))
     copy("bench_%s_layers.txt" % cfg, "%s_%s_bench_layers.txt" % (tag, cfg))
 copy("bbox_c3.json", "%s_c3_bbox_kernels.json" % tag)
+stats(os.path.join(src, "stats", "stats_kernel_stats.csv"), "%s_f16x3_bench_kernel_stats.csv" % tag)   # scripts/round2_final.sh
 stats(os.path.join(src, "c3_stats", "c3_kernel_stats.csv"), "%s_c3_kernel_stats.csv" % tag)
 stats(os.path.join(src, "mn8_stats", "mn8_kernel_stats.csv"), "%s_mn8_kernel_stats.csv" % tag)
 stats(os.path.join(src, "c5_stats", "c5_kernel_stats.csv"), "%s_c5_kernel_stats.csv" % tag)

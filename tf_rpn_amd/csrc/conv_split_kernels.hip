@@ -320,11 +320,13 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     float *patchf = reinterpret_cast<float *>(lds + (LDS_PIPE > LDS_STAGE ? LDS_PIPE : LDS_STAGE));
     const int lr = lane & 15, kg = lane >> 4;
     u32x4 phi[QB], plo[QB];            // im2col fragments (8 of the 32 k of pixel lr): hi / lo halves
-    int pdst[QB];                      // byte offset of this lane's 8-byte run inside a halo buffer (< 0: no pixel)
+    int pdst[QB];                      // byte offset of this lane's 8-byte run inside a halo buffer (no pixel: the dummy slot)
+    float b1_max = 0.0f;               // largest first-layer activation this lane produced (float16 range check)
     unsigned pin = 0;                  // bit q: the pixel is inside the image
     u32x4 w1hi = {0, 0, 0, 0}, w1lo = {0, 0, 0, 0};
     f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
     (void)patchf; (void)lr; (void)kg; (void)pin; (void)phi; (void)plo; (void)pdst; (void)w1hi; (void)w1lo; (void)b1v;
+    (void)b1_max;
 #define RPN_B1_LOADW(CHUNK)                                                                            \
     {                                                                                                  \
         const u32x4 *w1_ = reinterpret_cast<const u32x4 *>(a.w1) + ((CHUNK) * 16 + lr) * 8 + kg;       \
@@ -332,9 +334,12 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         w1lo = w1_[4];                                                                                 \
         b1v = *reinterpret_cast<const f32x4 *>(a.b1 + (CHUNK) * 16 + 4 * kg);                          \
     }
-    // block Q of the slice whose weights are in w1hi / w1lo -> halo buffer BUF
+    // block Q of the slice whose weights are in w1hi / w1lo -> halo buffer BUF.  Branch-free, so that the scheduler may
+    // place this work among the tap MFMAs of the interval: lanes without a pixel (the tail of the last block, the
+    // blocks past it) store to the buffer's dummy slot, and the float16 range check is one max per block, tested once
+    // at the end of the kernel.
 #define RPN_B1_BLOCK(Q, BUF)                                                                           \
-    if (wave + NW * (Q) < NBLK) {                                                                      \
+    {                                                                                                  \
         f32x4 c_ = {0.f, 0.f, 0.f, 0.f};                                                               \
         c_ = mfma16<F16>(w1lo, phi[Q], c_);                                                            \
         c_ = mfma16<F16>(w1hi, plo[Q], c_);                                                            \
@@ -343,23 +348,17 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         using h4_ = __attribute__((ext_vector_type(4))) E_;                                            \
         const bool in_ = (pin >> (Q)) & 1u;                                                            \
         h4_ hv_, lv_;                                                                                  \
-        float mx_ = 0.0f;                                                                              \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                             \
             float v_ = fmaxf(c_[r_] * a.scale1 + b1v[r_], 0.0f);                                       \
             v_ = in_ ? v_ : 0.0f;                                                                      \
-            mx_ = fmaxf(mx_, v_);                                                                      \
+            b1_max = fmaxf(b1_max, v_);                                                                \
             const E_ h_ = (E_)v_;                                                                      \
             hv_[r_] = h_;                                                                              \
             lv_[r_] = (E_)(v_ - (float)h_);                                                            \
         }                                                                                              \
-        if constexpr (F16) {                                                                           \
-            if (a.status && !(mx_ <= 65504.0f)) atomicOr(a.status, 1u /* RPN_STATUS_F16_RANGE */);     \
-        }                                                                                              \
-        if (pdst[Q] >= 0) {                                                                            \
-            char *d_ = reinterpret_cast<char *>(As + (BUF) * ABUF);                                    \
-            *reinterpret_cast<uint2 *>(d_ + pdst[Q]) = __builtin_bit_cast(uint2, hv_);                 \
-            *reinterpret_cast<uint2 *>(d_ + (pdst[Q] ^ 16)) = __builtin_bit_cast(uint2, lv_);          \
-        }                                                                                              \
+        char *d_ = reinterpret_cast<char *>(As + (BUF) * ABUF);                                        \
+        *reinterpret_cast<uint2 *>(d_ + pdst[Q]) = __builtin_bit_cast(uint2, hv_);                     \
+        *reinterpret_cast<uint2 *>(d_ + (pdst[Q] ^ 16)) = __builtin_bit_cast(uint2, lv_);              \
     }
     if constexpr (B1) {
         // image patch: rows oy0 - 2 .. oy0 + TH + 1, columns ox0 - 2 .. ox0 + 33, zero outside the image
@@ -418,7 +417,7 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
             const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) pin |= 1u << q;
             // channels 4 kg .. 4 kg + 3 of the slice: hi piece 2 * (kg >> 1), its half (kg & 1); lo piece = hi piece ^ 1
-            pdst[q] = valid ? (pp * 4 + ((2 * (kg >> 1)) ^ ((hx >> 2) & 3))) * 16 + (kg & 1) * 8 : -1;
+            pdst[q] = valid ? (pp * 4 + ((2 * (kg >> 1)) ^ ((hx >> 2) & 3))) * 16 + (kg & 1) * 8 : HP * 4 * 16 + (kg & 1) * 8;
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) RPN_B1_BLOCK(q, 0);
@@ -475,10 +474,10 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
             if (BBUF == 1) __syncthreads();              // every wave is done reading the single weight buffer
             RPN_STORE_B(BBUF == 2 ? (bbuf ^ 1) : 0);
             if constexpr (B1) {
-                if (chunk + 1 < chunks) {                    // the next slice's halo tile: QPS blocks per interval
+                // the next slice's halo tile: QPS blocks per interval (in the last slice: that slice's own tile once more,
+                // into the idle buffer -- cheaper than a branch that would fence this work off from the MFMAs)
 #pragma unroll
-                    for (int q = row * QPS; q < (row + 1) * QPS && q < QB; ++q) RPN_B1_BLOCK(q, abuf ^ 1);
-                }
+                for (int q = row * QPS; q < (row + 1) * QPS && q < QB; ++q) RPN_B1_BLOCK(q, abuf ^ 1);
             } else {
 #pragma unroll
                 for (int q = 0; q < A_RPS; ++q) As[(abuf ^ 1) * ABUF + a_loff[row * A_RPS + q]] = a_reg[q];
@@ -494,6 +493,9 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #undef RPN_LOAD_A
 #undef RPN_B1_LOADW
 #undef RPN_B1_BLOCK
+    if constexpr (B1 && F16) {
+        if (a.status && !(b1_max <= 65504.0f)) atomicOr(a.status, 1u /* RPN_STATUS_F16_RANGE */);
+    }
     // ---- epilogue: scale + bias + activation (+ fused 2x2 max-pool), transpose through LDS, 16-byte stores --
     float *stage = reinterpret_cast<float *>(lds) + wave * (32 * STAGE_LD);
     float bias_v[NI];
@@ -901,10 +903,10 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 //   * persistent workgroups (one per CU) walk the tiles of their XCD: the tap stream simply continues into the next
 //     tile (its halo tile and first weights are DMA'd during the last slice of the current one), so there is no
 //     prologue and no dispatch gap between tiles.
-//   * the MFMA operands are swapped (weights as A, pixels as B): a lane's 4 accumulator registers are then 4 consecutive
-//     CHANNELS of one pixel and the epilogue stores straight from registers (8-byte hi / lo halves of a SPLIT16 piece,
-//     or float4), no LDS staging -- the LDS stays free for the next tile's DMAs, and a wave that finishes its epilogue
-//     early already computes the next tile's first tap beside its SIMD partner's epilogue.
+//   * the epilogue stages through halo buffer 1 + the LDS left over (dead until the next tile's first interval refills
+//     them), one workgroup barrier per tile.  (Tried and dropped: swapped MFMA operands -- weights as A, pixels as B, so
+//     that a lane's 4 accumulator registers are 4 consecutive CHANNELS of one pixel -- with 8-byte stores straight from
+//     registers: 9.8k against 6.5k cycles per tile, the store issue became the limit.)
 // Hazards, by the rule "read a DMA'd buffer one interval after the wait that retires it":
 //   RAW  weights(t+2) (issued in interval t-1) are retired by the counted vmcnt at the end of interval t (which leaves
 //        only interval t's own DMAs in flight), then the barrier; read in interval t+1.  Halo pieces likewise (issued in
