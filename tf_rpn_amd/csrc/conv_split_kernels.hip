@@ -1237,6 +1237,9 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 // counter would otherwise make the wave wait for that epilogue's global stores -- all 256 workgroups
                 // finish their tiles together, so those stores are a burst (stamps: 12.9k cycles of epilogue in steady
                 // state against 6.5k on a workgroup's first tile).  The stores now have two intervals to drain.
+#ifdef RPN_EXP_HALF_BARRIERS                /* timing experiment only (results are wrong): a barrier every second tap */
+                if ((T & 1) == 0) continue;
+#endif
                 if (T == 0 && pair == 0) {
                 } else if constexpr (B_PER_WAVE == 2) {
                     if (s9 < A_PER_WAVE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
