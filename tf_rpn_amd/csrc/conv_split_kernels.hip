@@ -1166,7 +1166,9 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                         if (nxt >= 0) { tap = gt - total_taps; nb = nn0; }
                         else tap = total_taps - 1;
                     }
+#ifndef RPN_EXP_NO_DMA
                     RPN_DMA_B(tap * w_tap_bytes + nb * (PPP * 16), s9 % 3);
+#endif
                     ++gt;
                 }
                 if (dyn && pair == 0) {     // (nothing before tap 9 of the last slice needs to know the next tile)
@@ -1182,12 +1184,16 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 }
                 if (s9 < A_PER_WAVE) {      // halo piece s9 of the next slice: this tile's, or slice 0 of the next tile
                     const int nc = 2 * pair + c2 + 1;
+#ifndef RPN_EXP_NO_DMA
                     RPN_DMA_A(s9, a_goff[s9], nc < chunks ? nc * 128 : (nxt >= 0 ? 0 : (chunks - 1) * 128), (c2 + 1) & 1);
+#endif
                 }
                 // ---- half 0: row 0.  Program order = intended issue order: a fragment read behind each of the first MFMAs
 #pragma unroll
                 for (int i = 0; i < 2 * NJ; ++i) {    // chain heads (x lo * w hi) of tiles (m = i / NJ, j = i % NJ)
+#ifndef RPN_EXP_NO_LDSREAD
                     if (i < 4) fx1[i] = RPN_X_ADDR(CB, CR, CC, 1, i);
+#endif
                     acc[i / NJ][i % NJ] = mfma16<F16>(fx0[2 * (i / NJ) + 1], fw[CS][2 * (i % NJ)], acc[i / NJ][i % NJ]);
                 }
 #pragma unroll
@@ -1209,12 +1215,18 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 // ---- half 1: row 1; the next tap's weights and row-0 pixels arrive meanwhile
 #pragma unroll
                 for (int i = 0; i < 2 * NJ; ++i) {
+#ifndef RPN_EXP_NO_LDSREAD
                     fw[NS][i] = RPN_W_ADDR(NC, i);
+#else
+                    fw[NS][i] = fw[CS][i];
+#endif
                     acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ) + 1], fw[CS][2 * (i % NJ)], acc[2 + i / NJ][i % NJ]);
                 }
 #pragma unroll
                 for (int i = 0; i < 2 * NJ; ++i) {
+#ifndef RPN_EXP_NO_LDSREAD
                     if (i < 4) fx0[i] = RPN_X_ADDR(NB, NR, NC, 0, i);
+#endif
                     acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ)], fw[CS][2 * (i % NJ) + 1], acc[2 + i / NJ][i % NJ]);
                     acc[2 + i / NJ][i % NJ] = mfma16<F16>(fx1[2 * (i / NJ)], fw[CS][2 * (i % NJ)], acc[2 + i / NJ][i % NJ]);
                 }
@@ -1262,7 +1274,12 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
         if (tile_no < 2) RPN_STAMP_AT(20 + 6 * tile_no);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last interval's weight DMAs (issued a whole interval ago)
         if (tile_no < 2) RPN_STAMP_AT(21 + 6 * tile_no);
-#ifdef RPN_STAMP
+#ifdef RPN_EXP_NO_EPILOGUE                  /* timing experiment only: the accumulators are kept alive, nothing is written */
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[m][j]));
+#elif defined(RPN_STAMP)
         split16_epilogue<F16, POOL, RW, NW, NJ>(acc, reinterpret_cast<float *>(lds + A1_AT), a, img, oy0, ox0, n0, wave, wm, wn, lane,
                                                 tile_no < 2 ? 22 + 6 * tile_no : -1);
 #else
