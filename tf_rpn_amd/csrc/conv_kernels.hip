@@ -156,6 +156,46 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     float a_sreg[GENERIC ? 8 : 1];
     float4 b_reg[NB4];
 
+    // Fast path: the gather walks (tap, 16-channel slice) incrementally and loads through raw buffer descriptors -- an
+    // out-of-image pixel, a channel quad beyond Cin or a weight column beyond cout_pad is an out-of-range offset for
+    // which the hardware returns zeros: no division, no predicated branch around a load in the loop (the first
+    // version spent ~75 vector and ~50 scalar instructions and six exec-masked branches per 32 MFMAs here, on an
+    // issue port the float32 MFMA shares with the vector ALU).
+    constexpr unsigned kOobF = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), (short)0, (int)((size_t)a.H * a.W * a.Cin * 4 > 0x7fffffffull ? 0x7fffffff : (size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), (short)0, (int)(a.ps.floats() * 4 > 0x7fffffffull ? 0x7fffffff : a.ps.floats() * 4), 0x00020000);
+    int a_off0[2];                      // byte offset of (pixel j, tap (0,0), channel 4 a_q); may be negative (padding)
+    unsigned a_taps[2];                 // bit t: tap t of pixel j lies inside the image
+    unsigned b_off[NB4];                // byte offset of this thread's float4 in weight rows 0..15 (or kOobF)
+    if constexpr (!GENERIC) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            a_off0[j] = ((a_iy0[j] * a.W + a_ix0[j]) * a.Cin + 4 * a_q) * 4;
+            unsigned m = 0;
+            int t = 0;
+            for (int r = 0; r < a.R; ++r)
+                for (int q = 0; q < a.S; ++q, ++t) {
+                    const int iy = a_iy0[j] + r, ix = a_ix0[j] + q;
+                    if (t < 32 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << t;
+                }
+            a_taps[j] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int e = tid + i * kConvThreads;
+            const int kk = e / (BN / 4);
+            const int col = n0 + 4 * (e % (BN / 4));
+            const bool v = (B4 % kConvThreads == 0 || e < B4) && col < a.ps.cout_pad;
+            b_off[i] = v ? (unsigned)((kk * a.ps.cout_pad + col) * 4) : kOobF;
+        }
+    }
+    // walk state of the NEXT slice to load: tap index, its (r, s), slice within the tap, byte offset of the tap
+    int w_tap = 0, w_r = 0, w_s = 0, w_cs = 0, w_tapoff = 0;
+    const int b_step = 16 * a.ps.cout_pad * 4;          // bytes per slice of the packed weight matrix
+    int w_brow = 0;
+
     auto load_global = [&](int step) {
         if constexpr (GENERIC) {
             const int k = step * BK + a_kk;
@@ -169,27 +209,36 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                 const bool v = kv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 a_sreg[j] = v ? xin[((size_t)iy * a.W + ix) * a.Cin + c] : 0.0f;
             }
-        } else {
-            const int tap = step / cpt;
-            const int c0 = (step - tap * cpt) * BK + 4 * a_q;
-            const int r = tap / a.S, s = tap - r * a.S;
+            const int row0 = step * BK;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int iy = a_iy0[j] + r, ix = a_ix0[j] + s;
-                const bool v = c0 < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                a_reg[j] = v ? *reinterpret_cast<const float4 *>(xin + ((size_t)iy * a.W + ix) * a.Cin + c0)
+            for (int i = 0; i < NB4; ++i) {
+                const int e = tid + i * kConvThreads;
+                const int kk = e / (BN / 4);
+                const int col = n0 + 4 * (e % (BN / 4));
+                const bool v = (B4 % kConvThreads == 0 || e < B4) && col < a.ps.cout_pad;
+                b_reg[i] = v ? *reinterpret_cast<const float4 *>(a.w + (size_t)(row0 + kk) * a.ps.cout_pad + col)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
-        const int row0 = step * BK;      // both layouts: slice `step` covers packed rows [16*step, 16*step+16)
+        } else {
+            (void)step;                                  // (the walk state is the step)
+            const int c0 = w_cs * BK;
+            const bool cv = c0 + 4 * a_q < a.Cin;        // cin_pad > Cin: the quads past Cin are zero rows of the weights too
 #pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-            const int e = tid + i * kConvThreads;
-            const int kk = e / (BN / 4);
-            const int col = n0 + 4 * (e % (BN / 4));
-            const bool v = (B4 % kConvThreads == 0 || e < B4) && col < a.ps.cout_pad;
-            b_reg[i] = v ? *reinterpret_cast<const float4 *>(a.w + (size_t)(row0 + kk) * a.ps.cout_pad + col)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 2; ++j) {
+                const bool v = cv && ((a_taps[j] >> w_tap) & 1u);
+                const unsigned off = v ? (unsigned)(a_off0[j] + w_tapoff + c0 * 4) : kOobF;
+                a_reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < NB4; ++i)
+                b_reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[i], w_brow, 0));
+            w_brow += b_step;
+            if (++w_cs == cpt) {                         // next tap (scalar bookkeeping)
+                w_cs = 0;
+                ++w_tap;
+                if (++w_s == a.S) { w_s = 0; ++w_r; }
+                w_tapoff = (w_r * a.W + w_s) * a.Cin * 4;
+            }
         }
     };
 
