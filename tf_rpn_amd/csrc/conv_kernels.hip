@@ -18,6 +18,7 @@
 // Roofline: MFMA-bound; 2*M*N*K flops per launch against 157.3 TFLOP/s (f32 MFMA peak).
 #include "conv_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace rpn {
@@ -388,7 +389,9 @@ static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
 // Output channels per workgroup tile (128 | 64 | 32) of the f32 implicit-GEMM conv for a layer: the widest tile that
 // fits Cout -- unless that leaves CUs without a workgroup (single images, small feature maps: MobileNetV2's 1x1 layers
 // at batch 1 give 32 workgroups of 128 x 128), then the narrowest tile that fills them, or failing that the one with
-// the most workgroups.  Every variant handles every Cout (cout_pad is a multiple of 32).
+// the most workgroups.  "Fills" = two workgroups per CU (the 128 x 128 tile has one barrier per 16-channel slice: with one
+// 4-wave workgroup per CU nothing covers its waits -- 31 x 31 x 512 at batch 8: 0.379 ms on 256 tiles of 128 x 128,
+// 0.344 ms on 512 of 128 x 64).  Every variant handles every Cout (cout_pad is a multiple of 32).
 int conv_f32_tile_n(int B, int OH, int OW, int Cout)
 {
     static const int n_cus = [] {
@@ -399,8 +402,9 @@ int conv_f32_tile_n(int B, int OH, int OW, int Cout)
         return n;
     }();
     const long long m_tiles = (long long)((OW + TW - 1) / TW) * ((OH + TH - 1) / TH) * B;
+    static const int occ = getenv("RPN_F32_OCC") ? atoi(getenv("RPN_F32_OCC")) : 2;     // workgroups per CU wanted
     int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    while (bn > 32 && m_tiles * ((Cout + bn - 1) / bn) < n_cus) bn >>= 1;
+    while (bn > 32 && m_tiles * ((Cout + bn - 1) / bn) < (long long)occ * n_cus) bn >>= 1;
     return bn;
 }
 
