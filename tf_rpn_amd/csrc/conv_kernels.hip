@@ -482,6 +482,7 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
     f32x4_h bv[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bv[0][i] = wsrc[i];
+    __builtin_amdgcn_sched_barrier(0);                 // all 24 loads above are issued before the first MFMA waits for one
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         if (nb + 1 < NB) {
