@@ -829,6 +829,16 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     bool skip_next = false;
     int head_slabs = 1;                     // > 1: the head's input is that many partial-sum slabs of a split-K rpn_conv
     size_t head_conv_bias = 0;
+    // split-K factor of op i at this batch size: > 1 only for rpn_conv feeding the slab-adding head, when its output tensor
+    // has room for factor * B images (RPN_KSPLIT=1; conv3x3_split16_ksplit says when it pays)
+    auto ksplit_for = [&](size_t i) -> int {
+        const Op &o = m->ops[i];
+        if (!(o.kind == OP_CONV && o.split && o.k16 && o.out_f32) || m->keep_all || i + 1 >= m->ops.size() ||
+            m->ops[i + 1].kind != OP_HEAD || m->ops[i + 1].in != o.out || !rpn_head_supported(512, 5 * m->K) || !head_splitk())
+            return 1;
+        const int f = conv3x3_split16_ksplit(B, o.H, o.W, o.Cin, o.Cout, split_cout_pad(o.Cout));
+        return (size_t)f * B <= (size_t)m->tensors[o.out].slabs * m->max_batch ? f : 1;
+    };
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const Op &op = m->ops[oi];
         const float *x = tensor_ptr(m, op.in, d_imgs);
@@ -850,14 +860,9 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             e = launch_conv_cin3(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs), B,
                                  op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
                                  m->tensors[op.out].split_fmt ? 1 : 0, m->f16, s);
-        } else if (op.kind == OP_CONV && op.split && op.k16 && op.out_f32 && !m->keep_all && m->tensors[op.out].slabs >= 1 &&
-                   oi + 1 < m->ops.size() && m->ops[oi + 1].kind == OP_HEAD && m->ops[oi + 1].in == op.out &&
-                   rpn_head_supported(512, 5 * m->K) && head_splitk() &&
-                   conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout)) > 1 &&
-                   (size_t)conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout)) * B <=
-                       (size_t)m->tensors[op.out].slabs * m->max_batch) {
+        } else if (ksplit_for(oi) > 1) {
             // rpn_conv at a small batch: split-K, raw partial sums; the head adds the slabs (+ this layer's bias, ReLU)
-            head_slabs = conv3x3_split16_ksplit(B, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout));
+            head_slabs = ksplit_for(oi);
             head_conv_bias = op.b_off;
             e = launch_conv3x3_split16_ksplit(x, m->d_weights + op.w_off, tensor_ptr(m, op.out, d_imgs),
                                               (long long)B * op.H * op.W * op.Cout, B, op.H, op.W, op.Cin, op.Cout,
