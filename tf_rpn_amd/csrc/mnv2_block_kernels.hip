@@ -628,6 +628,182 @@ stem_block_kernel(IrArgs a)
     }
 }
 
+// ---- high-resolution blocks (blocks 1 and 2: 16 / 24 input channels), 8 x 8 output tiles ------------------------------------
+// ir_block_kernel's two-group pipeline pays one barrier-separated step of a few microseconds per chunk of expanded
+// channels whatever the work in it; with 16-32 input channels a step holds a few hundred cycles of MFMA, the 512-thread
+// workgroup is mostly latency, and the f32 MFMA shares its issue port with the vector work of the service waves.  Here
+// (the stem kernel's recipe) a 256-thread workgroup owns 8 x 8 output pixels and ALL four waves work in every phase:
+//   per chunk of CE expanded channels:  E  expand on the halo pixels (M-blocks dealt to the waves round robin; B operand =
+//                                          this chunk's We columns, straight from global memory into registers)
+//                                          + bias, ReLU6, zero outside the image -> Es          | barrier
+//                                       D  depthwise 3x3 + bias + ReLU6, thread = (channel, pixel group) -> Ds | barrier
+//                                       P  projection accumulate: wave w owns output M-block w (16 pixels)
+//   + bias (+ residual from the input tile in LDS) -> NHWC.
+// Two barriers per chunk (P(c) and E(c+1) touch disjoint buffers).  Overlap comes from 2-3 workgroups per CU.
+constexpr int HR_T = 8, HR_THREADS = 256;
+
+template <int CIN, int CEXP, int CE, int COUT, int S, bool RES>
+__global__ void __launch_bounds__(HR_THREADS)
+ir_block_hr_kernel(IrArgs a)
+{
+    constexpr int SX = CIN + 2;
+    constexpr int IH = (HR_T - 1) * S + 3, IW = IH, NH = IH * IW;        // halo on the input grid
+    constexpr int MB = (NH + 15) / 16, MH = MB * 16, MBW = (MB + 3) / 4;
+    constexpr int SEP = CE + 4, SD = CE + 2;
+    constexpr int NBE = CE / 16, NCHUNK = CEXP / CE;
+    constexpr int COUTP = (COUT + 15) / 16 * 16, NBO = COUTP / 16;
+    constexpr int KS = CIN / 4, PS = CE / 4;
+    constexpr int DG = CE == 16 ? 16 : (CE == 32 ? 8 : 4);               // depthwise pixel groups
+    constexpr int PXG = HR_T * HR_T / DG;                                 // output pixels per depthwise thread (4 | 8 | 16)
+    constexpr int DROWS = PXG <= HR_T ? 1 : PXG / HR_T, DCOLS = PXG <= HR_T ? PXG : HR_T;   // ... as rows x columns
+    static_assert(CIN % 4 == 0 && (SX / 2) % 2 == 1 && (SD / 2) % 2 == 1 && SEP % 8 == 4 && CEXP % CE == 0 && CE % 16 == 0 &&
+                      CE <= 48 && DG * CE <= HR_THREADS, "layout");
+    static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
+    __shared__ __attribute__((aligned(16))) float Xs[MH * SX];
+    __shared__ __attribute__((aligned(16))) float Es[MH * SEP];
+    __shared__ __attribute__((aligned(16))) float Ds[HR_T * HR_T * SD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int img = t / a.tiles_y;
+    const int oy0 = ty * HR_T, ox0 = tx * HR_T;
+    const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;              // halo origin on the input grid
+
+    // ---- input halo tile -> LDS (zero outside the image: those rows only feed masked-out expand outputs) ---------------
+    {
+        constexpr int CQ = CIN / 4;
+        const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * CIN;
+        for (int idx = tid; idx < MH * CQ; idx += HR_THREADS) {
+            const int m = idx / CQ, cq = idx - m * CQ;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const float4 *>(xin + ((size_t)gy * a.W + gx) * CIN + 4 * cq);
+            float2 *dst = reinterpret_cast<float2 *>(&Xs[m * SX + 4 * cq]);
+            dst[0] = make_float2(v.x, v.y);
+            dst[1] = make_float2(v.z, v.w);
+        }
+    }
+    // which of this lane's expand outputs (M-block wave + 4 mbi, row 4 lk + i) are pixels inside the image
+    unsigned vmask = 0;
+#pragma unroll
+    for (int mbi = 0; mbi < MBW; ++mbi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = (wave + 4 * mbi) * 16 + 4 * lk + i;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            if (m < NH && gy >= 0 && gy < a.DH && gx >= 0 && gx < a.DW) vmask |= 1u << (mbi * 4 + i);
+        }
+    const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
+    const int dy0 = (dg * PXG) / HR_T, dx0 = (dg * PXG) % HR_T;          // first output pixel of the group
+    f32x4 pacc[NBO];
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        // ---- E(c): (halo pixels x CIN) * We[:, chunk] -> + bias, ReLU6, zero outside the image -> Es ------------------
+        {
+            float we_r[KS][NBE], be_r[NBE];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int nb = 0; nb < NBE; ++nb) we_r[kk][nb] = a.we[(size_t)(4 * kk + lk) * CEXP + c * CE + nb * 16 + lr];
+#pragma unroll
+            for (int nb = 0; nb < NBE; ++nb) be_r[nb] = a.be[c * CE + nb * 16 + lr];
+#pragma unroll
+            for (int mbi = 0; mbi < MBW; ++mbi) {
+                const int mb = wave + 4 * mbi;
+                if (MB % 4 == 0 || mb < MB) {
+                    float av[KS];
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) av[kk] = Xs[(mb * 16 + lr) * SX + 4 * kk + lk];
+                    f32x4 eacc[NBE];
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb) eacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                        for (int nb = 0; nb < NBE; ++nb)
+                            eacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], we_r[kk][nb], eacc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            Es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
+                                ((vmask >> (mbi * 4 + i)) & 1u) ? relu6f(eacc[nb][i] + be_r[nb]) : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- D(c): depthwise 3x3 + bias + ReLU6; thread = (channel dc, pixel group dg) --------------------------------
+        if (dg < DG) {
+            float wd_r[10];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wd_r[k] = a.wd[(size_t)k * CEXP + c * CE + dc];
+            wd_r[9] = a.bd[c * CE + dc];
+#pragma unroll
+            for (int ry = 0; ry < DROWS; ++ry) {
+                const int py = dy0 + ry;
+                constexpr int WW = (DCOLS - 1) * S + 3;
+                float win[3][WW];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < WW; ++x) win[r][x] = Es[((py * S + r) * IW + dx0 * S + x) * SEP + dc];
+#pragma unroll
+                for (int px = 0; px < DCOLS; ++px) {
+                    float acc = wd_r[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_r[r * 3 + q], acc);
+                    Ds[(py * HR_T + dx0 + px) * SD + dc] = relu6f(acc);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P(c): acc (16 px of M-block `wave` x COUT) += D (16 x CE) * Wp[chunk] -------------------------------------
+        {
+            float pa[PS];
+#pragma unroll
+            for (int kk = 0; kk < PS; ++kk) pa[kk] = Ds[(wave * 16 + lr) * SD + 4 * kk + lk];
+#pragma unroll
+            for (int kk = 0; kk < PS; ++kk)
+#pragma unroll
+                for (int j = 0; j < NBO; ++j) {
+                    const float wv = a.wp[(size_t)(c * CE + 4 * kk + lk) * COUTP + j * 16 + lr];
+                    pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], wv, pacc[j], 0, 0, 0);
+                }
+        }
+    }
+    // ---- + bias (+ residual from the input tile) -> NHWC -------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+        const int co = j * 16 + lr;
+        if (co < COUT) {
+            const float bias = a.bp[co];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wave * 16 + 4 * lk + i;
+                const int py = p >> 3, px = p & 7;
+                const int oy = oy0 + py, ox = ox0 + px;
+                if (oy < a.OH && ox < a.OW) {
+                    float v = pacc[j][i] + bias;
+                    if constexpr (RES) v += Xs[((py + 1) * IW + px + 1) * SX + co];
+                    a.out[(((size_t)img * a.OH + oy) * a.OW + ox) * COUT + co] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- f16x3 variant for the low-resolution blocks (Cin = 64 / 96, stride 1) -----------------------------------------
 // Same pipeline (E / D / P over two wave groups, one barrier per step), but the two GEMMs run on
 // v_mfma_f32_16x16x32_f16 with every float32 operand carried as hi + lo float16 halves and each product formed as
@@ -990,6 +1166,13 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
     return hipGetLastError();
 }
 
+// RPN_MN_HR=0: blocks 1-2 on the two-group pipeline kernel (4 x 8 tiles) instead of ir_block_hr_kernel
+static int ir_hr_mode()
+{
+    static const int on = getenv("RPN_MN_HR") ? atoi(getenv("RPN_MN_HR")) : 1;
+    return on;
+}
+
 bool ir_block_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
     struct Cfg { int cin, cexp, cout, s, res; };
@@ -1040,6 +1223,20 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
         }
     } else if (!ir_block_supported(cin, cexp, cout, stride, residual)) {
         return hipErrorInvalidValue;
+    } else if (ir_hr_mode() && (cin == 16 || (cin == 24 && stride == 1 &&
+                                               (long long)((OW + HR_T - 1) / HR_T) * ((OH + HR_T - 1) / HR_T) * B >= 512))) {
+        // blocks 1 and 2 (250 x 250 / 125 x 125 inputs, 16 / 24 channels) on the 8 x 8-tile kernel.  Measured at batch 8,
+        // 500 x 500: 0.094 -> 0.066 ms and 0.067 -> 0.061 ms; the blocks behind them (more channels per pixel, smaller
+        // grids) are as fast or faster on the two-group pipeline, block 6 twice as fast.
+        a.tiles_x = (OW + HR_T - 1) / HR_T;
+        a.tiles_y = (OH + HR_T - 1) / HR_T;
+        const long long nb8 = (long long)a.tiles_x * a.tiles_y * B;
+        if (nb8 <= 0 || nb8 > 0x7fffffffll) return hipErrorInvalidValue;
+#define RPN_IRHR(CIN_, CEXP_, CE_, COUT_, S_, RES_)                                                                    \
+    hipLaunchKernelGGL((ir_block_hr_kernel<CIN_, CEXP_, CE_, COUT_, S_, RES_>), dim3((unsigned)nb8), dim3(HR_THREADS), 0, s, a)
+        if (cin == 16) RPN_IRHR(16, 96, 16, 24, 2, false);       // (32-channel chunks: 2 instead of 3 workgroups per CU, 0.077 ms)
+        else RPN_IRHR(24, 144, 48, 24, 1, true);
+#undef RPN_IRHR
     } else if (cin == 16) RPN_IR(16, 96, 16, 24, 2, false, false);
     else if (cin == 24 && stride == 1) RPN_IR(24, 144, 48, 24, 1, true, false);
     else if (cin == 24) RPN_IR(24, 144, 16, 32, 2, false, false);
