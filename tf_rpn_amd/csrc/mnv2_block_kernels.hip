@@ -628,40 +628,47 @@ stem_block_kernel(IrArgs a)
     }
 }
 
-// ---- high-resolution blocks (blocks 1 and 2: 16 / 24 input channels), 8 x 8 output tiles ------------------------------------
+// ---- high-resolution blocks (blocks 1-3: 16 / 24 input channels), 4 x 8 (or 8 x 8) output tiles ---------------------------
 // ir_block_kernel's two-group pipeline pays one barrier-separated step of a few microseconds per chunk of expanded
 // channels whatever the work in it; with 16-32 input channels a step holds a few hundred cycles of MFMA, the 512-thread
 // workgroup is mostly latency, and the f32 MFMA shares its issue port with the vector work of the service waves.  Here
-// (the stem kernel's recipe) a 256-thread workgroup owns 8 x 8 output pixels and ALL four waves work in every phase:
+// (the stem kernel's recipe) a 256-thread workgroup owns TH x 8 output pixels and ALL four waves work in every phase:
 //   per chunk of CE expanded channels:  E  expand on the halo pixels (M-blocks dealt to the waves round robin; B operand =
 //                                          this chunk's We columns, straight from global memory into registers)
 //                                          + bias, ReLU6, zero outside the image -> Es          | barrier
 //                                       D  depthwise 3x3 + bias + ReLU6, thread = (channel, pixel group) -> Ds | barrier
 //                                       P  projection accumulate: wave w owns output M-block w (16 pixels)
 //   + bias (+ residual from the input tile in LDS) -> NHWC.
-// Two barriers per chunk (P(c) and E(c+1) touch disjoint buffers).  Overlap comes from 2-3 workgroups per CU.
+// Two barriers per chunk (P(c) and E(c+1) touch disjoint buffers).  Overlap comes from the other workgroups of the CU: the
+// 4-row tile (25-32 KB of LDS, six workgroups per CU) beats the 8-row one (three) on every block and batch size measured.
 constexpr int HR_T = 8, HR_THREADS = 256;
 
-template <int CIN, int CEXP, int CE, int COUT, int S, bool RES>
+// TH x 8 output pixels per workgroup (TH = 8 | 4: with 4 rows the projection's two M-blocks are shared by wave pairs
+// that split the output-channel blocks, as in ir_block_kernel).
+template <int CIN, int CEXP, int CE, int COUT, int S, bool RES, int TH = 8>
 __global__ void __launch_bounds__(HR_THREADS)
 ir_block_hr_kernel(IrArgs a)
 {
     constexpr int SX = CIN + 2;
-    constexpr int IH = (HR_T - 1) * S + 3, IW = IH, NH = IH * IW;        // halo on the input grid
+    constexpr int NPX = TH * HR_T;                                       // output pixels: 64 | 32
+    constexpr int IH = (TH - 1) * S + 3, IW = (HR_T - 1) * S + 3, NH = IH * IW;   // halo on the input grid
     constexpr int MB = (NH + 15) / 16, MH = MB * 16, MBW = (MB + 3) / 4;
     constexpr int SEP = CE + 4, SD = CE + 2;
     constexpr int NBE = CE / 16, NCHUNK = CEXP / CE;
     constexpr int COUTP = (COUT + 15) / 16 * 16, NBO = COUTP / 16;
     constexpr int KS = CIN / 4, PS = CE / 4;
     constexpr int DG = CE == 16 ? 16 : (CE == 32 ? 8 : 4);               // depthwise pixel groups
-    constexpr int PXG = HR_T * HR_T / DG;                                 // output pixels per depthwise thread (4 | 8 | 16)
+    constexpr int PXG = NPX / DG;                                         // output pixels per depthwise thread (2 .. 16)
+    constexpr int PMB = NPX / 16;                                         // M-blocks of the projection: 4 | 2
+    constexpr int NJ = PMB == 4 ? NBO : (NBO + 1) / 2;                    // ... N-blocks per wave
+    static_assert(TH == 8 || TH == 4, "tile");
     constexpr int DROWS = PXG <= HR_T ? 1 : PXG / HR_T, DCOLS = PXG <= HR_T ? PXG : HR_T;   // ... as rows x columns
     static_assert(CIN % 4 == 0 && (SX / 2) % 2 == 1 && (SD / 2) % 2 == 1 && SEP % 8 == 4 && CEXP % CE == 0 && CE % 16 == 0 &&
                       CE <= 48 && DG * CE <= HR_THREADS, "layout");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
     __shared__ __attribute__((aligned(16))) float Xs[MH * SX];
     __shared__ __attribute__((aligned(16))) float Es[MH * SEP];
-    __shared__ __attribute__((aligned(16))) float Ds[HR_T * HR_T * SD];
+    __shared__ __attribute__((aligned(16))) float Ds[NPX * SD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -670,8 +677,10 @@ ir_block_hr_kernel(IrArgs a)
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int img = t / a.tiles_y;
-    const int oy0 = ty * HR_T, ox0 = tx * HR_T;
+    const int oy0 = ty * TH, ox0 = tx * HR_T;
     const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;              // halo origin on the input grid
+    const int pmb = PMB == 4 ? wave : (wave & 1), pnb0 = PMB == 4 ? 0 : (wave >> 1);   // projection: M-block, first N-block
+    constexpr int PNS = PMB == 4 ? 1 : 2;                                               // ... N-block stride
 
     // ---- input halo tile -> LDS (zero outside the image: those rows only feed masked-out expand outputs) ---------------
     {
@@ -702,9 +711,9 @@ ir_block_hr_kernel(IrArgs a)
         }
     const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
     const int dy0 = (dg * PXG) / HR_T, dx0 = (dg * PXG) % HR_T;          // first output pixel of the group
-    f32x4 pacc[NBO];
+    f32x4 pacc[NJ];
 #pragma unroll
-    for (int j = 0; j < NBO; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     for (int c = 0; c < NCHUNK; ++c) {
@@ -773,25 +782,29 @@ ir_block_hr_kernel(IrArgs a)
         {
             float pa[PS];
 #pragma unroll
-            for (int kk = 0; kk < PS; ++kk) pa[kk] = Ds[(wave * 16 + lr) * SD + 4 * kk + lk];
+            for (int kk = 0; kk < PS; ++kk) pa[kk] = Ds[(pmb * 16 + lr) * SD + 4 * kk + lk];
 #pragma unroll
             for (int kk = 0; kk < PS; ++kk)
 #pragma unroll
-                for (int j = 0; j < NBO; ++j) {
-                    const float wv = a.wp[(size_t)(c * CE + 4 * kk + lk) * COUTP + j * 16 + lr];
-                    pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], wv, pacc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+                    const int nb = pnb0 + PNS * j;
+                    if (PMB == 4 || NBO % 2 == 0 || nb < NBO) {
+                        const float wv = a.wp[(size_t)(c * CE + 4 * kk + lk) * COUTP + nb * 16 + lr];
+                        pacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], wv, pacc[j], 0, 0, 0);
+                    }
                 }
         }
     }
     // ---- + bias (+ residual from the input tile) -> NHWC -------------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < NBO; ++j) {
-        const int co = j * 16 + lr;
-        if (co < COUT) {
+    for (int j = 0; j < NJ; ++j) {
+        const int nb = pnb0 + PNS * j;
+        const int co = nb * 16 + lr;
+        if ((PMB == 4 || NBO % 2 == 0 || nb < NBO) && co < COUT) {
             const float bias = a.bp[co];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int p = wave * 16 + 4 * lk + i;
+                const int p = pmb * 16 + 4 * lk + i;
                 const int py = p >> 3, px = p & 7;
                 const int oy = oy0 + py, ox = ox0 + px;
                 if (oy < a.OH && ox < a.OW) {
@@ -1166,7 +1179,7 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
     return hipGetLastError();
 }
 
-// RPN_MN_HR=0: blocks 1-2 on the two-group pipeline kernel (4 x 8 tiles) instead of ir_block_hr_kernel
+// RPN_MN_HR=0: blocks 1-3 on the two-group pipeline kernel instead of ir_block_hr_kernel
 static int ir_hr_mode()
 {
     static const int on = getenv("RPN_MN_HR") ? atoi(getenv("RPN_MN_HR")) : 1;
@@ -1223,19 +1236,21 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
         }
     } else if (!ir_block_supported(cin, cexp, cout, stride, residual)) {
         return hipErrorInvalidValue;
-    } else if (ir_hr_mode() && (cin == 16 || (cin == 24 && stride == 1 &&
-                                               (long long)((OW + HR_T - 1) / HR_T) * ((OH + HR_T - 1) / HR_T) * B >= 512))) {
-        // blocks 1 and 2 (250 x 250 / 125 x 125 inputs, 16 / 24 channels) on the 8 x 8-tile kernel.  Measured at batch 8,
-        // 500 x 500: 0.094 -> 0.066 ms and 0.067 -> 0.061 ms; the blocks behind them (more channels per pixel, smaller
-        // grids) are as fast or faster on the two-group pipeline, block 6 twice as fast.
+    } else if (ir_hr_mode() && (cin == 16 || cin == 24) &&
+               (stride == 1 || cin == 16 || (long long)((OW + HR_T - 1) / HR_T) * ((OH + 3) / 4) * B >= 512)) {
+        // blocks 1-3 (16 / 24 input channels at 250 x 250 / 125 x 125) on the 4 x 8-tile, every-wave-in-every-phase kernel
+        // (six 256-thread workgroups per CU).  Batch 8, 500 x 500: 0.094 -> 0.059, 0.067 -> 0.055, 0.045 -> 0.035 ms (block 3
+        // only on grids of >= 512 tiles: at one 500 x 500 image the pipeline kernel is faster, 0.017 vs 0.021 ms).  Blocks
+        // 4-6 (32 channels in, smaller grids) are as fast or faster on the two-group pipeline: they stay there.
         a.tiles_x = (OW + HR_T - 1) / HR_T;
-        a.tiles_y = (OH + HR_T - 1) / HR_T;
-        const long long nb8 = (long long)a.tiles_x * a.tiles_y * B;
-        if (nb8 <= 0 || nb8 > 0x7fffffffll) return hipErrorInvalidValue;
+        a.tiles_y = (OH + 3) / 4;
+        const long long nbh = (long long)a.tiles_x * a.tiles_y * B;
+        if (nbh <= 0 || nbh > 0x7fffffffll) return hipErrorInvalidValue;
 #define RPN_IRHR(CIN_, CEXP_, CE_, COUT_, S_, RES_)                                                                    \
-    hipLaunchKernelGGL((ir_block_hr_kernel<CIN_, CEXP_, CE_, COUT_, S_, RES_>), dim3((unsigned)nb8), dim3(HR_THREADS), 0, s, a)
-        if (cin == 16) RPN_IRHR(16, 96, 16, 24, 2, false);       // (32-channel chunks: 2 instead of 3 workgroups per CU, 0.077 ms)
-        else RPN_IRHR(24, 144, 48, 24, 1, true);
+    hipLaunchKernelGGL((ir_block_hr_kernel<CIN_, CEXP_, CE_, COUT_, S_, RES_, 4>), dim3((unsigned)nbh), dim3(HR_THREADS), 0, s, a)
+        if (cin == 16) RPN_IRHR(16, 96, 16, 24, 2, false);       // (32-channel chunks: fewer workgroups per CU, slower)
+        else if (stride == 1) RPN_IRHR(24, 144, 48, 24, 1, true);
+        else RPN_IRHR(24, 144, 16, 32, 2, false);
 #undef RPN_IRHR
     } else if (cin == 16) RPN_IR(16, 96, 16, 24, 2, false, false);
     else if (cin == 24 && stride == 1) RPN_IR(24, 144, 48, 24, 1, true, false);
