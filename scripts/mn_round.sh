@@ -12,7 +12,7 @@ for R in 1 2; do for V in ${VALS:-0 1}; do
   for C in "--backbone mobilenet_v2" "--config c5" "--backbone mobilenet_v2 --batch 1"; do
     echo -n "$KNOB=$V $C: " >> $OUT/res.txt
     env $KNOB=$V timeout -k 10 200 python bench.py $C --no-cpu-baseline --no-extra-legs --layers 2> $OUT/layers_${V}.tmp | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> $OUT/res.txt
-    [ "$R" = 1 ] && head -8 $OUT/layers_${V}.tmp | tail -6 | cut -c1-78 >> $OUT/res.txt
+    [ "$R" = 1 ] && head -3 $OUT/layers_${V}.tmp | tail -1 | cut -c1-78 >> $OUT/res.txt
   done
 done; done
 cat $OUT/res.txt

@@ -476,18 +476,22 @@ ir_block_kernel(IrArgs a)
 //      + bias, ReLU6, zero outside Conv1's grid (the depthwise pads the EXPANDED tensor) -> Es
 //   D  depthwise: thread = (channel, output row half): 16 outputs from a 3 x 18 window read once -> Ds (overlays the patch)
 //   P  (128 px x 32) * (32 x 16) on the MFMA, 2 M-blocks per wave, + bias -> NHWC
-constexpr int ST_TH = 8, ST_TW = 16, ST_THREADS = 256;
+constexpr int ST_TW = 16, ST_THREADS = 256;
 
+// ST_TH x 16 output pixels per workgroup: 8 (45 KB of LDS, three workgroups per CU) or 4 (25 KB, six; 1.7x instead of 1.4x
+// redundant Conv1 work on the halo, but twice the resident workgroups to cover the phases' round trips).
+template <int ST_TH>
 __global__ void __launch_bounds__(ST_THREADS)
 stem_block_kernel(IrArgs a)
 {
-    constexpr int IH = ST_TH + 2, IW = ST_TW + 2, NH = IH * IW;          // halo on Conv1's grid: 10 x 18 = 180 pixels
-    constexpr int MB = (NH + 15) / 16;                                    // 12 M-blocks
-    constexpr int MBW = MB / 4;                                           // 3 per wave
+    constexpr int IH = ST_TH + 2, IW = ST_TW + 2, NH = IH * IW;          // halo on Conv1's grid: 10 x 18 = 180 | 6 x 18 = 108 pixels
+    constexpr int MB = (NH + 15) / 16;                                    // 12 | 7 M-blocks
+    constexpr int MBW = (MB + 3) / 4;                                     // 3 | 2 per wave (round robin)
+    constexpr int PMW = ST_TH * ST_TW / 64;                               // projection M-blocks per wave: 2 | 1
     constexpr int PR = 2 * (IH - 1) + 3, PC = (2 * (IW - 1) + 3) * 3, PSTR = PC + 2;   // image patch: 21 rows x 111 floats
     constexpr int SEP = 36, SD = 34;                                      // row strides of Es / Ds (see ir_block_kernel)
     constexpr int KS = 7;                                                 // k-steps of Conv1 (K = 27 -> 28)
-    static_assert(MB % 4 == 0, "M-blocks per wave");
+    static_assert(ST_TH == 8 || ST_TH == 4, "tile");
     constexpr int XD_FLOATS = PR * PSTR > ST_TH * ST_TW * SD ? PR * PSTR : ST_TH * ST_TW * SD;
     __shared__ __attribute__((aligned(16))) float XD[XD_FLOATS];          // the image patch, then Ds
     __shared__ __attribute__((aligned(16))) float Es[MB * 16 * SEP];
@@ -510,7 +514,9 @@ stem_block_kernel(IrArgs a)
         for (int nb = 0; nb < 2; ++nb) we_r[kk][nb] = a.we[(4 * kk + lk) * 32 + nb * 16 + lr];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) wp_r[kk] = a.wp[(4 * kk + lk) * 16 + lr];
-    const int dc = tid & 31, dg = tid >> 5;                               // depthwise: channel, output row
+    const int dc = tid & 31, dg = tid >> 5;                               // depthwise: channel, pixel group (8: a row | half a row)
+    constexpr int DPX = ST_TH * ST_TW / 8;                                // outputs per depthwise thread: 16 | 8
+    const int drow = ST_TH == 8 ? dg : (dg >> 1), dcol0 = ST_TH == 8 ? 0 : (dg & 1) * 8;
 #pragma unroll
     for (int k = 0; k < 9; ++k) wd_r[k] = a.wd[k * 32 + dc];
     wd_r[9] = a.bd[dc];
@@ -570,11 +576,13 @@ stem_block_kernel(IrArgs a)
             for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][mbi], we_r[kk][nb], eacc[mbi][nb], 0, 0, 0);
+                    if (MB % 4 == 0 || wave + 4 * mbi < MB)
+                        eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][mbi], we_r[kk][nb], eacc[mbi][nb], 0, 0, 0);
 #pragma unroll
         for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (!(MB % 4 == 0 || wave + 4 * mbi < MB)) continue;
                 const bool in = (vmask >> (mbi * 4 + i)) & 1u;
                 float *e = &Es[((wave + 4 * mbi) * 16 + 4 * lk + i) * SEP + lr];
                 e[0] = in ? relu6f(eacc[mbi][0][i] + be0) : 0.0f;
@@ -585,15 +593,15 @@ stem_block_kernel(IrArgs a)
 
     // ---- D: depthwise 3x3 + bias + ReLU6: thread = (channel dc, output row dg), 16 outputs ----------------------------
     {
-        const float *es = Es + (dg * IW) * SEP + dc;
-        float *ds = XD + (dg * ST_TW) * SD + dc;
-        float win[3][IW];
+        const float *es = Es + (drow * IW + dcol0) * SEP + dc;
+        float *ds = XD + (drow * ST_TW + dcol0) * SD + dc;
+        float win[3][DPX + 2];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int x = 0; x < IW; ++x) win[r][x] = es[(r * IW + x) * SEP];
+            for (int x = 0; x < DPX + 2; ++x) win[r][x] = es[(r * IW + x) * SEP];
 #pragma unroll
-        for (int px = 0; px < ST_TW; ++px) {
+        for (int px = 0; px < DPX; ++px) {
             float acc = wd_r[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -606,22 +614,24 @@ stem_block_kernel(IrArgs a)
 
     // ---- P: projection 32 -> 16 + bias -> NHWC -----------------------------------------------------------------------
     {
-        f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float pa[8][2];
+        f32x4 pacc[PMW];
+        float pa[8][PMW];
+#pragma unroll
+        for (int mbi = 0; mbi < PMW; ++mbi) pacc[mbi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-            for (int mbi = 0; mbi < 2; ++mbi) pa[kk][mbi] = XD[((2 * wave + mbi) * 16 + lr) * SD + 4 * kk + lk];
+            for (int mbi = 0; mbi < PMW; ++mbi) pa[kk][mbi] = XD[((PMW * wave + mbi) * 16 + lr) * SD + 4 * kk + lk];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-            for (int mbi = 0; mbi < 2; ++mbi)
+            for (int mbi = 0; mbi < PMW; ++mbi)
                 pacc[mbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk][mbi], wp_r[kk], pacc[mbi], 0, 0, 0);
 #pragma unroll
-        for (int mbi = 0; mbi < 2; ++mbi)
+        for (int mbi = 0; mbi < PMW; ++mbi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int p = (2 * wave + mbi) * 16 + 4 * lk + i;         // = output row 2 wave + mbi, column 4 lk + i
+                const int p = (PMW * wave + mbi) * 16 + 4 * lk + i;       // = output row p / 16, column p % 16
                 const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
                 if (oy < a.OH && ox < a.OW) a.out[(((size_t)img * a.OH + oy) * a.OW + ox) * 16 + lr] = pacc[mbi][i] + bpv;
             }
@@ -1226,11 +1236,13 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
         if (!(cin == 3 && cexp == 32 && cout == 16 && stride == 1 && !residual)) return hipErrorInvalidValue;
         static const int stem8 = getenv("RPN_MN_STEM8") ? atoi(getenv("RPN_MN_STEM8")) : 1;     // 0: the 4 x 8 tile pipeline
         if (stem8) {
+            const int th = stem8 == 4 ? 4 : 8;      // (4 x 16 tiles, six workgroups per CU: no faster at batch 8, slower at 1024 x 1024)
             a.tiles_x = (OW + ST_TW - 1) / ST_TW;
-            a.tiles_y = (OH + ST_TH - 1) / ST_TH;
+            a.tiles_y = (OH + th - 1) / th;
             const long long nb8 = (long long)a.tiles_x * a.tiles_y * B;
             if (nb8 <= 0 || nb8 > 0x7fffffffll) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(stem_block_kernel, dim3((unsigned)nb8), dim3(ST_THREADS), 0, s, a);
+            if (th == 8) hipLaunchKernelGGL(stem_block_kernel<8>, dim3((unsigned)nb8), dim3(ST_THREADS), 0, s, a);
+            else hipLaunchKernelGGL(stem_block_kernel<4>, dim3((unsigned)nb8), dim3(ST_THREADS), 0, s, a);
         } else {
             RPN_IR(28, 32, 32, 16, 1, false, true);
         }
