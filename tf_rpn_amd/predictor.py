@@ -67,7 +67,11 @@ class Proposer(object):
             # empty.  Without it the first conv kernel of batch k+1 wins that race, fills every CU, and the NMS only
             # gets in at the NEXT boundary -- beside a persistent conv layer whose statically scheduled workgroups then
             # wait for "their" CU (block2_conv1: 0.21 -> 0.31 ms).  A higher stream priority alone does not help.
-            self._nms_handshake = int(os.environ.get("RPN_NMS_HANDSHAKE", "1")) != 0
+            # Needed where a step's first conv kernel fills every CU for most of the NMS's run time and is followed by
+            # persistent layers (VGG16: block 1 in one launch, 0.44 ms).  MobileNetV2's first kernels are short and its
+            # blocks are scheduled dynamically: there the extra event hop only costs (one image: 0.320 vs 0.303 ms).
+            hs = os.environ.get("RPN_NMS_HANDSHAKE")
+            self._nms_handshake = (int(hs) != 0) if hs is not None else (backbone == "vgg16")
             self._nms_go = None
             self._slot = 0
             self._bufs = []
