@@ -1,0 +1,46 @@
+"""Phase stamps of the NMS kernel (a -DRPN_NMS_STAMP build: RPN_HIP_LIB=ab/nmsstamp.so).  Prints, for workgroup 0 and the
+median over workgroups, the cycles between consecutive stamps with their phase codes:
+1 start, 2 band selected, 3 band compacted, 4 band sorted, 5 chunk set up, 6 step A, 7 step B, 8 walk (wave 0), 9 group done,
+10 greedy done, 11 outputs written."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import cases
+from oracle import bbox_oracle as bo
+from tf_rpn_amd import _lib as L
+anchors = bo.generate_anchors(bo.get_hyper_params("vgg16")); A = len(anchors)
+B = 64
+rng = np.random.RandomState(2)
+d = torch.from_numpy(rng.standard_normal((B, A, 4)).astype(np.float32)).cuda()
+s = torch.from_numpy(cases.permutation_scores(np.random.RandomState(3), B, A)).cuda()
+a = torch.from_numpy(anchors).cuda()
+ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device="cuda")
+oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
+keep, vptr = L.host_floats(np.float32([0.1, 0.1, 0.2, 0.2]))
+lib = L.lib()
+for _ in range(3):
+    L.check(lib.rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, 0.7, float("-inf"), 1, L.ptr(ob), L.ptr(osc),
+                               L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (64 * 512))()
+raw = ctypes.CDLL(L.LIB_PATH)
+raw.rpn_debug_read_nms_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert raw.rpn_debug_read_nms_stamps(buf, 64 * 512) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 512)
+code = (st >> np.uint64(56)).astype(int); cyc = (st & np.uint64((1 << 56) - 1)).astype(np.int64)
+n = int((code[0] > 0).sum())
+print("workgroup 0: %d stamps, total %d cycles" % (n, cyc[0, n - 1] - cyc[0, 0]))
+row = ["%d:%d" % (code[0, i], cyc[0, i] - cyc[0, i - 1]) for i in range(1, n)]
+print(" ".join(row))
+# per-code totals, median over workgroups
+tot = {}
+for w in range(64):
+    nw = int((code[w] > 0).sum())
+    t = {}
+    for i in range(1, nw):
+        t[code[w, i]] = t.get(code[w, i], 0) + int(cyc[w, i] - cyc[w, i - 1])
+    for k, v in t.items():
+        tot.setdefault(k, []).append(v)
+print("median cycles per phase code over workgroups:", {k: int(np.median(v)) for k, v in sorted(tot.items())})
+print("valid:", ov[:4].tolist())

@@ -170,10 +170,30 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
 // ctl words
 enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by radix_select */, CTL_LOW = 8 /* u64 */ };
 
+// Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the
+// first 64 workgroups, in program order (slot 0 = start; the probe knows the sequence).
+#ifdef RPN_NMS_STAMP
+__device__ unsigned long long g_nms_stamps[64 * 512];
+#define NMS_STAMP(code)                                                                                       \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && nms_sidx < 512)                                            \
+            g_nms_stamps[blockIdx.x * 512 + nms_sidx++] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); \
+    } while (0)
+extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), (size_t)n * 8);
+}
+#else
+#define NMS_STAMP(code) ((void)0)
+#endif
+
 template <bool DECODE>
 __global__ void __launch_bounds__(kNmsThreads)
 nms_kernel(NmsArgs p)
 {
+#ifdef RPN_NMS_STAMP
+    int nms_sidx = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(p.max_sel);
     unsigned long long *band = reinterpret_cast<unsigned long long *>(smem + L.band);
@@ -198,6 +218,7 @@ nms_kernel(NmsArgs p)
 
     if (tid < 16) ctl[tid] = 0;
     __syncthreads();
+    NMS_STAMP(1);
 
     unsigned long long hi_bound = ~0ull;       // keys of the current band are < hi_bound (exclusive)
 
@@ -214,6 +235,7 @@ nms_kernel(NmsArgs p)
             ctl + CTL_SEL, &band_expected);
         if (thr == 0ull) break;              // nothing left
         if (p.stop_after == 1) return;
+        NMS_STAMP(2);
 
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
         if (tid == 0) ctl[CTL_BANDN] = 0;
@@ -242,6 +264,7 @@ nms_kernel(NmsArgs p)
             }
         }
         __syncthreads();
+        NMS_STAMP(3);
         if (p.stop_after == 3) return;
         int band_n = ctl[CTL_BANDN];
         if (band_n > kBandCap) band_n = kBandCap;    // cannot happen: the select guarantees <= kBandCap
@@ -279,6 +302,7 @@ nms_kernel(NmsArgs p)
         }
         if (tid == 0) ctl[CTL_POS] = 0;
         __syncthreads();
+        NMS_STAMP(4);
 
         // ================= 2. greedy selection over chunks of the sorted band ===============================
         while (true) {
@@ -301,6 +325,7 @@ nms_kernel(NmsArgs p)
                 if (T < lo + 64) deadw[tid] = T <= lo ? ~0ull : (~0ull << (T - lo));
             }
             __syncthreads();
+            NMS_STAMP(5);
             if (p.stop_after == 4) return;
 
             // The chunk is walked in 4 groups of 64 candidates (one 64-bit word of the live mask).  Per group:
@@ -342,6 +367,7 @@ nms_kernel(NmsArgs p)
                         atomicOr(&deadw[gw], bits);
                     }
                     __syncthreads();
+                    NMS_STAMP(6);
                 }
                 {
                     const int il = tid >> 4, piece = tid & 15;
@@ -349,12 +375,16 @@ nms_kernel(NmsArgs p)
                     unsigned bits = 0u;
                     const bool i_dead = (deadw[gw] >> il) & 1ull;
                     const int j0 = piece * 16;
-                    if (!i_dead && j0 + 15 > i) {
+                    // own group's word: the candidates BEFORE i that suppress it (its suppressor set: the walk below
+                    // resolves the group from these, in parallel); later groups' words: the candidates AFTER i that it
+                    // suppresses (ORed into their dead words if i gets selected).  The test is symmetric in its two boxes.
+                    const bool own = (piece >> 2) == gw;
+                    if (!i_dead && (own ? j0 < i : j0 > i)) {
                         const int is = cslot(i);
                         const float4 s4 = cbox4[is];
                         const CBox si{s4.x, s4.y, s4.z, s4.w, carea[is]};
                         unsigned todo = (unsigned)(~deadw[piece >> 2] >> ((piece & 3) * 16)) & 0xFFFFu;
-                        if (j0 <= i) todo &= (0xFFFFu << (i - j0)) << 1;        // only j > i
+                        if (own && j0 + 16 > i) todo &= (1u << (i - j0)) - 1u;     // own group: only j < i
                         // all 16 candidates of the piece, unconditionally (one 16-byte + one 4-byte conflict-free LDS read
                         // each, no find-first-set loop); the bits of dead candidates are masked off afterwards
 #pragma unroll 4
@@ -369,6 +399,7 @@ nms_kernel(NmsArgs p)
                     reinterpret_cast<unsigned short *>(mask)[il * 16 + piece] = (unsigned short)bits;
                 }
                 __syncthreads();
+                NMS_STAMP(7);
                 if (p.stop_after == 5) return;
                 if (tid < 64) {
                     const unsigned long long own = mask[lane * kChunkWords + gw];
@@ -379,18 +410,29 @@ nms_kernel(NmsArgs p)
                     unsigned long long avail =
                         ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dead0 >> 32)) << 32) |
                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dead0));
-                    unsigned long long selmask = 0ull;
-                    int c2 = cur;
-                    while (avail != 0ull && c2 < max_sel) {
-                        const int i = __ffsll((long long)avail) - 1;
-                        selmask |= 1ull << i;
-                        ++c2;
-                        const unsigned long long row =
-                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)own_hi, i) << 32) |
-                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)own_lo, i);
-                        avail &= ~(row | (1ull << i));
+                    // Greedy selection inside the group as a fixed point instead of a 64-step serial walk (one selection per
+                    // ~200 cycles of scalar <-> vector round trips: 7-9k cycles per group in the stamps): candidate l is
+                    // selected iff it is live and no SELECTED earlier candidate is in its suppressor set `own`.  Per round
+                    // every undecided lane looks at its set: a selected member -> dead; no undecided member left -> selected
+                    // (the lowest undecided lane always decides, so the loop ends; chains are a few links long in practice).
+                    // The unique solution of that recursion is the sequential walk's result; the output cap keeps its
+                    // first (max_sel - cur) members, exactly where the walk would have stopped.
+                    (void)own_lo; (void)own_hi;
+                    const unsigned long long mybit = 1ull << lane;
+                    unsigned long long und = avail, selall = 0ull;
+                    while (und != 0ull) {
+                        const bool me = (und & mybit) != 0ull;
+                        const bool hit = (own & selall) != 0ull;
+                        const bool blocked = (own & und) != 0ull;
+                        const unsigned long long newsel = __ballot(me && !hit && !blocked);
+                        const unsigned long long newdead = __ballot(me && hit);
+                        selall |= newsel;
+                        und &= ~(newsel | newdead);
                     }
-                    const bool picked_me = (selmask >> lane) & 1ull;
+                    const int room = max_sel - cur;
+                    const bool picked_me = ((selall >> lane) & 1ull) && __popcll(selall & (mybit - 1ull)) < room;
+                    const unsigned long long selmask = __ballot(picked_me);
+                    const int c2 = cur + __popcll(selmask);
                     if (picked_me) {
                         const int slot = cur + __popcll(selmask & ((1ull << lane) - 1ull));
                         const int i = gw * 64 + lane;
@@ -407,8 +449,10 @@ nms_kernel(NmsArgs p)
                         }
                     }
                     if (lane == 0) ctl[CTL_NSEL] = c2;
+                    NMS_STAMP(8);
                 }
                 __syncthreads();
+                NMS_STAMP(9);
                 cur = ctl[CTL_NSEL];
                 if (p.stop_after == 6) return;
             }
@@ -422,6 +466,7 @@ nms_kernel(NmsArgs p)
     __syncthreads();
 
     // ================= 3. outputs =================================================================
+    NMS_STAMP(10);
     if (p.stop_after == 8) return;
     const int nsel = ctl[CTL_NSEL];
     if (p.C == 1) {
@@ -450,6 +495,7 @@ nms_kernel(NmsArgs p)
             }
         }
         if (tid == 0) p.out_valid[b] = nvalid;
+        NMS_STAMP(11);
     } else {
         int *si = p.stage_idx + ((size_t)b * p.C + c) * max_sel;
         for (int r = tid; r < nsel; r += kNmsThreads) si[r] = sel_idx[r];
