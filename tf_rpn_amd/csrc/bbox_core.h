@@ -131,6 +131,22 @@ __device__ __forceinline__ bool nms_suppresses(const CBox &i, const CBox &j, flo
     return inter / uni > thr;
 }
 
+// The same decision, branch-free, for the inner loops: `decided` is cleared when the quotient would be needed (the ratio
+// within 2^-18 of the threshold, a tiny or NaN union, a threshold for which the host switched the shortcuts off) -- the
+// caller then repeats its tests with nms_suppresses.  Boxes of area <= 0 must carry area = +inf here (nms_area_key): the
+// union is then +inf and every path gives TF's answer for them, `0 > thr`, without a test of its own.
+__device__ __forceinline__ bool nms_suppresses_fast(const CBox &i, const CBox &j, float thr_lo, float thr_hi, bool &decided)
+{
+    const float iymin = fmaxf(i.ymin, j.ymin), ixmin = fmaxf(i.xmin, j.xmin);
+    const float iymax = fminf(i.ymax, j.ymax), ixmax = fminf(i.xmax, j.xmax);
+    const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
+    const float uni = i.area + j.area - inter;
+    const bool hi = inter > thr_hi * uni, lo = inter < thr_lo * uni;
+    decided = decided && (uni >= 1e-30f) && (hi || lo);
+    return hi;
+}
+__device__ __forceinline__ float nms_area_key(float area) { return area <= 0.0f ? INFINITY : area; }
+
 // monotone map float -> uint32 (descending float order == descending uint order);
 // -0.0 is folded onto +0.0 so that equal scores tie exactly as a float compare would.
 __device__ __forceinline__ unsigned orderable(float s)

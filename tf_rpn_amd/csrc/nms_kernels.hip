@@ -315,7 +315,7 @@ nms_kernel(NmsArgs p)
                 const CBox cb = canonical(fetch_box<DECODE>(p, b, (int)order[pos + tid], qc));
                 const int st = cslot(tid);
                 cbox4[st] = make_float4(cb.ymin, cb.xmin, cb.ymax, cb.xmax);
-                carea[st] = cb.area;
+                carea[st] = nms_area_key(cb.area);          // (+inf for area <= 0: see nms_suppresses_fast)
             }
             if (tid < kChunkWords) deadw[tid] = 0ull;
             __syncthreads();
@@ -351,10 +351,19 @@ nms_kernel(NmsArgs p)
                         const int st = cslot(t);
                         const float4 c4 = cbox4[st];
                         const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
+                        bool decided = true;                        // branch-free tests; the exact ones only if one was close
                         for (int j = part; j < nsel; j += 16) {
                             const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
                                           sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
-                            hit |= nms_suppresses(ci, sj, p.iou_thr, p.iou_lo, p.iou_hi);
+                            hit |= nms_suppresses_fast(ci, sj, p.iou_lo, p.iou_hi, decided);
+                        }
+                        if (!decided) {
+                            hit = false;
+                            for (int j = part; j < nsel; j += 16) {
+                                const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
+                                              sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
+                                hit |= nms_suppresses(ci, sj, p.iou_thr, p.iou_lo, p.iou_hi);
+                            }
                         }
                     }
                     // lanes 16q .. 16q+15 of a wave belong to candidate 4 * wave + q
@@ -387,12 +396,22 @@ nms_kernel(NmsArgs p)
                         if (own && j0 + 16 > i) todo &= (1u << (i - j0)) - 1u;     // own group: only j < i
                         // all 16 candidates of the piece, unconditionally (one 16-byte + one 4-byte conflict-free LDS read
                         // each, no find-first-set loop); the bits of dead candidates are masked off afterwards
+                        bool decided = true;
 #pragma unroll 4
                         for (int jj = 0; jj < 16; ++jj) {
                             const int js = (jj << 4) | piece;               // cslot(j0 + jj)
                             const float4 q4 = cbox4[js];
                             const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
-                            if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                            bits |= (unsigned)nms_suppresses_fast(cj, si, p.iou_lo, p.iou_hi, decided) << jj;
+                        }
+                        if (!decided) {                                     // a ratio close to the threshold: the exact tests
+                            bits = 0u;
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int js = (jj << 4) | piece;
+                                const float4 q4 = cbox4[js];
+                                const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
+                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                            }
                         }
                         bits &= todo;
                     }
