@@ -156,7 +156,8 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
     size_t o = 0;
     l.band = o;    o = align16(o + (size_t)8 * kBandCap);               // u64 keys, later u32 order in place
     l.hist = o;    o = align16(o + (size_t)4 * kBins);
-    l.sel_c = o;   o = align16(o + (size_t)20 * max_sel);               // canonical selected boxes [5][max_sel]
+    l.sel_c = o;   o = align16(o + (size_t)16 * max_sel);               // canonical selected boxes: float4 [max_sel] ...
+    o = align16(o + (size_t)4 * max_sel);                                //                           ... + area [max_sel]
     l.sel_idx = o; o = align16(o + (size_t)4 * max_sel);
     l.cbox = o;    o = align16(o + (size_t)20 * kChunk);                // canonical chunk boxes: float4 [kChunk] + area [kChunk]
     l.mask = o;    o = align16(o + (size_t)8 * 64 * kChunkWords);       // [64 rows of the current group][4] u64
@@ -199,7 +200,8 @@ nms_kernel(NmsArgs p)
     unsigned long long *band = reinterpret_cast<unsigned long long *>(smem + L.band);
     unsigned *order = reinterpret_cast<unsigned *>(smem + L.band);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
-    float *sel_c = reinterpret_cast<float *>(smem + L.sel_c);
+    float4 *sel_c4 = reinterpret_cast<float4 *>(smem + L.sel_c);
+    float *sel_a = reinterpret_cast<float *>(smem + L.sel_c + align16((size_t)16 * p.max_sel));
     int *sel_idx = reinterpret_cast<int *>(smem + L.sel_idx);
     float4 *cbox4 = reinterpret_cast<float4 *>(smem + L.cbox);               // canonical chunk boxes (ymin, xmin, ymax, xmax)
     float *carea = reinterpret_cast<float *>(smem + L.cbox) + 4 * kChunk;    // ... and their areas
@@ -352,17 +354,24 @@ nms_kernel(NmsArgs p)
                         const float4 c4 = cbox4[st];
                         const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
                         bool decided = true;                        // branch-free tests; the exact ones only if one was close
-                        for (int j = part; j < nsel; j += 16) {
-                            const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
-                                          sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
-                            hit |= nms_suppresses_fast(ci, sj, p.iou_lo, p.iou_hi, decided);
+                        int j = part;
+                        for (; j + 16 < nsel; j += 32) {            // two selected boxes per trip: their LDS reads overlap
+                            const float4 a4 = sel_c4[j], b4 = sel_c4[j + 16];
+                            const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]}, sb{b4.x, b4.y, b4.z, b4.w, sel_a[j + 16]};
+                            hit |= nms_suppresses_fast(ci, sa, p.iou_lo, p.iou_hi, decided);
+                            hit |= nms_suppresses_fast(ci, sb, p.iou_lo, p.iou_hi, decided);
+                        }
+                        if (j < nsel) {
+                            const float4 a4 = sel_c4[j];
+                            const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]};
+                            hit |= nms_suppresses_fast(ci, sa, p.iou_lo, p.iou_hi, decided);
                         }
                         if (!decided) {
                             hit = false;
-                            for (int j = part; j < nsel; j += 16) {
-                                const CBox sj{sel_c[0 * max_sel + j], sel_c[1 * max_sel + j], sel_c[2 * max_sel + j],
-                                              sel_c[3 * max_sel + j], sel_c[4 * max_sel + j]};
-                                hit |= nms_suppresses(ci, sj, p.iou_thr, p.iou_lo, p.iou_hi);
+                            for (j = part; j < nsel; j += 16) {
+                                const float4 a4 = sel_c4[j];
+                                const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]};
+                                hit |= nms_suppresses(ci, sa, p.iou_thr, p.iou_lo, p.iou_hi);
                             }
                         }
                     }
@@ -378,8 +387,13 @@ nms_kernel(NmsArgs p)
                     __syncthreads();
                     NMS_STAMP(6);
                 }
-                {
-                    const int il = tid >> 4, piece = tid & 15;
+                // (only the pieces of this group's word and of the later words hold work: 16 - 4 gw of the 16, dealt to the
+                // first 64 x (16 - 4 gw) threads, so that the later groups of a chunk occupy 12, 8, 4 waves instead of 16
+                // waves each three quarters idle)
+                const int np = 16 - 4 * gw;
+                if (tid < 64 * np) {
+                    const int il = gw == 0 ? (tid >> 4) : (gw == 2 ? (tid >> 3) : (gw == 3 ? (tid >> 2) : tid / 12));
+                    const int piece = 4 * gw + (tid - il * np);
                     const int i = gw * 64 + il;
                     unsigned bits = 0u;
                     const bool i_dead = (deadw[gw] >> il) & 1ull;
@@ -456,11 +470,8 @@ nms_kernel(NmsArgs p)
                         const int slot = cur + __popcll(selmask & ((1ull << lane) - 1ull));
                         const int i = gw * 64 + lane;
                         const float4 b4 = cbox4[cslot(i)];
-                        sel_c[0 * max_sel + slot] = b4.x;
-                        sel_c[1 * max_sel + slot] = b4.y;
-                        sel_c[2 * max_sel + slot] = b4.z;
-                        sel_c[3 * max_sel + slot] = b4.w;
-                        sel_c[4 * max_sel + slot] = carea[cslot(i)];
+                        sel_c4[slot] = b4;
+                        sel_a[slot] = carea[cslot(i)];
                         sel_idx[slot] = (int)order[pos + i];
                         for (int w = gw + 1; w < kChunkWords; ++w) {
                             const unsigned long long r = mask[lane * kChunkWords + w];
