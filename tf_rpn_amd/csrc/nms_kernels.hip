@@ -154,7 +154,7 @@ __device__ __forceinline__ unsigned long long make_key(float s, float thr, int i
 // the band may take, or is bin 0 (which also collects the scores below 0).  hist: 2048 words; ctl: 4 ints.
 __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, int N, float score_thr,
                                           unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
-                                          unsigned long long *thr_out, int *count)
+                                          unsigned long long *thr_out, int *count, int *bin_out)
 {
     constexpr int NB = 2048;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -205,11 +205,87 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
     __syncthreads();
     const int d = ctl[0], n = ctl[1];
     __syncthreads();                        // (ctl is reused by the caller)
+    *bin_out = d;
     if (d == -1) { *thr_out = 0ull; *count = 0; return true; }
-    if (d == -2) { *thr_out = 1ull; *count = n; return true; }
+    if (d == -2) { *thr_out = 1ull; *count = n; *bin_out = -1; return true; }       // (bin 0 included: no histogram order)
     if (d == 0 || n > cap) return false;
     *thr_out = (unsigned long long)orderable((float)d * (1.0f / 2048.0f)) << 32;
     *count = n;
+    return true;
+}
+
+__device__ __forceinline__ int linear_bin(float s) { return (int)fminf(fmaxf(s * 2048.0f, 0.0f), 2047.0f); }
+__device__ __forceinline__ float key_score(unsigned long long key)            // inverse of orderable()
+{
+    const unsigned o = (unsigned)(key >> 32);
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// The band in descending key order WITHOUT a sorting network, from the linear histogram that chose it: bin b's keys go
+// to positions [off(b), off(b) + count(b)), off(b) = keys in the bins above b (a suffix scan over the 2048 counts); inside
+// a bin (4 keys on average at 8649 anchors) a key's place is the number of larger keys in its bin.  One pass over the
+// scores scatters the band's keys to their bins' segments (per-bin LDS cursors), a second step ranks inside the segments.
+// hist: [0,2048) counts (from band_select_linear), [2048,4096) offsets, [4096,6144) cursors, [6144,6161) scan scratch.
+// Returns false (nothing written) when a bin of the band holds more than 32 keys: the caller then sorts the old way.
+__device__ inline bool band_order_linear(const float *__restrict__ sc, int C, int N, float score_thr, unsigned long long thr,
+                                         unsigned long long hi_bound, int d, int n, unsigned *hist, unsigned long long *band,
+                                         unsigned *order, unsigned long long *low_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned *boff = hist + 2048, *cur = hist + 4096, *scratch = hist + 6144;
+    // suffix scan from the top bin: thread t owns bins 2047 - 2t and 2046 - 2t
+    const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
+    const unsigned c0 = b0 >= d ? hist[b0] : 0u, c1 = b1 >= d ? hist[b1] : 0u;
+    unsigned incl = c0 + c1;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    if (tid == 0) scratch[16] = 0u;
+    cur[b0] = 0u;
+    cur[b1] = 0u;
+    __syncthreads();
+    unsigned wpre = 0u;
+    for (int w = 0; w < wave; ++w) wpre += scratch[w];
+    const unsigned excl = wpre + incl - (c0 + c1);
+    boff[b0] = excl;
+    boff[b1] = excl + c0;
+    if (c0 > 32u || c1 > 32u) atomicOr(&scratch[16], 1u);
+    __syncthreads();
+    if (scratch[16] != 0u) return false;
+    // scatter: the band's keys to their bins' segments
+    for (int base = tid; base < N; base += 8 * kNmsThreads) {
+        float sb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
+            if (key != 0ull && key >= thr && key < hi_bound) {
+                const int b = linear_bin(sb[u]);
+                band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
+            }
+        }
+    }
+    __syncthreads();
+    // rank inside the bin's segment (keys are unique)
+    unsigned long long key = 0ull;
+    int pos = -1;
+    if (tid < n) {
+        key = band[tid];
+        const int b = linear_bin(key_score(key));
+        const int seg0 = (int)boff[b], cnt = (int)hist[b];
+        int rank = 0;
+        for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key ? 1 : 0;
+        pos = seg0 + rank;
+    }
+    __syncthreads();                         // every key is in a register: `order` aliases `band`
+    if (pos >= 0) {
+        order[pos] = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        if (pos == n - 1) *low_out = key;
+    }
+    __syncthreads();
     return true;
 }
 
@@ -303,13 +379,29 @@ nms_kernel(NmsArgs p)
         const int band_target = min(kBandTarget, max(512, 2 * want_left));
         const int band_cap = band_target <= 768 ? 1024 : kBandCap;
         unsigned long long thr = 0ull;
+        int lin_bin = -1;                    // >= 0: the band was chosen by the linear histogram (still in `hist`) at this bin
         if (!p.linear_select ||
-            !band_select_linear(sc, C, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected))
+            !band_select_linear(sc, C, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected,
+                                &lin_bin)) {
+            lin_bin = -1;
             thr = radix_select<kNmsThreads>([&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound,
                                             band_target, band_cap, hist, ctl + CTL_SEL, &band_expected);
+        }
         if (thr == 0ull) break;              // nothing left
         if (p.stop_after == 1) return;
         NMS_STAMP(2);
+
+        int band_n = 0;
+        bool ordered = false;
+        if (lin_bin > 0 && band_expected <= kNmsThreads && p.linear_select != 2) {
+            ordered = band_order_linear(sc, C, N, p.score_thr, thr, hi_bound, lin_bin, band_expected, hist, band, order,
+                                        reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
+            if (ordered) {
+                band_n = band_expected;
+                hi_bound = *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW);     // the next band continues strictly below
+            }
+        }
+        if (!ordered) {
 
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
         if (tid == 0) ctl[CTL_BANDN] = 0;
@@ -340,7 +432,7 @@ nms_kernel(NmsArgs p)
         __syncthreads();
         NMS_STAMP(3);
         if (p.stop_after == 3) return;
-        int band_n = ctl[CTL_BANDN];
+        band_n = ctl[CTL_BANDN];
         if (band_n > kBandCap) band_n = kBandCap;    // cannot happen: the select guarantees <= kBandCap
         if (band_n == 0) break;
         if (band_n <= kNmsThreads) {
@@ -374,6 +466,7 @@ nms_kernel(NmsArgs p)
             }
             hi_bound = lowest;                       // the next band continues strictly below this one
         }
+        }   // !ordered
         if (tid == 0) ctl[CTL_POS] = 0;
         __syncthreads();
         NMS_STAMP(4);
