@@ -552,22 +552,20 @@ nms_kernel(NmsArgs p)
                     __syncthreads();
                     NMS_STAMP(6);
                 }
-                // (only the pieces of this group's word and of the later words hold work: 16 - 4 gw of the 16, dealt to the
-                // first 64 x (16 - 4 gw) threads, so that the later groups of a chunk occupy 12, 8, 4 waves instead of 16
-                // waves each three quarters idle)
-                const int np = 16 - 4 * gw;
-                if (tid < 64 * np) {
-                    const int il = gw == 0 ? (tid >> 4) : (gw == 2 ? (tid >> 3) : (gw == 3 ? (tid >> 2) : tid / 12));
-                    const int piece = 4 * gw + (tid - il * np);
+                // (B1) the group's own 64 x 64 block only: for each live candidate i the candidates BEFORE it that suppress it
+                // (its suppressor set: the walk below resolves the group from these, in parallel; the test is symmetric in
+                // its two boxes).  4 threads per row, 16 candidates each.  What the group's SELECTED boxes suppress in the
+                // later groups of the chunk is computed after the walk (B2) -- for the selected rows only, where building
+                // full rows before the walk did it for every live candidate, selected or not.
+                if (tid < 256) {
+                    const int il = tid >> 2;
+                    const int piece = 4 * gw + (tid & 3);
                     const int i = gw * 64 + il;
                     unsigned bits = 0u;
                     const bool i_dead = (deadw[gw] >> il) & 1ull;
                     const int j0 = piece * 16;
-                    // own group's word: the candidates BEFORE i that suppress it (its suppressor set: the walk below
-                    // resolves the group from these, in parallel); later groups' words: the candidates AFTER i that it
-                    // suppresses (ORed into their dead words if i gets selected).  The test is symmetric in its two boxes.
-                    const bool own = (piece >> 2) == gw;
-                    if (!i_dead && (own ? j0 < i : j0 > i)) {
+                    constexpr bool own = true;
+                    if (!i_dead && j0 < i) {
                         const int is = cslot(i);
                         const float4 s4 = cbox4[is];
                         const CBox si{s4.x, s4.y, s4.z, s4.w, carea[is]};
@@ -638,16 +636,45 @@ nms_kernel(NmsArgs p)
                         sel_c4[slot] = b4;
                         sel_a[slot] = carea[cslot(i)];
                         sel_idx[slot] = (int)order[pos + i];
-                        for (int w = gw + 1; w < kChunkWords; ++w) {
-                            const unsigned long long r = mask[lane * kChunkWords + w];
-                            if (r) atomicOr(&deadw[w], r);
-                        }
                     }
                     if (lane == 0) ctl[CTL_NSEL] = c2;
                     NMS_STAMP(8);
                 }
                 __syncthreads();
                 NMS_STAMP(9);
+                {
+                    // (B2) the boxes this group selected (list positions cur .. new count) against the candidates of the
+                    // chunk's later groups: item = (selected box, 16-candidate piece); hits go straight into the later
+                    // groups' dead words (read by their walks behind at least one more barrier)
+                    const int c_new = ctl[CTL_NSEL];
+                    const int npl = 4 * (kChunkWords - 1 - gw);
+                    for (int item = tid; item < (c_new - cur) * npl; item += kNmsThreads) {
+                        const int sl = cur + item / npl, piece = 4 * (gw + 1) + item % npl;
+                        if (piece * 16 >= T) continue;                      // past the band end: dead already
+                        const float4 s4 = sel_c4[sl];
+                        const CBox si{s4.x, s4.y, s4.z, s4.w, sel_a[sl]};
+                        unsigned bits = 0u;
+                        bool decided = true;
+#pragma unroll 4
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const int js = (jj << 4) | piece;               // cslot(16 * piece + jj)
+                            const float4 q4 = cbox4[js];
+                            const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
+                            bits |= (unsigned)nms_suppresses_fast(cj, si, p.iou_lo, p.iou_hi, decided) << jj;
+                        }
+                        if (!decided) {
+                            bits = 0u;
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int js = (jj << 4) | piece;
+                                const float4 q4 = cbox4[js];
+                                const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
+                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                            }
+                        }
+                        if (bits) atomicOr(&deadw[piece >> 2], (unsigned long long)bits << ((piece & 3) * 16));
+                    }
+                    if (npl > 0) __syncthreads();                           // uniform: the next group reads its dead word
+                }
                 cur = ctl[CTL_NSEL];
                 if (p.stop_after == 6) return;
             }
