@@ -9,10 +9,27 @@ from tf_rpn_amd import _lib as L
 VAR = np.float32([0.1, 0.1, 0.2, 0.2])
 anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
 A = len(anchors)
-for B, kind in ((8, "perm"), (8, "model-like"), (64, "perm")):
+_model = {}
+def model_outputs(B):     # the head outputs of bench.py's model (random weights, U[0,1) images)
+    if not _model:
+        from tf_rpn_amd.models._rpn_model import synthetic_weights
+        from tf_rpn_amd.predictor import Proposer
+        from tf_rpn_amd.utils import train_utils
+        hp = dict(train_utils.get_hyper_params("vgg16"))
+        prop = Proposer("vgg16", hyper_params=hp, weights=synthetic_weights("vgg16", hp, seed=1), precision="f16x3",
+                        max_batch=B, iou_threshold=0.7, overlap_nms=True)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+        prop.propose_async(torch.rand((B, 500, 500, 3), generator=gen, device="cuda", dtype=torch.float32))
+        torch.cuda.synchronize()
+        _model["d"] = prop._bufs[0]["reg"][:B].view(B, -1, 4).cpu().numpy().copy()
+        _model["s"] = prop._bufs[0]["cls"][:B].view(B, -1).cpu().numpy().copy()
+    return _model["d"], _model["s"]
+for B, kind in ((8, "perm"), (8, "model-like"), (8, "model"), (64, "perm")):
     rng = np.random.RandomState(2)
     deltas = rng.standard_normal((B, A, 4)).astype(np.float32)
-    if kind == "perm":
+    if kind == "model":
+        deltas, scores = model_outputs(B)
+    elif kind == "perm":
         scores = cases.permutation_scores(np.random.RandomState(3), B, A)
     else:   # smooth score field: neighbours have similar scores -> deep walks (like a conv head's output)
         f = rng.standard_normal((B, 31, 31, 9)).astype(np.float32)

@@ -9,12 +9,27 @@ import numpy as np, torch
 import cases
 from oracle import bbox_oracle as bo
 from tf_rpn_amd import _lib as L
-anchors = bo.generate_anchors(bo.get_hyper_params("vgg16")); A = len(anchors)
-B = 64
-rng = np.random.RandomState(2)
-d = torch.from_numpy(rng.standard_normal((B, A, 4)).astype(np.float32)).cuda()
-s = torch.from_numpy(cases.permutation_scores(np.random.RandomState(3), B, A)).cuda()
-a = torch.from_numpy(anchors).cuda()
+KIND = sys.argv[1] if len(sys.argv) > 1 else "perm"
+if KIND == "model":       # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
+    from tf_rpn_amd.models._rpn_model import synthetic_weights
+    from tf_rpn_amd.predictor import Proposer
+    from tf_rpn_amd.utils import train_utils
+    hp = dict(train_utils.get_hyper_params("vgg16"))
+    B = 8
+    prop = Proposer("vgg16", hyper_params=hp, weights=synthetic_weights("vgg16", hp, seed=1), precision="f16x3", max_batch=B,
+                    iou_threshold=0.7, overlap_nms=True)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    prop.propose_async(torch.rand((B, 500, 500, 3), generator=gen, device="cuda", dtype=torch.float32))
+    torch.cuda.synchronize()
+    a = prop.anchors; A = prop.total_anchors
+    d = prop._bufs[0]["reg"][:B].view(B, -1, 4).clone(); s = prop._bufs[0]["cls"][:B].view(B, -1).clone()
+else:
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16")); A = len(anchors)
+    B = 64
+    rng = np.random.RandomState(2)
+    d = torch.from_numpy(rng.standard_normal((B, A, 4)).astype(np.float32)).cuda()
+    s = torch.from_numpy(cases.permutation_scores(np.random.RandomState(3), B, A)).cuda()
+    a = torch.from_numpy(anchors).cuda()
 ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device="cuda")
 oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
 keep, vptr = L.host_floats(np.float32([0.1, 0.1, 0.2, 0.2]))
@@ -35,7 +50,7 @@ row = ["%d:%d" % (code[0, i], cyc[0, i] - cyc[0, i - 1]) for i in range(1, n)]
 print(" ".join(row))
 # per-code totals, median over workgroups
 tot = {}
-for w in range(64):
+for w in range(B):
     nw = int((code[w] > 0).sum())
     t = {}
     for i in range(1, nw):

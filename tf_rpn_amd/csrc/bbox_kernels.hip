@@ -250,19 +250,6 @@ __device__ __forceinline__ float vmin_vs(float v, float s)
     return r;
 }
 
-__device__ __forceinline__ float vmax_vv(float a, float b)
-{
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmin_vv(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
 // a / b for two pairs, correctly rounded under the range condition above (the instruction sequence of the IEEE divide)
