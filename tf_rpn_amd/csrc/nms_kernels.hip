@@ -302,8 +302,11 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
     size_t o = 0;
     l.band = o;    o = align16(o + (size_t)8 * kBandCap);               // u64 keys, later u32 order in place
     l.hist = o;    o = align16(o + (size_t)4 * kBins);
-    l.sel_c = o;   o = align16(o + (size_t)16 * max_sel);               // canonical selected boxes: float4 [max_sel] ...
-    o = align16(o + (size_t)4 * max_sel);                                //                           ... + area [max_sel]
+    // canonical selected boxes: float4 [max_sel + 32] + area [max_sel + 32].  The 32 more: entries past the selected
+    // count hold a box of infinite area (suppresses nothing, is decided at once), so the loops over the list run to the next
+    // multiple of 32 with a uniform trip count and no lane predicate
+    l.sel_c = o;   o = align16(o + (size_t)16 * (max_sel + 32));
+    o = align16(o + (size_t)4 * (max_sel + 32));
     l.sel_idx = o; o = align16(o + (size_t)4 * max_sel);
     l.cbox = o;    o = align16(o + (size_t)20 * kChunk);                // canonical chunk boxes: float4 [kChunk] + area [kChunk]
     l.mask = o;    o = align16(o + (size_t)8 * 64 * kChunkWords);       // [64 rows of the current group][4] u64
@@ -347,7 +350,7 @@ nms_kernel(NmsArgs p)
     unsigned *order = reinterpret_cast<unsigned *>(smem + L.band);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
     float4 *sel_c4 = reinterpret_cast<float4 *>(smem + L.sel_c);
-    float *sel_a = reinterpret_cast<float *>(smem + L.sel_c + align16((size_t)16 * p.max_sel));
+    float *sel_a = reinterpret_cast<float *>(smem + L.sel_c + align16((size_t)16 * (p.max_sel + 32)));
     int *sel_idx = reinterpret_cast<int *>(smem + L.sel_idx);
     float4 *cbox4 = reinterpret_cast<float4 *>(smem + L.cbox);               // canonical chunk boxes (ymin, xmin, ymax, xmax)
     float *carea = reinterpret_cast<float *>(smem + L.cbox) + 4 * kChunk;    // ... and their areas
@@ -365,6 +368,10 @@ nms_kernel(NmsArgs p)
     const int C = p.C;
 
     if (tid < 16) ctl[tid] = 0;
+    for (int i = tid; i < max_sel + 32; i += kNmsThreads) {
+        sel_c4[i] = float4{0.f, 0.f, 0.f, 0.f};
+        sel_a[i] = INFINITY;
+    }
     __syncthreads();
     NMS_STAMP(1);
 
@@ -473,7 +480,7 @@ nms_kernel(NmsArgs p)
 
         // ================= 2. greedy selection over chunks of the sorted band ===============================
         while (true) {
-            const int nsel = ctl[CTL_NSEL];
+            const int nsel = __builtin_amdgcn_readfirstlane(ctl[CTL_NSEL]);
             const int pos = ctl[CTL_POS];
             if (nsel >= max_sel || pos >= band_n) break;
             const int T = min(kChunk, band_n - pos);
@@ -519,21 +526,19 @@ nms_kernel(NmsArgs p)
                         const float4 c4 = cbox4[st];
                         const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
                         bool decided = true;                        // branch-free tests; the exact ones only if one was close
-                        int j = part;
-                        for (; j + 16 < nsel; j += 32) {            // two selected boxes per trip: their LDS reads overlap
-                            const float4 a4 = sel_c4[j], b4 = sel_c4[j + 16];
-                            const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]}, sb{b4.x, b4.y, b4.z, b4.w, sel_a[j + 16]};
+                        // two selected boxes per trip (their LDS reads overlap), a uniform number of trips: the list is
+                        // padded to a multiple of 32 with boxes that suppress nothing
+                        const float4 *sp = sel_c4 + part;
+                        const float *ap = sel_a + part;
+                        for (int j0 = 0; j0 < nsel; j0 += 32) {
+                            const float4 a4 = sp[j0], b4 = sp[j0 + 16];
+                            const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j0]}, sb{b4.x, b4.y, b4.z, b4.w, ap[j0 + 16]};
                             hit |= nms_suppresses_fast(ci, sa, p.iou_lo, p.iou_hi, decided);
                             hit |= nms_suppresses_fast(ci, sb, p.iou_lo, p.iou_hi, decided);
                         }
-                        if (j < nsel) {
-                            const float4 a4 = sel_c4[j];
-                            const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]};
-                            hit |= nms_suppresses_fast(ci, sa, p.iou_lo, p.iou_hi, decided);
-                        }
                         if (!decided) {
                             hit = false;
-                            for (j = part; j < nsel; j += 16) {
+                            for (int j = part; j < nsel; j += 16) {
                                 const float4 a4 = sel_c4[j];
                                 const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]};
                                 hit |= nms_suppresses(ci, sa, p.iou_thr, p.iou_lo, p.iou_hi);
