@@ -161,6 +161,24 @@ __device__ __forceinline__ bool nms_suppresses_fast(const CBox &i, const CBox &j
     decided = decided && (uni >= 1e-30f) && (hi || lo);
     return hi;
 }
+// The loop form of the same decision (what the NMS kernel's inner loops use).  Returns r = inter - thr * uni from ONE fused
+// multiply-add: one rounding, so r has the sign of the exact difference and `r > 0` is `inter / uni > thr` in exact
+// arithmetic.  `m` collects (v_min) the smallest |r| - eps * uni over the tests of a loop, eps = thr * 2^-18: if it ends
+// above 1e-30, every exact ratio was further than 2^-18 (relative) from the threshold -- 2^5 times the rounding of the IEEE
+// quotient TF compares -- and every `r > 0` is TF's answer; otherwise the caller repeats its tests with nms_suppresses.
+// A NaN or -inf r (a box of area key +inf, NaN or infinite coordinates) is "not suppressed", which is TF's answer for
+// those (0 > thr, or a NaN quotient); its margin is NaN, which v_min passes over.  Only for 1e-6 <= thr <= 1e6 (the host
+// starts `m` at 0 otherwise).
+__device__ __forceinline__ float nms_excess(const CBox &i, const CBox &j, float thr, float eps, float &m)
+{
+    const float iymin = vmax_vv(i.ymin, j.ymin), ixmin = vmax_vv(i.xmin, j.xmin);
+    const float iymax = vmin_vv(i.ymax, j.ymax), ixmax = vmin_vv(i.xmax, j.xmax);
+    const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
+    const float uni = i.area + j.area - inter;
+    const float r = __builtin_fmaf(-thr, uni, inter);
+    m = vmin_vv(m, __builtin_fmaf(-eps, uni, __builtin_fabsf(r)));
+    return r;
+}
 __device__ __forceinline__ float nms_area_key(float area) { return area <= 0.0f ? INFINITY : area; }
 
 // monotone map float -> uint32 (descending float order == descending uint order);

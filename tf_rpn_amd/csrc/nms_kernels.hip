@@ -43,7 +43,11 @@ constexpr int kChunkWords = kChunk / 64;
 // Chunk boxes are stored at slot(j) = (j % 16) * 16 + j / 16: the threads that build one suppression row read 16
 // candidates 16 apart (j = 16 * piece + jj, piece = lane % 16) -- consecutive slots, conflict-free; in natural order
 // those reads are 8-way bank conflicts (measured: 8 us per 64-row group).
-__device__ __forceinline__ int cslot(int j) { return ((j & 15) << 4) | (j >> 4); }
+// LDS slot of chunk candidate j = 16 * piece + jj: row jj of a 16 x 16 transpose, the piece XOR-swizzled by the row's upper
+// two bits.  Threads that differ in the piece (step B2) and threads that cover a group's 4 pieces x 4 rows (step B1) both read
+// 16 different 16-byte columns.
+__device__ __forceinline__ int cslot2(int jj, int piece) { return (jj << 4) | (piece ^ (jj & 12)); }
+__device__ __forceinline__ int cslot(int j) { return cslot2(j & 15, j >> 4); }
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct NmsArgs {
@@ -57,6 +61,7 @@ struct NmsArgs {
     int max_total;
     float iou_thr, score_thr;
     float iou_lo, iou_hi;    // iou_thr * (1 -+ 2^-18) (nms_suppresses); -inf / +inf when iou_thr is not positive and finite
+    float iou_eps, m0;       // nms_excess: iou_thr * 2^-18 and the start of its margin (+inf; 0 = always take the exact tests)
     int clip;
     // final outputs (written directly when C == 1)
     float *out_boxes, *out_scores, *out_classes;
@@ -525,18 +530,20 @@ nms_kernel(NmsArgs p)
                         const int st = cslot(t);
                         const float4 c4 = cbox4[st];
                         const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
-                        bool decided = true;                        // branch-free tests; the exact ones only if one was close
                         // two selected boxes per trip (their LDS reads overlap), a uniform number of trips: the list is
-                        // padded to a multiple of 32 with boxes that suppress nothing
+                        // padded to a multiple of 32 with boxes that suppress nothing.  Branch-free: the largest excess
+                        // and the smallest margin (nms_excess); the exact tests only if one ratio was close
                         const float4 *sp = sel_c4 + part;
                         const float *ap = sel_a + part;
+                        float ha = -INFINITY, hb = -INFINITY, ma = p.m0, mb = p.m0;
                         for (int j0 = 0; j0 < nsel; j0 += 32) {
                             const float4 a4 = sp[j0], b4 = sp[j0 + 16];
                             const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j0]}, sb{b4.x, b4.y, b4.z, b4.w, ap[j0 + 16]};
-                            hit |= nms_suppresses_fast(ci, sa, p.iou_lo, p.iou_hi, decided);
-                            hit |= nms_suppresses_fast(ci, sb, p.iou_lo, p.iou_hi, decided);
+                            ha = vmax_vv(ha, nms_excess(ci, sa, p.iou_thr, p.iou_eps, ma));
+                            hb = vmax_vv(hb, nms_excess(ci, sb, p.iou_thr, p.iou_eps, mb));
                         }
-                        if (!decided) {
+                        hit = vmax_vv(ha, hb) > 0.0f;
+                        if (!(vmin_vv(ma, mb) > 1e-30f)) {
                             hit = false;
                             for (int j = part; j < nsel; j += 16) {
                                 const float4 a4 = sel_c4[j];
@@ -559,45 +566,47 @@ nms_kernel(NmsArgs p)
                 }
                 // (B1) the group's own 64 x 64 block only: for each live candidate i the candidates BEFORE it that suppress it
                 // (its suppressor set: the walk below resolves the group from these, in parallel; the test is symmetric in
-                // its two boxes).  4 threads per row, 16 candidates each.  What the group's SELECTED boxes suppress in the
+                // its two boxes).  16 threads per row, 4 candidates each.  What the group's SELECTED boxes suppress in the
                 // later groups of the chunk is computed after the walk (B2) -- for the selected rows only, where building
                 // full rows before the walk did it for every live candidate, selected or not.
-                if (tid < 256) {
-                    const int il = tid >> 2;
-                    const int piece = 4 * gw + (tid & 3);
+                {
+                    // 16 threads per row, 4 candidates each: piece (sub & 3) of the group, rows 4 (sub >> 2) .. + 3 of it
+                    const int il = tid >> 4, sub = tid & 15;
+                    const int piece = 4 * gw + (sub & 3), jj0 = 4 * (sub >> 2);
                     const int i = gw * 64 + il;
+                    const int j0 = piece * 16 + jj0;
                     unsigned bits = 0u;
-                    const bool i_dead = (deadw[gw] >> il) & 1ull;
-                    const int j0 = piece * 16;
-                    constexpr bool own = true;
-                    if (!i_dead && j0 < i) {
+                    const unsigned long long dw = deadw[gw];
+                    if (!((dw >> il) & 1ull) && j0 < i) {
                         const int is = cslot(i);
                         const float4 s4 = cbox4[is];
                         const CBox si{s4.x, s4.y, s4.z, s4.w, carea[is]};
-                        unsigned todo = (unsigned)(~deadw[piece >> 2] >> ((piece & 3) * 16)) & 0xFFFFu;
-                        if (own && j0 + 16 > i) todo &= (1u << (i - j0)) - 1u;     // own group: only j < i
-                        // all 16 candidates of the piece, unconditionally (one 16-byte + one 4-byte conflict-free LDS read
-                        // each, no find-first-set loop); the bits of dead candidates are masked off afterwards
-                        bool decided = true;
-#pragma unroll 4
-                        for (int jj = 0; jj < 16; ++jj) {
-                            const int js = (jj << 4) | piece;               // cslot(j0 + jj)
+                        unsigned todo = (unsigned)(~dw >> (j0 & 63)) & 0xFu;
+                        if (j0 + 4 > i) todo &= (1u << (i - j0)) - 1u;             // only j < i
+                        float m = p.m0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int js = cslot2(jj0 + t, piece);
                             const float4 q4 = cbox4[js];
                             const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
-                            bits |= (unsigned)nms_suppresses_fast(cj, si, p.iou_lo, p.iou_hi, decided) << jj;
+                            bits |= (unsigned)(nms_excess(cj, si, p.iou_thr, p.iou_eps, m) > 0.0f) << t;
                         }
-                        if (!decided) {                                     // a ratio close to the threshold: the exact tests
+                        if (!(m > 1e-30f)) {                                // a ratio close to the threshold: the exact tests
                             bits = 0u;
-                            for (int jj = 0; jj < 16; ++jj) {
-                                const int js = (jj << 4) | piece;
+                            for (int t = 0; t < 4; ++t) {
+                                const int js = cslot2(jj0 + t, piece);
                                 const float4 q4 = cbox4[js];
                                 const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
-                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << t;
                             }
                         }
                         bits &= todo;
                     }
-                    reinterpret_cast<unsigned short *>(mask)[il * 16 + piece] = (unsigned short)bits;
+                    // bits 16 (sub & 3) + 4 (sub >> 2) + t of row il's own word: lanes sub and sub ^ 4 share a byte
+                    const unsigned other = (unsigned)__shfl_xor((int)bits, 4);
+                    if (!(sub & 4))
+                        reinterpret_cast<unsigned char *>(mask)[(il * kChunkWords + gw) * 8 + 2 * (sub & 3) + (sub >> 3)] =
+                            (unsigned char)(bits | (other << 4));
                 }
                 __syncthreads();
                 NMS_STAMP(7);
@@ -651,32 +660,38 @@ nms_kernel(NmsArgs p)
                     // (B2) the boxes this group selected (list positions cur .. new count) against the candidates of the
                     // chunk's later groups: item = (selected box, 16-candidate piece); hits go straight into the later
                     // groups' dead words (read by their walks behind at least one more barrier)
+                    // (finer items when there are few of them: 8 or 4 candidates per thread instead of 16)
                     const int c_new = ctl[CTL_NSEL];
                     const int npl = 4 * (kChunkWords - 1 - gw);
-                    for (int item = tid; item < (c_new - cur) * npl; item += kNmsThreads) {
-                        const int sl = cur + item / npl, piece = 4 * (gw + 1) + item % npl;
-                        if (piece * 16 >= T) continue;                      // past the band end: dead already
+                    const int items16 = (c_new - cur) * npl;
+                    const int fsh = items16 <= kNmsThreads / 4 ? 2 : (items16 <= kNmsThreads / 2 ? 1 : 0);   // log2(parts per piece)
+                    const int per = 16 >> fsh;
+                    for (int item = tid; item < (items16 << fsh); item += kNmsThreads) {
+                        const int pi = item % npl, rest = item / npl;       // the piece varies fastest: conflict-free reads
+                        const int part = rest & ((1 << fsh) - 1), sl = cur + (rest >> fsh);
+                        const int piece = 4 * (gw + 1) + pi, jj0 = part * per;
+                        if (piece * 16 + jj0 >= T) continue;                // past the band end: dead already
                         const float4 s4 = sel_c4[sl];
                         const CBox si{s4.x, s4.y, s4.z, s4.w, sel_a[sl]};
                         unsigned bits = 0u;
-                        bool decided = true;
+                        float m = p.m0;
 #pragma unroll 4
-                        for (int jj = 0; jj < 16; ++jj) {
-                            const int js = (jj << 4) | piece;               // cslot(16 * piece + jj)
+                        for (int t = 0; t < per; ++t) {
+                            const int js = cslot2(jj0 + t, piece);
                             const float4 q4 = cbox4[js];
                             const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
-                            bits |= (unsigned)nms_suppresses_fast(cj, si, p.iou_lo, p.iou_hi, decided) << jj;
+                            bits |= (unsigned)(nms_excess(cj, si, p.iou_thr, p.iou_eps, m) > 0.0f) << t;
                         }
-                        if (!decided) {
+                        if (!(m > 1e-30f)) {
                             bits = 0u;
-                            for (int jj = 0; jj < 16; ++jj) {
-                                const int js = (jj << 4) | piece;
+                            for (int t = 0; t < per; ++t) {
+                                const int js = cslot2(jj0 + t, piece);
                                 const float4 q4 = cbox4[js];
                                 const CBox cj{q4.x, q4.y, q4.z, q4.w, carea[js]};
-                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << jj;
+                                if (nms_suppresses(cj, si, p.iou_thr, p.iou_lo, p.iou_hi)) bits |= 1u << t;
                             }
                         }
-                        if (bits) atomicOr(&deadw[piece >> 2], (unsigned long long)bits << ((piece & 3) * 16));
+                        if (bits) atomicOr(&deadw[piece >> 2], (unsigned long long)bits << ((piece & 3) * 16 + jj0));
                     }
                     if (npl > 0) __syncthreads();                           // uniform: the next group reads its dead word
                 }
@@ -817,6 +832,9 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
         p.iou_lo = -INFINITY;
         p.iou_hi = INFINITY;
     }
+    const bool fast = p.iou_thr >= 1e-6f && p.iou_thr <= 1e6f;
+    p.iou_eps = fast ? p.iou_thr * 0x1p-18f : 0.0f;
+    p.m0 = fast ? INFINITY : 0.0f;
     const LdsLayout L = lds_layout(p.max_sel);
     if (L.total > kLdsLimit)
         return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,
