@@ -242,6 +242,39 @@ def test_nms_heavy_suppression_walks_many_chunks():
     assert (got[3] < 300).all() and (got[3] >= 20).all()      # ~40 overlapping clusters survive as 30-40 boxes
 
 
+def test_nms_ratios_on_and_next_to_the_threshold():
+    """IoUs that are exactly the threshold, or one float above / below it: dyadic boxes whose intersection / union is exactly
+    1/4, 1/2, 3/4 (the kernel's fused pre-test is undecided there and must fall back to the IEEE quotient), with the
+    threshold at that value and at its two neighbours; and ratios a few 2^-20 away from the threshold."""
+    rng = np.random.RandomState(21)
+    rows = []
+    for k in range(400):                                     # pairs (a, b): b shares a's corner, IoU = 1/4, 1/2 or 3/4
+        s = 2.0 ** -rng.randint(3, 6)
+        y, x = rng.randint(0, 8, size=2) * 0.125
+        f = (0.25, 0.5, 0.75)[k % 3]
+        rows += [[y, x, y + s, x + s], [y, x, y + s, x + s * f]]
+    boxes = np.float32(rows)
+    boxes = boxes[rng.permutation(len(boxes))][None]
+    scores = cases.permutation_scores(rng, 1, boxes.shape[1])
+    for centre in (0.25, 0.5, 0.75):
+        c = np.float32(centre)
+        for thr in (np.nextafter(c, np.float32(0)), c, np.nextafter(c, np.float32(1))):
+            _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=800, max_total_size=800,
+                       iou_threshold=float(thr), clip_boxes=False)
+    # near misses: b = a narrowed by (1 - f) with f = thr * (1 + k 2^-20), k = -8 .. 8
+    rows = []
+    for k in range(-8, 9):
+        for rep in range(12):
+            s = np.float32(rng.uniform(0.05, 0.3))
+            y, x = np.float32(rng.uniform(0, 0.6, size=2))
+            f = np.float32(0.7) * np.float32(1 + k * 2.0 ** -20)
+            rows += [[y, x, y + s, x + s], [y, x, y + s, x + s * f]]
+    boxes = np.float32(rows)[None]
+    scores = cases.permutation_scores(rng, 1, boxes.shape[1])
+    _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+               iou_threshold=0.7, clip_boxes=False)
+
+
 def test_nms_thresholds_sizes_and_limits():
     rng = np.random.RandomState(13)
     boxes = cases.clustered_boxes(rng, 2, 1000, n_clusters=30)
