@@ -663,7 +663,7 @@ nms_kernel(NmsArgs p)
                     // (finer items when there are few of them: 8 or 4 candidates per thread instead of 16)
                     const int c_new = ctl[CTL_NSEL];
                     const int npl = 4 * (kChunkWords - 1 - gw);
-                    const int items16 = (c_new - cur) * npl;
+                    const int items16 = c_new < max_sel ? (c_new - cur) * npl : 0;    // (output complete: nothing follows)
                     const int fsh = items16 <= kNmsThreads / 4 ? 2 : (items16 <= kNmsThreads / 2 ? 1 : 0);   // log2(parts per piece)
                     const int per = 16 >> fsh;
                     for (int item = tid; item < (items16 << fsh); item += kNmsThreads) {
