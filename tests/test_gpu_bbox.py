@@ -275,6 +275,38 @@ def test_nms_ratios_on_and_next_to_the_threshold():
                iou_threshold=0.7, clip_boxes=False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_nms_without_the_linear_histogram_subprocess(mode):
+    """RPN_NMS_LINEAR (read once per process) = 0: radix select + compaction + bitonic sort only; = 2: histogram select,
+    band sorted the old way.  Same outputs, bit for bit, as the oracle on C3-shaped, clustered and multi-band inputs."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import cases
+        from oracle import bbox_oracle as bo
+        from tests.test_gpu_bbox import _check_nms, VAR
+        anchors = bo.generate_anchors(bo.get_hyper_params("vgg16")); A = len(anchors)
+        deltas = np.random.RandomState(2).standard_normal((4, A, 4)).astype(np.float32)
+        boxes = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))
+        scores = cases.permutation_scores(np.random.RandomState(3), 4, A)
+        for thr in (0.5, 0.7):
+            got = _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                             iou_threshold=thr)
+            assert (got[3] == 300).all()
+        rng = np.random.RandomState(15)
+        cl = cases.clustered_boxes(rng, 2, 20000, n_clusters=60, jitter=0.002)
+        _check_nms(cl[:, :, None, :], cases.permutation_scores(rng, 2, 20000)[:, :, None], max_output_size_per_class=300,
+                   max_total_size=300, iou_threshold=0.4)
+        print("nms fallback ok")
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPN_NMS_LINEAR=mode), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "nms fallback ok" in r.stdout
+
+
 def test_nms_thresholds_sizes_and_limits():
     rng = np.random.RandomState(13)
     boxes = cases.clustered_boxes(rng, 2, 1000, n_clusters=30)
