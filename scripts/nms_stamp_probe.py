@@ -10,6 +10,7 @@ import cases
 from oracle import bbox_oracle as bo
 from tf_rpn_amd import _lib as L
 KIND = sys.argv[1] if len(sys.argv) > 1 else "perm"
+THR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.7
 if KIND == "model":       # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
     from tf_rpn_amd.models._rpn_model import synthetic_weights
     from tf_rpn_amd.predictor import Proposer
@@ -35,7 +36,7 @@ oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((
 keep, vptr = L.host_floats(np.float32([0.1, 0.1, 0.2, 0.2]))
 lib = L.lib()
 for _ in range(3):
-    L.check(lib.rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, 0.7, float("-inf"), 1, L.ptr(ob), L.ptr(osc),
+    L.check(lib.rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, THR, float("-inf"), 1, L.ptr(ob), L.ptr(osc),
                                L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (64 * 512))()
