@@ -24,6 +24,7 @@ def model_outputs(B):     # the head outputs of bench.py's model (random weights
         _model["d"] = prop._bufs[0]["reg"][:B].view(B, -1, 4).cpu().numpy().copy()
         _model["s"] = prop._bufs[0]["cls"][:B].view(B, -1).cpu().numpy().copy()
     return _model["d"], _model["s"]
+THR = float(os.environ.get("NMS_THR", "0.7"))
 for B, kind in ((8, "perm"), (8, "model-like"), (8, "model"), (64, "perm")):
     rng = np.random.RandomState(2)
     deltas = rng.standard_normal((B, A, 4)).astype(np.float32)
@@ -41,11 +42,11 @@ for B, kind in ((8, "perm"), (8, "model-like"), (8, "model"), (64, "perm")):
     oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
     keep, vptr = L.host_floats(VAR)
     def run():
-        L.check(L.lib().rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, 0.7, float("-inf"), 1, L.ptr(ob),
+        L.check(L.lib().rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, THR, float("-inf"), 1, L.ptr(ob),
                                        L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
-    print("stop=%s B=%d %s: %.1f us" % (os.environ.get("RPN_NMS_STOP", "0"), B, kind, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+    print("thr=%s B=%d %s: %.1f us" % (THR, B, kind, e0.elapsed_time(e1) / 20 * 1e3), flush=True)

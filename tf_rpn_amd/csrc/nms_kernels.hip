@@ -274,22 +274,28 @@ __device__ inline bool band_order_linear(const float *__restrict__ sc, int C, in
         }
     }
     __syncthreads();
-    // rank inside the bin's segment (keys are unique)
-    unsigned long long key = 0ull;
-    int pos = -1;
-    if (tid < n) {
-        key = band[tid];
-        const int b = linear_bin(key_score(key));
-        const int seg0 = (int)boff[b], cnt = (int)hist[b];
-        int rank = 0;
-        for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key ? 1 : 0;
-        pos = seg0 + rank;
+    // rank inside the bin's segment (keys are unique); up to two keys per thread (n <= 2048)
+    unsigned long long key[2] = {0ull, 0ull};
+    int pos[2] = {-1, -1};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * kNmsThreads;
+        if (i < n) {
+            key[u] = band[i];
+            const int b = linear_bin(key_score(key[u]));
+            const int seg0 = (int)boff[b], cnt = (int)hist[b];
+            int rank = 0;
+            for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key[u] ? 1 : 0;
+            pos[u] = seg0 + rank;
+        }
     }
     __syncthreads();                         // every key is in a register: `order` aliases `band`
-    if (pos >= 0) {
-        order[pos] = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        if (pos == n - 1) *low_out = key;
-    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (pos[u] >= 0) {
+            order[pos[u]] = 0xFFFFFFFFu - (unsigned)(key[u] & 0xFFFFFFFFull);
+            if (pos[u] == n - 1) *low_out = key[u];
+        }
     __syncthreads();
     return true;
 }
@@ -381,14 +387,22 @@ nms_kernel(NmsArgs p)
     NMS_STAMP(1);
 
     unsigned long long hi_bound = ~0ull;       // keys of the current band are < hi_bound (exclusive)
+    int visited = 0, have_before = 0;          // candidates of the band before this one; boxes selected before it (uniform)
 
     while (true) {
         // ================= 1. pick the next band: keys in [thr, hi_bound) ==========================
         int band_expected = 0;
         // band size: a few times the number of boxes still wanted (most images finish inside the first band), so that
         // the sort below is a 1024-key rank sort instead of a 4096-key bitonic network
-        const int want_left = max_sel - ctl[CTL_NSEL];
-        const int band_target = min(kBandTarget, max(512, 2 * want_left));
+        const int have = ctl[CTL_NSEL];
+        const int want_left = max_sel - have;
+        // first band: twice the boxes wanted.  Later bands: sized from the yield of the band before (boxes selected per
+        // candidate visited; it falls as the selected set grows, hence the factor 2), so that a deep walk -- low IoU
+        // threshold, clustered boxes -- takes 2 bands instead of 4; up to what the histogram ordering handles (2 keys
+        // per thread).  A band that is too large costs little: its chunks are only built as far as the walk gets.
+        const int by_yield = (int)min((long long)want_left * visited / max(have - have_before, 1) * 2, 1792ll);
+        const int band_target = visited == 0 ? min(kBandTarget, max(512, 2 * want_left)) : max(512, by_yield);
+        have_before = have;
         const int band_cap = band_target <= 768 ? 1024 : kBandCap;
         unsigned long long thr = 0ull;
         int lin_bin = -1;                    // >= 0: the band was chosen by the linear histogram (still in `hist`) at this bin
@@ -405,7 +419,7 @@ nms_kernel(NmsArgs p)
 
         int band_n = 0;
         bool ordered = false;
-        if (lin_bin > 0 && band_expected <= kNmsThreads && p.linear_select != 2) {
+        if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
             ordered = band_order_linear(sc, C, N, p.score_thr, thr, hi_bound, lin_bin, band_expected, hist, band, order,
                                         reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             if (ordered) {
@@ -703,6 +717,7 @@ nms_kernel(NmsArgs p)
             if (p.stop_after == 7) return;
         }
         if (ctl[CTL_NSEL] >= max_sel) break;
+        visited = band_n;
         __syncthreads();
     }
     __syncthreads();
