@@ -220,6 +220,29 @@ def test_nms_full_size_decoded_anchors(backbone, B, iou_thr):
     assert (got[3] == 300).all()
 
 
+@pytest.mark.parametrize("iou_thr", [0.5, 0.7])
+def test_nms_deep_walk_on_a_smooth_score_field(iou_thr):
+    """What a trained head produces rather than C3's random draw: boxes close to their anchors (small deltas) and a smooth
+    objectness field, so that neighbours overlap heavily AND have near-equal scores -- thousands of candidates are visited,
+    across several bands of adaptive size, for 300 outputs."""
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
+    A = len(anchors)
+    rng = np.random.RandomState(31)
+    deltas = (0.3 * rng.standard_normal((3, A, 4))).astype(np.float32)
+    f = rng.standard_normal((3, 31, 31, 9)).astype(np.float32)
+    for _ in range(3):
+        f = (f + np.roll(f, 1, 1) + np.roll(f, 1, 2) + np.roll(f, -1, 1) + np.roll(f, -1, 2)) / 5
+    scores = (1 / (1 + np.exp(-8 * f))).reshape(3, A).astype(np.float32)
+    boxes = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))
+    got = _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                     iou_threshold=iou_thr)
+    assert (got[3] > 200).all()          # (at 0.5 every candidate is visited and fewer than 300 survive)
+    fb, fs, fi, fv = bbox_utils.decode_and_nms(anchors, deltas, scores, VAR, 300, iou_threshold=iou_thr)
+    gpu_boxes = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)
+    rb, rs, _rc, rv, ri = co.combined_nms(gpu_boxes[:, :, None, :], scores[:, :, None], 300, 300, iou_threshold=iou_thr)
+    assert np.array_equal(fv, rv) and np.array_equal(fi, ri) and np.array_equal(fb, rb)
+
+
 def test_nms_ties_and_duplicates_on_raw_anchors():
     """Clipped anchors contain 744 exact duplicate rows; with constant / coarse scores every tie rule fires."""
     anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
@@ -305,6 +328,49 @@ def test_nms_without_the_linear_histogram_subprocess(mode):
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "nms fallback ok" in r.stdout
+
+
+def test_nms_randomised_shapes_thresholds_and_box_kinds():
+    """240 seeded random problems against the oracle, bit for bit: N from 1 to 3000 (partial groups, partial chunks, several
+    chunks), output sizes from 1 to 400, thresholds over (0, 1) including dyadic ones that the boxes' ratios hit exactly,
+    random / tightly clustered / grid-aligned / duplicated / flipped / degenerate boxes, tie-free and heavily tied scores,
+    with and without a score threshold."""
+    rng = np.random.RandomState(77)
+    for it in range(240):
+        B = int(rng.randint(1, 4))
+        N = int(rng.choice([rng.randint(1, 70), rng.randint(60, 330), rng.randint(300, 3000)]))
+        kind = it % 4
+        if kind == 0:
+            boxes = cases.random_boxes(rng, (B, N))
+        elif kind == 1:
+            boxes = cases.clustered_boxes(rng, B, N, n_clusters=int(rng.randint(1, 30)), jitter=float(rng.choice([0.0, 0.002, 0.02])))
+        elif kind == 2:       # grid-aligned boxes: intersections / unions in exact dyadic ratios
+            y, x = rng.randint(0, 12, size=(2, B, N)) / 16.0
+            h, w = rng.randint(1, 5, size=(2, B, N)) / 16.0
+            boxes = np.stack([y, x, y + h, x + w], axis=-1).astype(np.float32)
+        else:                 # a mixture with duplicates, flipped corners and degenerate boxes
+            boxes = cases.clustered_boxes(rng, B, N, n_clusters=8)
+            k = max(1, N // 5)
+            boxes[:, rng.randint(0, N, size=k)] = boxes[:, rng.randint(0, N, size=k)]
+            fl = rng.randint(0, N, size=k)
+            boxes[:, fl] = boxes[:, fl][..., [2, 3, 0, 1]]
+            boxes[:, rng.randint(0, N, size=max(1, N // 20)), 2] = boxes[:, rng.randint(0, N, size=max(1, N // 20)), 0]
+        if it % 3 == 0:
+            scores = cases.permutation_scores(rng, B, N)
+        elif it % 3 == 1:
+            scores = (rng.randint(0, 6, size=(B, N)) / 8.0).astype(np.float32)           # heavy ties: the index order decides
+        else:
+            scores = rng.uniform(-0.5, 1.5, size=(B, N)).astype(np.float32)              # outside [0, 1): the radix path
+        thr = float(rng.choice([rng.uniform(0.05, 0.95), 0.25, 0.5, 0.75, 1.0 / 3.0]))
+        m = int(rng.choice([1, 7, 64, 100, 300, 400]))
+        kw = dict(max_output_size_per_class=m, max_total_size=int(rng.choice([m, max(1, m // 2)])), iou_threshold=thr,
+                  clip_boxes=bool(it & 1))
+        if it % 5 == 0:
+            kw["score_threshold"] = float(rng.uniform(0.0, 0.6))
+        try:
+            _check_nms(boxes[:, :, None, :], scores[:, :, None], **kw)
+        except AssertionError as e:
+            raise AssertionError("case %d (B=%d N=%d kind=%d %r): %s" % (it, B, N, kind, kw, e))
 
 
 def test_nms_thresholds_sizes_and_limits():
