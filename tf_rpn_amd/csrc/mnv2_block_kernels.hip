@@ -1121,8 +1121,9 @@ ir_block_x3_kernel(IrX3Args a)
 bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
     if (stride != 1 || cexp != 6 * cin) return false;
+    static const int b45 = getenv("RPN_MN_X3_B45") ? atoi(getenv("RPN_MN_X3_B45")) : 1;     // blocks 4, 5 (32 -> 192 -> 32)
     return (cin == 64 && cout == 64 && residual) || (cin == 64 && cout == 96 && !residual) ||
-           (cin == 96 && cout == 96 && residual);
+           (cin == 96 && cout == 96 && residual) || (b45 && cin == 32 && cout == 32 && residual);
 }
 
 // Host packing of one 1x1 weight matrix W[k][n] (row-major, ld = n_total) into the fragment-major hi / lo images the
@@ -1183,7 +1184,8 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
         int sc = -1, ss = -1;
         a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == 1 && (cin != 64 || cout == 64);
     }
-    if (cin == 64 && cout == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 64, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
+    if (cin == 32) hipLaunchKernelGGL((ir_block_x3_kernel<32, 192, 32, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
+    else if (cin == 64 && cout == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 64, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
     else if (cin == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 96, false>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((ir_block_x3_kernel<96, 576, 96, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
     return hipGetLastError();
