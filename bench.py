@@ -272,14 +272,26 @@ def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmu
     prop.wait()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # latency of ONE step end to end (images resident -> proposals resident, nothing overlapped across steps): HIP events
+    # around propose() on an idle device, median of `steps` repeats -- what configs quoted per image (c1, c5) mean by it
+    lat = []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        prop.propose(imgs)                       # orders the current stream behind the NMS
+        e1.record()
+        torch.cuda.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    lat.sort()
     n_launches = len(prop.rpn_model.ops())
     del prop, imgs
     torch.cuda.empty_cache()
     return {"workload": "%s: %s, %dx%d, %d anchors/cell, batch %d per GPU" % (label, backbone, hp["img_size"], hp["img_size"],
                                                                              hp["anchor_count"], B),
             "value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4),
-            "ms_per_image": round(1e3 * dt / steps / B, 4), "steps": steps, "dtype": precision,
-            "conv_launches_per_step": n_launches}
+            "ms_per_image": round(1e3 * dt / steps / B, 4), "latency_ms_one_step_unpipelined": round(lat[len(lat) // 2], 4),
+            "steps": steps, "dtype": precision, "conv_launches_per_step": n_launches}
 
 
 def c3_leg(hp, n=30):

@@ -11,16 +11,21 @@ from oracle import bbox_oracle as bo
 from tf_rpn_amd import _lib as L
 KIND = sys.argv[1] if len(sys.argv) > 1 else "perm"
 THR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.7
-if KIND == "model":       # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
+if KIND in ("model", "model_c5"):   # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
     from tf_rpn_amd.models._rpn_model import synthetic_weights
     from tf_rpn_amd.predictor import Proposer
     from tf_rpn_amd.utils import train_utils
-    hp = dict(train_utils.get_hyper_params("vgg16"))
-    B = 8
-    prop = Proposer("vgg16", hyper_params=hp, weights=synthetic_weights("vgg16", hp, seed=1), precision="f16x3", max_batch=B,
+    if KIND == "model":
+        bb, B, size = "vgg16", 8, 500
+        hp = dict(train_utils.get_hyper_params("vgg16"))
+    else:                           # configs[4]: MobileNetV2, 1024 x 1024, 15 anchors per cell, one image
+        bb, B, size = "mobilenet_v2", 1, 1024
+        hp = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                               anchor_ratios=[1., 2., 1. / 2., 3., 1. / 3.]))
+    prop = Proposer(bb, hyper_params=hp, weights=synthetic_weights(bb, hp, seed=1), precision="f16x3", max_batch=B,
                     iou_threshold=0.7, overlap_nms=True)
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
-    prop.propose_async(torch.rand((B, 500, 500, 3), generator=gen, device="cuda", dtype=torch.float32))
+    prop.propose_async(torch.rand((B, size, size, 3), generator=gen, device="cuda", dtype=torch.float32))
     torch.cuda.synchronize()
     a = prop.anchors; A = prop.total_anchors
     d = prop._bufs[0]["reg"][:B].view(B, -1, 4).clone(); s = prop._bufs[0]["cls"][:B].view(B, -1).clone()

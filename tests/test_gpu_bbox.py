@@ -373,6 +373,25 @@ def test_nms_randomised_shapes_thresholds_and_box_kinds():
             raise AssertionError("case %d (B=%d N=%d kind=%d %r): %s" % (it, B, N, kind, kw, e))
 
 
+def test_nms_bunched_and_saturated_scores():
+    """Scores bunched into a few of the selection histogram's 2048 linear bins (so the kernel refines inside the crossing
+    bin), including the top bin of a saturated sigmoid with scores exactly 1.0, ties inside a sub-bin and a bunch whose
+    crossing bin is bin 0 / holds more ties than a band may take (the radix select takes over)."""
+    rng = np.random.RandomState(41)
+    N = 30000
+    boxes = cases.random_boxes(rng, (2, N), smin=0.02, smax=0.08)
+    b4 = boxes[:, :, None, :]
+    sat = 1.0 / (1.0 + np.exp(-rng.normal(11.0, 4.0, size=(2, N))))                  # most of them in [0.9995, 1]
+    sat = sat.astype(np.float32)
+    assert (sat == 1.0).sum() > 10 and (sat > 2047 / 2048).mean() > 0.5
+    mid = (0.5 + 1e-4 * rng.standard_normal((2, N))).astype(np.float32)               # one or two bins around 0.5
+    coarse = (np.float32(0.75) + rng.randint(0, 40, size=(2, N)).astype(np.float32) * np.float32(2.0 ** -23))   # 40 distinct values
+    low = (1e-5 * rng.uniform(size=(2, N))).astype(np.float32)                       # everything in bin 0
+    for scores in (sat, mid, coarse, low):
+        for thr in (0.5, 0.7):
+            _check_nms(b4, scores[:, :, None], max_output_size_per_class=300, max_total_size=300, iou_threshold=thr)
+
+
 def test_nms_thresholds_sizes_and_limits():
     rng = np.random.RandomState(13)
     boxes = cases.clustered_boxes(rng, 2, 1000, n_clusters=30)

@@ -49,6 +49,7 @@ constexpr int kChunkWords = kChunk / 64;
 __device__ __forceinline__ int cslot2(int jj, int piece) { return (jj << 4) | (piece ^ (jj & 12)); }
 __device__ __forceinline__ int cslot(int j) { return cslot2(j & 15, j >> 4); }
 constexpr size_t kLdsLimit = 160 * 1024;
+constexpr int kLoadBatch = 8;          // score loads in flight per thread in the passes over all N scores
 
 struct NmsArgs {
     const float *boxes;      // (B,N,q,4)            [plain]   | deltas (B,N,4) [decode]
@@ -157,27 +158,13 @@ __device__ __forceinline__ unsigned long long make_key(float s, float thr, int i
 // threshold score d / 2048 (exact in float; score >= d / 2048 <=> floor(score * 2048) >= d), i.e. the key threshold
 // orderable(d / 2048) << 32.  Returns false -- caller falls back to the radix select -- when that bin holds more than
 // the band may take, or is bin 0 (which also collects the scores below 0).  hist: 2048 words; ctl: 4 ints.
-__device__ inline bool band_select_linear(const float *__restrict__ sc, int C, int N, float score_thr,
-                                          unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
-                                          unsigned long long *thr_out, int *count, int *bin_out)
+// wave 0: the bin where the count from the top bin down reaches `want` -> ctl[0] (-1: no keys at all, -2: fewer than
+// `want` in all), ctl[1] = keys in the bins >= it (or the total).  Lane l owns bins 2047 - 32 l .. - 31.
+__device__ __forceinline__ void linear_hist_find(const unsigned *hist, int want, int *ctl)
 {
     constexpr int NB = 2048;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
-    __syncthreads();
-    for (int base = tid; base < N; base += 8 * kNmsThreads) {
-        float sb[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);     // 0 for NaN / below threshold
-            if (key != 0ull && key < hi_bound)
-                atomicAdd(&hist[(int)fminf(fmaxf(sb[u] * 2048.0f, 0.0f), 2047.0f)], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {                         // wave 0: suffix sums from the top bin; lane l owns bins 2047 - 32 l .. - 31
+    if (tid < 64) {
         constexpr int per = NB / 64;
         const int top = NB - 1 - lane * per;
         unsigned mine = 0u;
@@ -207,15 +194,72 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
             ctl[1] = (int)run;              // keys in bins >= d
         }
     }
+}
+
+__device__ inline bool band_select_linear(const float *__restrict__ sc, int C, int N, float score_thr,
+                                          unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
+                                          unsigned long long *thr_out, int *count, int *bin_out)
+{
+    constexpr int NB = 2048;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
+    __syncthreads();
+    for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
+        float sb[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) {
+            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);     // 0 for NaN / below threshold
+            if (key != 0ull && key < hi_bound)
+                atomicAdd(&hist[(int)fminf(fmaxf(sb[u] * 2048.0f, 0.0f), 2047.0f)], 1u);
+        }
+    }
+    __syncthreads();
+    linear_hist_find(hist, want, ctl);
     __syncthreads();
     const int d = ctl[0], n = ctl[1];
-    __syncthreads();                        // (ctl is reused by the caller)
+    const int in_d = d > 0 ? (int)hist[d] : 0;
+    __syncthreads();                        // (ctl is reused below and by the caller)
     *bin_out = d;
     if (d == -1) { *thr_out = 0ull; *count = 0; return true; }
     if (d == -2) { *thr_out = 1ull; *count = n; *bin_out = -1; return true; }       // (bin 0 included: no histogram order)
-    if (d == 0 || n > cap) return false;
-    *thr_out = (unsigned long long)orderable((float)d * (1.0f / 2048.0f)) << 32;
-    *count = n;
+    if (d == 0) return false;
+    if (n <= cap) {
+        *thr_out = (unsigned long long)orderable((float)d * (1.0f / 2048.0f)) << 32;
+        *count = n;
+        return true;
+    }
+    // The crossing bin holds more than the band may take (scores bunched in a narrow range -- a head's sigmoid outputs at
+    // 61 440 anchors put hundreds of keys into one bin): one more pass refines INSIDE that bin with 2048 sub-bins,
+    // sub = floor((score * 2048 - d) * 2048) (exact: the difference of two floats in [d, d + 1) and a power-of-two scale),
+    // instead of handing the whole problem to the three-pass radix select.  Threshold score (2048 d + sub) / 2^22.
+    const int above = n - in_d;             // keys in the bins above d: all in the band
+    for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
+    __syncthreads();
+    const float fd = (float)d;
+    for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
+        float sb[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) {
+            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
+            const float scaled = sb[u] * 2048.0f;
+            if (key != 0ull && key < hi_bound && (int)fminf(fmaxf(scaled, 0.0f), 2047.0f) == d)
+                atomicAdd(&hist[(int)fminf(fmaxf((scaled - fd) * 2048.0f, 0.0f), 2047.0f)], 1u);
+        }
+    }
+    __syncthreads();
+    linear_hist_find(hist, want - above, ctl);
+    __syncthreads();
+    const int d2 = ctl[0], n2 = ctl[1];
+    __syncthreads();
+    *bin_out = -1;                          // (the band is not ordered from this histogram)
+    // (bin 2047 and its sub-bin 2047 also collect the scores >= 1 -- a saturated sigmoid: still exactly {score >= threshold})
+    if (d2 < 0 || above + n2 > cap) return false;
+    *thr_out = (unsigned long long)orderable((float)(d * 2048 + d2) * (1.0f / 4194304.0f)) << 32;
+    *count = above + n2;
     return true;
 }
 
@@ -432,16 +476,16 @@ nms_kernel(NmsArgs p)
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
         if (tid == 0) ctl[CTL_BANDN] = 0;
         __syncthreads();
-        for (int base = tid; base < N; base += 8 * kNmsThreads) {       // loads batched as in radix_select
-            unsigned long long kb[8];
+        for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {       // loads batched: kLoadBatch in flight per thread
+            float sb[kLoadBatch];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kLoadBatch; ++u) {
                 const int i = base + u * kNmsThreads;
-                kb[u] = i < N ? make_key(sc[(size_t)i * C], p.score_thr, i) : 0ull;
+                sb[u] = i < N ? sc[(size_t)i * C] : NAN;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned long long key = kb[u];
+            for (int u = 0; u < kLoadBatch; ++u) {
+                const unsigned long long key = make_key(sb[u], p.score_thr, base + u * kNmsThreads);      // 0 for NaN
                 const bool in = key >= thr && key < hi_bound && key != 0ull;
                 // one LDS atomic per wave: slots handed out by ballot rank (the band is sorted afterwards, so the order
                 // of the slots is irrelevant)
