@@ -440,14 +440,15 @@ nms_kernel(NmsArgs p)
         // the sort below is a 1024-key rank sort instead of a 4096-key bitonic network
         const int have = ctl[CTL_NSEL];
         const int want_left = max_sel - have;
-        // first band: twice the boxes wanted.  Later bands: sized from the yield of the band before (boxes selected per
+        // first band: three times the boxes wanted (ordering 900 keys costs what ordering 600 does; the chunks are only built
+        // as far as the walk gets).  Later bands: sized from the yield of the band before (boxes selected per
         // candidate visited; it falls as the selected set grows, hence the factor 2), so that a deep walk -- low IoU
         // threshold, clustered boxes -- takes 2 bands instead of 4; up to what the histogram ordering handles (2 keys
         // per thread).  A band that is too large costs little: its chunks are only built as far as the walk gets.
         const int by_yield = (int)min((long long)want_left * visited / max(have - have_before, 1) * 2, 1792ll);
-        const int band_target = visited == 0 ? min(kBandTarget, max(512, 2 * want_left)) : max(512, by_yield);
+        const int band_target = visited == 0 ? min(kBandTarget, max(512, 3 * want_left)) : max(512, by_yield);
         have_before = have;
-        const int band_cap = band_target <= 768 ? 1024 : kBandCap;
+        const int band_cap = band_target <= 960 ? 1024 : kBandCap;
         unsigned long long thr = 0ull;
         int lin_bin = -1;                    // >= 0: the band was chosen by the linear histogram (still in `hist`) at this bin
         if (!p.linear_select ||
