@@ -272,14 +272,16 @@ def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmu
     prop.wait()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # latency of ONE step end to end (images resident -> proposals resident, nothing overlapped across steps): HIP events
-    # around propose() on an idle device, median of `steps` repeats -- what configs quoted per image (c1, c5) mean by it
+    # latency of ONE step end to end (images resident -> proposals resident, nothing overlapped across steps, everything
+    # on one stream = Proposer(overlap_nms=False)): HIP events around propose() on an idle device, median of `steps`
+    # repeats -- what configs quoted per image (c1, c5) mean by it
+    prop.overlap_nms = False
     lat = []
     for _ in range(steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        prop.propose(imgs)                       # orders the current stream behind the NMS
+        prop.propose(imgs)
         e1.record()
         torch.cuda.synchronize()
         lat.append(e0.elapsed_time(e1))
