@@ -11,13 +11,16 @@ from oracle import bbox_oracle as bo
 from tf_rpn_amd import _lib as L
 KIND = sys.argv[1] if len(sys.argv) > 1 else "perm"
 THR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.7
-if KIND in ("model", "model_c5"):   # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
+if KIND in ("model", "model_c5", "model_c1"):   # the head outputs of the bench's model (random weights, U[0,1) images): what bench.py's step feeds it
     from tf_rpn_amd.models._rpn_model import synthetic_weights
     from tf_rpn_amd.predictor import Proposer
     from tf_rpn_amd.utils import train_utils
     if KIND == "model":
         bb, B, size = "vgg16", 8, 500
         hp = dict(train_utils.get_hyper_params("vgg16"))
+    elif KIND == "model_c1":         # configs[0]: MobileNetV2, 500 x 500, one image
+        bb, B, size = "mobilenet_v2", 1, 500
+        hp = dict(train_utils.get_hyper_params("mobilenet_v2"))
     else:                           # configs[4]: MobileNetV2, 1024 x 1024, 15 anchors per cell, one image
         bb, B, size = "mobilenet_v2", 1, 1024
         hp = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
