@@ -85,11 +85,39 @@ def spawn_ranks(n, cmd, env=None, timeout=None, poll=0.2):
         return rc, cap.read()
 
 
+def count_gpus_without_hip():
+    """Number of GPUs this process may use, without touching the HIP runtime: the KFD topology nodes that have SIMDs
+    (CPU nodes report simd_count 0), cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when
+    one of them is set.  None when the topology cannot be read."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    try:
+        for path in nodes:
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += 1 if int(line.split()[1]) > 0 else 0
+                        break
+    except (OSError, ValueError, IndexError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` (N > 1) without a launcher: start one process per GPU.  Nothing here initialises HIP:
-    torch.cuda.device_count() only counts devices."""
-    import torch
-    have = torch.cuda.device_count()
+    """`python bench.py --gpus N` (N > 1) without a launcher: start one process per GPU.  Nothing here may initialise HIP
+    (a process that has must not start GPU workers on this pool), so the devices are counted from the kernel driver's
+    topology in sysfs; only when that is unreadable does it fall back to torch.cuda.device_count()."""
+    have = count_gpus_without_hip()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
     if have < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but this machine exposes %d HIP device(s)\n" % (args.gpus, have))
         return 2
@@ -125,82 +153,186 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the configs[2] box-path leg (`c3`) and the exact-float32 leg (`exact_f32`) of the N = 1 line")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the whole CPU-baseline leg")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     return ap.parse_args()
 
 
+def _cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+_CONV_CHILD = """
+import sys, time, pickle
+import numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import conv_oracle as cv
+backbone, n_threads, batch, size = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+weights = pickle.load(open(sys.argv[5], "rb"))
+torch.set_num_threads(n_threads)
+img = np.random.RandomState(0).uniform(0, 1, size=(batch, size, size, 3)).astype(np.float32)
+t0 = time.perf_counter(); cv.rpn_forward(backbone, img, weights); dt = time.perf_counter() - t0
+print("CONV_SECONDS %%.6f" %% dt, flush=True)
+"""
+
+
 def cpu_baseline(backbone, hyper_params, weights, iou_threshold, target_seconds):
-    """CPU oracle ("port") on this box's host cores: whole path for one image at a time."""
+    """CPU oracle ("port": the TF2 reference cannot run here) on this box's host cores, as BASELINE.md section 3 lays it
+    out: the conv stack on torch-CPU float32 (oneDNN) at n = 1 thread and n = all cores this process may use, batch 1 and
+    batch 8; the box path as the numpy "eager-like" restatement and as the plain-C restatement, timed separately.  The
+    headline `value` is the whole path (conv stack + plain-C decode / NMS(300)) at the best thread count found, on a
+    bounded sample.  The whole leg is budgeted at ~`target_seconds` (default 15 s)."""
+    import pickle
+    import tempfile
+
     import numpy as np
     import torch
 
     from oracle import bbox_oracle as bo
     from oracle import c_oracle as co
     from oracle import conv_oracle as cv
+    t_leg = time.perf_counter()
     rng = np.random.RandomState(0)
     anchors = bo.generate_anchors(hyper_params)
     var = np.float32(hyper_params["variances"])
     size = hyper_params["img_size"]
+    A = len(anchors)
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    variants = []
 
-    def one_image():
-        img = rng.uniform(0, 1, size=(1, size, size, 3)).astype(np.float32)
-        reg, cls = cv.rpn_forward(backbone, img, weights)
-        boxes = co.decode(anchors, reg.reshape(1, -1, 4), var)
-        co.combined_nms(boxes[:, :, None, :], cls.reshape(1, -1, 1), 300, 300, iou_threshold=iou_threshold)
+    def conv_once(batch):
+        img = rng.uniform(0, 1, size=(batch, size, size, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        out = cv.rpn_forward(backbone, img, weights)
+        return time.perf_counter() - t0, out
 
-    # thread count: oneDNN collapses when oversubscribed (256 threads on the 2x64-core host: 12 s/image,
-    # 16 threads: 0.2 s/image), so time one image at a few counts and keep the fastest
+    # (a) conv stack, thread sweep at batch 1 (oneDNN collapses when oversubscribed -- 256 threads on the 2 x 64-core host:
+    # 12 s per image -- so wide counts run in a child process under a timeout instead of in this one)
     best = None
-    for n_threads in sorted({min(os.cpu_count() or 1, n) for n in (8, 16, 32, 64)}):
+    for n_threads in sorted({min(usable, n) for n in (16, 32)}):
         torch.set_num_threads(n_threads)
-        one_image()                                # warm-up (oneDNN primitive caches)
-        t1 = time.perf_counter()
-        one_image()
-        dt1 = time.perf_counter() - t1
-        if best is None or dt1 < best[1]:
-            best = (n_threads, dt1)
+        conv_once(1)                                   # warm-up (oneDNN primitive caches)
+        dt, _ = conv_once(1)
+        variants.append({"leg": "conv stack (torch-CPU f32)", "threads": n_threads, "batch": 1, "seconds": round(dt, 4),
+                         "images_per_s": round(1.0 / dt, 3)})
+        if best is None or dt < best[1]:
+            best = (n_threads, dt)
     cores = best[0]
     torch.set_num_threads(cores)
-    one_image()
+    dt8, (reg8, cls8) = conv_once(8)
+    variants.append({"leg": "conv stack (torch-CPU f32)", "threads": cores, "batch": 8, "seconds": round(dt8, 4),
+                     "images_per_s": round(8.0 / dt8, 3)})
+
+    def conv_child(n_threads, limit):
+        with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+            pickle.dump(weights, f)
+            f.flush()
+            try:
+                r = subprocess.run([sys.executable, "-c", _CONV_CHILD % ROOT, backbone, str(n_threads), "1", str(size), f.name],
+                                   capture_output=True, text=True, timeout=limit)
+                for line in r.stdout.splitlines():
+                    if line.startswith("CONV_SECONDS"):
+                        return float(line.split()[1])
+            except subprocess.TimeoutExpired:
+                return None
+        return None
+
+    for n_threads, label in ((1, "n = 1"), (usable, "n = all usable cores")):
+        if any(v["threads"] == n_threads and v["batch"] == 1 for v in variants):
+            continue
+        limit = 8.0
+        dt = conv_child(n_threads, limit)              # cold oneDNN caches: one image, no warm-up (stated)
+        variants.append({"leg": "conv stack (torch-CPU f32), child process, no warm-up", "threads": n_threads, "batch": 1,
+                         "seconds": None if dt is None else round(dt, 4),
+                         "images_per_s": None if dt is None else round(1.0 / dt, 3),
+                         "note": label + ("" if dt is not None else ": did not finish one image in %.0f s" % limit)})
+
+    # (b) box path on the conv stack's own outputs at batch 8: numpy "eager-like" restatement, then the plain-C one
+    reg = reg8.reshape(8, -1, 4)
+    cls = cls8.reshape(8, -1)
+    t0 = time.perf_counter()
+    boxes_np = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(reg[:1], var))
+    bo.combined_non_max_suppression(boxes_np[:, :, None, :], cls[:1, :, None], 300, 300, iou_threshold=iou_threshold)
+    dt_np = time.perf_counter() - t0
+    variants.append({"leg": "decode + NMS(300), numpy restatement (eager-like)", "threads": 1, "batch": 1,
+                     "seconds": round(dt_np, 4), "images_per_s": round(1.0 / dt_np, 3), "boxes_per_s": round(A / dt_np, 1)})
+    t0 = time.perf_counter()
+    boxes_c = co.decode(anchors, reg, var)
+    co.combined_nms(boxes_c[:, :, None, :], cls[:, :, None], 300, 300, iou_threshold=iou_threshold)
+    dt_c = time.perf_counter() - t0
+    variants.append({"leg": "decode + NMS(300), plain-C restatement", "threads": 1, "batch": 8, "seconds": round(dt_c, 4),
+                     "images_per_s": round(8.0 / dt_c, 3), "boxes_per_s": round(8.0 * A / dt_c, 1)})
+
+    # (c) headline: the whole path at the best thread count, in the better of the two batch shapes measured above
+    # (one image per call or 8), for what is left of the budget
+    nb = 8 if 8.0 / dt8 > 1.0 / best[1] else 1
+
+    def one_batch():
+        img = rng.uniform(0, 1, size=(nb, size, size, 3)).astype(np.float32)
+        r, c = cv.rpn_forward(backbone, img, weights)
+        bx = co.decode(anchors, r.reshape(nb, -1, 4), var)
+        co.combined_nms(bx[:, :, None, :], c.reshape(nb, -1, 1), 300, 300, iou_threshold=iou_threshold)
+
+    left = max(2.0, target_seconds - (time.perf_counter() - t_leg))
     t0 = time.perf_counter()
     n = 0
     while True:
-        one_image()
-        n += 1
+        one_batch()
+        n += nb
         dt = time.perf_counter() - t0
-        if dt >= target_seconds or n >= 64:
+        if dt >= left or n >= 64:
             break
-    model_name = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model_name = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
     return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images of the same workload, one at a time (torch-CPU f32 conv stack with %d threads + "
-                      "plain-C decode/NMS(300), single thread), %.1f s" % (n, cores, dt),
-            "cpu": model_name}
+            "sample": "%d images of the same workload, %d per call (torch-CPU f32 conv stack with %d threads + plain-C "
+                      "decode/NMS(300), single thread), %.1f s" % (n, nb, cores, dt),
+            "cpu": _cpu_model_name(), "logical_cpus": logical, "usable_cpus": usable,
+            "variants": variants, "leg_seconds": round(time.perf_counter() - t_leg, 1)}
 
 
-def measured_traffic(kernel, precision):
+def measured_traffic(kernel, precision, backbone, img_size, batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, written by scripts/make_traffic.py under the same kernel names as this file's
+    (profiles/*_traffic.json, written by scripts/collect_profiles.py under the same kernel names as this file's
     per-op table: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command) -- PMC
     counters cannot be collected from inside an un-profiled run, so the figure is read back from the newest committed
-    profile and labelled with its file name (`traffic_source`).  (None, None) when no profile matches."""
+    profile and labelled with its file name (`traffic_source`).  A profile only counts when its recorded `workload`
+    (backbone, img_size, per-GPU batch, precision) is THIS run's: a figure measured on another shape is not this
+    kernel's traffic.  (None, None) when no profile matches."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % precision)))
-    for path in reversed(paths):
+    want = {"backbone": backbone, "img_size": int(img_size), "batch": int(batch), "precision": precision}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             with open(path) as f:
-                return round(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+                prof = json.load(f)
+            if prof.get("workload") != want:
+                continue
+            return round(prof["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
+
+
+def c3_traffic():
+    """HBM bytes per launch of the configs[2] box kernels from the newest committed counter passes
+    (profiles/*_c3_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of scripts/bench_bbox.py, B = 64)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)["kernels"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
 
 
 def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=5, warmup=2):
@@ -236,7 +368,7 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=5, warmup
         d = tot.setdefault(op["kernel"], [0.0, 0.0, 0])
         d[0] += t
         d[1] += op["flops_per_image"] * B
-        d[2] += 1
+        d[2] += op["launches"]
     dom = max(tot, key=lambda k: tot[k][0])
     achieved = tot[dom][1] / (tot[dom][0] * 1e-3) / 1e12
     del prop
@@ -286,7 +418,7 @@ def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmu
         torch.cuda.synchronize()
         lat.append(e0.elapsed_time(e1))
     lat.sort()
-    n_launches = len(prop.rpn_model.ops())
+    n_launches = sum(op["launches"] for op in prop.rpn_model.ops())
     del prop, imgs
     torch.cuda.empty_cache()
     return {"workload": "%s: %s, %dx%d, %d anchors/cell, batch %d per GPU" % (label, backbone, hp["img_size"], hp["img_size"],
@@ -356,8 +488,15 @@ def c3_leg(hp, n=30):
                                                      0, L.stream_ptr()), "rpn_decode_nms"), max(5, n // 2))
         by = B * (20.0 * A + 7204.0)
         out["decode_nms_iou%.1f" % thr] = {"us": round(t * 1e6, 2), "boxes_per_sec": round(B * A / t, 1),
-                                           "GBps": round(by / t / 1e9, 2), "bytes": by,
+                                           "GBps": round(by / t / 1e9, 2), "frac": round(by / t / 8e12, 4), "bytes": by,
                                            "mean_valid": round(float(ov.float().mean().item()), 1)}
+    # measured HBM traffic per launch (committed counter passes of the same kernels at this shape, labelled with the file)
+    kernels, src = c3_traffic()
+    for key, pat in (("decode", "decode_kernel"), ("iou_map", "iou_map"), ("decode_nms_iou0.5", "nms_kernel<true>"),
+                     ("decode_nms_iou0.7", "nms_kernel<true>")):
+        hit = [v for k, v in kernels.items() if pat in k]
+        out[key]["traffic"] = hit[0]["hbm_bytes_per_launch"] if hit else None
+        out[key]["traffic_source"] = src if hit else None
     return out
 
 
@@ -514,6 +653,17 @@ def main():
     all_ms, _ = model.profile_ms()
     last_ms = [d if op["kernel"] == dom else a for op, d, a in zip(ops, dom_ms, all_ms)]
     model.set_profiling(0)
+    # the conv stack alone (images resident -> reg / cls written), per-op events OFF: two events around a whole forward
+    stack = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        prop.forward(imgs)
+        e1.record()
+        torch.cuda.synchronize()
+        stack.append(e0.elapsed_time(e1))
+    conv_stack_ms = sorted(stack)[len(stack) // 2]
     if overlap:                                   # time decode+NMS alone, after the region, for the report
         torch.cuda.synchronize()
         d_, s_ = prop._bufs[0]["reg"][:B].view(B, -1, 4), prop._bufs[0]["cls"][:B].view(B, -1)
@@ -545,7 +695,14 @@ def main():
         gather_ms = e0.elapsed_time(e1) / 10
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    per_rank = None
     if world > 1:
+        # every rank's own clock over the K steps and its own all-gather time, so that a scaling line explains itself
+        mine = torch.tensor([elapsed, gather_ms if gather_ms is not None else 0.0], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"images_per_s": [round(B * args.steps / float(v[0].item()), 2) for v in allr],
+                    "allgather_ms": [round(float(v[1].item()), 4) for v in allr]}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -558,20 +715,26 @@ def main():
             d = by_kernel.setdefault(op["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
             d["ms"] += ms
             d["flops"] += op["flops_per_image"] * B
-            d["launches"] += 1
+            d["launches"] += op["launches"]
         d = by_kernel[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         # the peak of the arithmetic the DOMINANT KERNEL runs in: split-precision 3x3 kernels -> 16-bit MFMA / 3 products;
         # everything else (float32 implicit GEMM, the fused MobileNetV2 blocks) -> the float32 MFMA
-        peak = PEAK_TFLOPS[args.precision] if "split" in dom else PEAK_TFLOPS["f32"]
-        traffic, traffic_source = measured_traffic(dom, args.precision)
+        dom_arith = next(op["arith"] for op in ops if op["kernel"] == dom)
+        peak = PEAK_TFLOPS[dom_arith]
+        traffic, traffic_source = measured_traffic(dom, args.precision, args.backbone, hp["img_size"], B)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flops_per_launch": d["flops"] / d["launches"],
                     "timing": ("HIP events on the launch stream around this kernel's launches in the K timed steps"
                                + (": one launch per step, round robin (every launch sampled >= 2 times)" if rotate else "")),
-                    "conv_stack_ms": round(sum(last_ms), 3), "decode_nms_ms": round(nms_ms, 4)}
+                    "arith": dom_arith,
+                    "conv_stack_ms": round(conv_stack_ms, 4),
+                    "conv_stack_ms_note": "HIP events around whole forwards, per-op events off (median of 5)",
+                    "sum_of_op_ms_with_per_op_events": round(sum(last_ms), 3),
+                    "conv_launches_per_step": sum(op["launches"] for op in ops),
+                    "decode_nms_ms": round(nms_ms, 4)}
         out = {
             "metric": "proposal images/sec at 500x500x3 VOC batch; NMS boxes/sec",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -594,6 +757,7 @@ def main():
                                       if overlap else "serial on the conv stream"},
             "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "per_rank": per_rank,
             "roofline": roofline,
         }
         if world == 1 and not args.no_extra_legs:
@@ -622,6 +786,8 @@ def main():
             out["nms_boxes_per_sec_note"] = "this run's own decode+NMS at its per-GPU batch (%d images)" % B
         if args.layers:
             for op, ms in zip(ops, last_ms):
+                if not op["launches"]:              # a pool that runs inside the previous conv's epilogue: no launch
+                    continue
                 tf = op["flops_per_image"] * B / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 gbs = op["bytes_per_image"] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 print("%-28s %-34s %8.3f ms %8.2f TF/s %9.1f GB/s" % (op["name"], op["kernel"], ms, tf, gbs),

@@ -17,6 +17,27 @@
  *     returns a thread-local human-readable message for the last failure.
  *   - there is NO CPU fallback: without a HIP device every compute call fails with
  *     RPN_ERR_NO_DEVICE.
+ *
+ * Environment knobs of the library (read once per process).  These are ALL the names the
+ * shipped library reads (tests/test_host.py compares this list with the binary's strings);
+ * every setting computes the same arithmetic contract -- integer / index outputs bit-exact,
+ * floats within the documented bound -- they select between implementations:
+ *   RPN_KNOB RPN_B1_FUSE     (1)  VGG16 block 1 as one launch under f16x3; 0: two kernels
+ *   RPN_KNOB RPN_HEAD_SPLITK (1)  rpn_reg | rpn_cls on the split-K head kernel; 0: generic f32 implicit GEMM
+ *   RPN_KNOB RPN_KSPLIT      (0)  1: rpn_conv split along K at small batches (lower latency; a batch-1 result is
+ *                                 then no longer bit-identical to the same image inside a larger batch)
+ *   RPN_KNOB RPN_S16_DYN     (0)  1: dynamic tile queue in the persistent split-precision conv kernel
+ *   RPN_KNOB RPN_S16_C64     (0)  1: block1_conv2 on the persistent kernel's 64-wide tiles
+ *   RPN_KNOB RPN_NMS_LINEAR  (1)  NMS band selection from the linear score histogram; 0: radix select +
+ *                                 bitonic sort only; 2: histogram select, sorted the old way
+ *   RPN_KNOB RPN_NMS_CLUSTER (0 = automatic)  workgroups per (image, class) that share the NMS band selection
+ *                                 when few images have many anchors; 1: always one workgroup
+ *   RPN_KNOB RPN_MN_FUSE     (1)  MobileNetV2: one launch per inverted-residual block; 0: layer by layer
+ *   RPN_KNOB RPN_MN_X3       (1)  MobileNetV2 under f16x3: 16-bit MFMA GEMMs inside the fused blocks; 0: f32 MFMA
+ * Kernel / tile selection switches for A/B timing and the timing experiments whose results are
+ * wrong on purpose (RPN_NMS_STOP, RPN_IOU_EXP, RPN_SPLIT_*, RPN_IOU_*, ...) exist only in a
+ * laboratory build (`make -C tf_rpn_amd/csrc lab` -> librpn_hip_lab.so, -DRPN_LAB); the product
+ * library does not contain their names.
  */
 #ifndef RPN_HIP_H
 #define RPN_HIP_H
@@ -196,6 +217,11 @@ int rpn_model_set_profiling_mask(rpn_model *m, const unsigned char *mask, int n)
 /* with a mask: time ONE marked op per forward, round robin (2 events per forward); rpn_model_get_profile then averages
    each op over the forwards in which it was the one timed */
 int rpn_model_set_profiling_rotate(rpn_model *m, int on);
+/* arithmetic of op i's matrix work: an rpn_precision value (RPN_PRECISION_F32 for the float32-MFMA / vector-ALU kernels,
+ * the model's split precision for the kernels that form each product from three 16-bit MFMAs); -1 for a bad index.
+ * A 2x2 max-pool that runs inside the previous conv's epilogue is reported by rpn_model_op_info with the kernel name
+ * "fused:maxpool_split" and zero bytes: it is not a launch. */
+int rpn_model_op_arith(const rpn_model *m, int i);
 int rpn_model_num_ops(const rpn_model *m);
 int rpn_model_op_info(const rpn_model *m, int i, char *name, int name_len, char *kernel, int kernel_len,
                       double *flops_per_image, double *bytes_per_image);

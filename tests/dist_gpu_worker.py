@@ -1,0 +1,71 @@
+"""Child process of tests/test_gpu_distributed.py: one rank of a world-size-2 run of the image-sharded proposal path on
+ONE GPU.  Each rank runs the HIP path on its `shard_bounds` slice; the records are exchanged under the gloo backend,
+staged through host memory HERE ONLY (the product calls torch.distributed.all_gather_into_tensor on device tensors, which
+is RCCL on a real multi-GPU node; this machine has one GPU, and RCCL does not run two ranks on one device).
+
+argv: total out_dir      env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
+Writes out_dir/rank<r>.npz with the gathered records of the three code paths; exit code 0 when it ran to the end.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from tf_rpn_amd.models._rpn_model import synthetic_weights
+from tf_rpn_amd.predictor import Proposer, compact_gathered, shard_bounds
+from tf_rpn_amd.utils import train_utils
+
+
+def main():
+    total, out_dir = int(sys.argv[1]), sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real_all_gather = dist.all_gather_into_tensor
+
+    def staged_all_gather(out, inp, *a, **k):       # device -> host -> gloo -> host -> device (the test's stand-in for RCCL)
+        torch.cuda.current_stream().synchronize()
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        real_all_gather(host_out, inp.detach().cpu().contiguous(), *a, **k)
+        out.copy_(host_out.to(out.device))
+
+    dist.all_gather_into_tensor = staged_all_gather
+    try:
+        torch.cuda.set_device(0)
+        hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+        weights = synthetic_weights("vgg16", hp, seed=5)
+        imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11))     # same on every rank
+        lo, hi = shard_bounds(total, world, rank)
+        local = imgs[lo:hi].cuda().contiguous()
+        rows = -(-total // world)
+        res = {}
+        # (1) the serial distributed step with uneven shards: propose_distributed(total=...)
+        prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7)
+        res["serial"] = prop.propose_distributed(local, total=total).cpu().numpy()
+        # (2) the same with a caller-provided gather buffer
+        gbuf = torch.full((world * rows, prop.topn * 5 + 1), 7.0, device="cuda")
+        res["serial_buf"] = prop.propose_distributed(local, gather_out=gbuf, total=total).cpu().numpy()
+        # (3) the pipelined step (NMS + packing + gather on the side stream), rows > B on the short rank: two steps + flush
+        prop2 = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7,
+                         overlap_nms=True)
+        gather_bufs = [torch.full((world * rows, prop2.topn * 5 + 1), 9.0, device="cuda") for _ in range(2)]
+        first = prop2.propose_distributed_pipelined(local, gather_bufs)
+        assert first is None
+        second = prop2.propose_distributed_pipelined(local, gather_bufs)
+        res["pipe_step1"] = compact_gathered(second, total, world).cpu().numpy()
+        last = prop2.flush_distributed(gather_bufs)
+        res["pipe_step2"] = compact_gathered(last, total, world).cpu().numpy()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+        dist.barrier()
+    finally:
+        dist.all_gather_into_tensor = real_all_gather
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

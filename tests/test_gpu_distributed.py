@@ -1,0 +1,43 @@
+"""GPU suite: the N > 1 path with world_size 2 on ONE MI355X.
+
+Two fresh child processes (tests/dist_gpu_worker.py) each run the HIP path on their `shard_bounds` slice of `total`
+images and exchange the proposal records (gloo, staged through host memory in the worker only: one GPU cannot host two
+RCCL ranks).  The compacted gather must equal the single-process proposals of all `total` images BIT FOR BIT -- this runs
+`Proposer.propose_distributed(total=...)`, its uneven-shard padding and the pipelined path's `rows > B` branch with
+world > 1, which the CPU suite can only exercise with synthetic records."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tf_rpn_amd.models._rpn_model import synthetic_weights
+from tf_rpn_amd.predictor import Proposer
+from tf_rpn_amd.utils import train_utils
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("total", [7, 8])
+def test_two_ranks_on_one_gpu_match_single_process(total, tmp_path):
+    sys.path.insert(0, ROOT)
+    from bench import spawn_ranks
+    rc, _out = spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(total), str(tmp_path)],
+                           timeout=600)
+    assert rc == 0
+    # single process, all images in one batch (the default path is bit-identical across batch sizes)
+    hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("vgg16", hp, seed=5)
+    imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11)).cuda()
+    prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=total, iou_threshold=0.7)
+    boxes, scores, valid, _ = prop.propose(imgs)
+    want = prop.pack_records(boxes, scores, valid).cpu().numpy()
+    assert want.shape == (total, prop.topn * 5 + 1) and (valid > 0).all()
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        for key in ("serial", "serial_buf", "pipe_step1", "pipe_step2"):
+            assert got[key].shape == want.shape, (rank, key, got[key].shape)
+            assert np.array_equal(got[key].view(np.uint32), want.view(np.uint32)), (rank, key)

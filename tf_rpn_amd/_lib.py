@@ -64,6 +64,7 @@ _SIGNATURES = {
     "rpn_model_set_profiling_mask": (ctypes.c_int, [vp, vp, ctypes.c_int]),
     "rpn_model_set_profiling_rotate": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_model_num_ops": (ctypes.c_int, [vp]),
+    "rpn_model_op_arith": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_model_op_info": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "rpn_model_get_profile": (ctypes.c_int, [vp, c_float_p, ctypes.c_int, c_int_p]),

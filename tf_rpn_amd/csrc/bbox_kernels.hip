@@ -558,7 +558,7 @@ extern "C" int rpn_encode(const float *d_bboxes, int bboxes_batched, const float
 
 static bool nt_rows()
 {
-    static const int nt = getenv("RPN_IOU_NT") ? atoi(getenv("RPN_IOU_NT")) : 1;
+    static const int nt = RPN_LAB_KNOB("RPN_IOU_NT", 1);
     return nt != 0;
 }
 
@@ -572,9 +572,9 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     RPN_REQUIRE_DEVICE();
     RPN_REQUIRE((long long)A * G < (1ll << 31) && B <= 65535, "rpn_iou_map: A*G or B too large");
     const int per_img = A * G;
-    static const int chunked = getenv("RPN_IOU_CHUNKED") ? atoi(getenv("RPN_IOU_CHUNKED")) : 1;
-    static const int nt = getenv("RPN_IOU_NT") ? atoi(getenv("RPN_IOU_NT")) : 1;
-    static const int rowsk = getenv("RPN_IOU_ROWS") ? atoi(getenv("RPN_IOU_ROWS")) : 1;
+    static const int chunked = RPN_LAB_KNOB("RPN_IOU_CHUNKED", 1);
+    static const int nt = RPN_LAB_KNOB("RPN_IOU_NT", 1);
+    static const int rowsk = RPN_LAB_KNOB("RPN_IOU_ROWS", 1);
     const int g32 = (G % 4 == 0) ? 4 : (G % 2 == 0 ? 2 : 1);          // >= gcd(G, 32) capped at 4
     const size_t wave_lds = (size_t)iou_rows_wave_floats(G) * sizeof(float);
     if (rowsk && G >= 1 && g32 <= 2 && wave_lds <= 12 * 1024 && A >= 64) {
@@ -583,9 +583,9 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
         const int tiles_per_img = (A + 63) / 64;
         const long long n_tiles = (long long)tiles_per_img * B;
         RPN_REQUIRE(n_tiles <= 0x7fffffffll, "rpn_iou_map: too many tiles");
-        static const int persist = getenv("RPN_IOU_PERSIST") ? atoi(getenv("RPN_IOU_PERSIST")) : 0;
-        static const int fast = getenv("RPN_IOU_FAST") ? atoi(getenv("RPN_IOU_FAST")) : 1;
-        static const int wv = getenv("RPN_IOU_WAVES") ? atoi(getenv("RPN_IOU_WAVES")) : 4;     // waves per workgroup: 4 | 2
+        static const int persist = RPN_LAB_KNOB("RPN_IOU_PERSIST", 0);
+        static const int fast = RPN_LAB_KNOB("RPN_IOU_FAST", 1);
+        static const int wv = RPN_LAB_KNOB("RPN_IOU_WAVES", 4);     // waves per workgroup: 4 | 2
         const int W = wv == 2 ? 2 : 4;
         long long wgs = (n_tiles + W - 1) / W;
         if (persist) {
@@ -609,11 +609,14 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
         const long long chunks = (total + kIouChunk - 1) / kIouChunk;
         RPN_REQUIRE(chunks <= 0x7fffffffll, "rpn_iou_map: too many chunks");
         const size_t lds = (size_t)G * 40;
-        static const int iexp = getenv("RPN_IOU_EXP") ? atoi(getenv("RPN_IOU_EXP")) : 0;
+#ifdef RPN_LAB      /* timing experiment: the map then holds coordinates, not IoUs */
+        static const int iexp = RPN_LAB_KNOB("RPN_IOU_EXP", 0);
         if (iexp == 2)
             hipLaunchKernelGGL((iou_map_chunk_kernel<true, 2>), dim3((unsigned)chunks), dim3(kThreads), lds, as_stream(stream),
                                d_bboxes, bboxes_batched, A, d_gt, G, B, total, d_iou);
-        else if (nt)
+        else
+#endif
+        if (nt)
             hipLaunchKernelGGL(iou_map_chunk_kernel<true>, dim3((unsigned)chunks), dim3(kThreads), lds, as_stream(stream),
                                d_bboxes, bboxes_batched, A, d_gt, G, B, total, d_iou);
         else

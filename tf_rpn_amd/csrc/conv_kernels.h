@@ -4,6 +4,8 @@
 
 #include <cstddef>
 
+#include "rpn_knobs.h"
+
 namespace rpn {
 
 enum Act { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_RELU6 = 3 };

@@ -402,7 +402,7 @@ int conv_f32_tile_n(int B, int OH, int OW, int Cout)
         return n;
     }();
     const long long m_tiles = (long long)((OW + TW - 1) / TW) * ((OH + TH - 1) / TH) * B;
-    static const int occ = getenv("RPN_F32_OCC") ? atoi(getenv("RPN_F32_OCC")) : 2;     // workgroups per CU wanted
+    static const int occ = RPN_LAB_KNOB("RPN_F32_OCC", 2);     // workgroups per CU wanted
     int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     while (bn > 32 && m_tiles * ((Cout + bn - 1) / bn) < (long long)occ * n_cus) bn >>= 1;
     return bn;

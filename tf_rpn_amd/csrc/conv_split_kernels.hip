@@ -1875,20 +1875,15 @@ static hipError_t launch_split_variant(const SplitConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// experiment knobs (speed only, never results): RPN_SPLIT_TILE = 82 | 81 | 42 | 41 forces a tile shape,
+// laboratory knobs (-DRPN_LAB builds only; speed only, never results): RPN_SPLIT_TILE = 82 | 81 | 42 | 41 forces a tile shape,
 // RPN_SPLIT_BBUF = 1 | 2 the number of weight buffers
-static int env_int(const char *name)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : 0;
-}
 
 template <bool F16, bool POOL>
 static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
 {
     // tile choice: 64-wide N tiles for Cout <= 64; shorter / narrower tiles when the grid would not put
     // two workgroups on each of the 256 CUs
-    static const int force_tile = env_int("RPN_SPLIT_TILE"), force_bbuf = env_int("RPN_SPLIT_BBUF");
+    static const int force_tile = RPN_LAB_KNOB("RPN_SPLIT_TILE", 0), force_bbuf = RPN_LAB_KNOB("RPN_SPLIT_BBUF", 0);
     const long long mt8 = (long long)((a.W + 31) / 32) * ((a.H + 7) / 8) * a.B;
     const long long mt4 = (long long)((a.W + 31) / 32) * ((a.H + 3) / 4) * a.B;
     const int nt128 = (a.Cout + 127) / 128;
@@ -1902,11 +1897,11 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
     int bbuf = (tile == 82) ? 1 : 2;
     if (force_bbuf) bbuf = force_bbuf;
     if (tile == 82 && bbuf == 2) bbuf = 1;                   // 92 KB: one workgroup per CU, not offered
-    static const int force_waves = env_int("RPN_SPLIT_WAVES");        // 8: 512-thread workgroups on the 8x32 x 128 tile
+    static const int force_waves = RPN_LAB_KNOB("RPN_SPLIT_WAVES", 0);        // 8: 512-thread workgroups on the 8x32 x 128 tile
     if (tile == 82 && force_waves == 8) return launch_split_variant<8, 2, 1, F16, POOL, 8>(a, s);
     // experiment (RPN_SPLIT_SMALL=2): 128 px x 128 ch tiles shared by 8 waves for small feature maps.  Measured on
     // 31x31x512, batch 8: 0.137 ms vs 0.126 ms for the default 4-wave 128 x 64 tiles, so it stays off.
-    static const int small_mode = env_int("RPN_SPLIT_SMALL");
+    static const int small_mode = RPN_LAB_KNOB("RPN_SPLIT_SMALL", 0);
     if constexpr (!POOL) {
         if (tile == 41 && small_mode == 2 && mt4 * nt128 >= 256) return launch_split_variant<4, 2, 2, F16, false, 8>(a, s);
     }
@@ -1933,7 +1928,7 @@ static hipError_t launch_split_tiles(const SplitConvArgs &a, hipStream_t s)
 // layer (block1_conv2 on this kernel beside the overlapped NMS: 2800 vs 2737 images/s with the static schedule).
 static unsigned *sched_counters(hipStream_t s)
 {
-    static const int dyn = getenv("RPN_S16_DYN") ? atoi(getenv("RPN_S16_DYN")) : 0;
+    static const int dyn = RPN_KNOB("RPN_S16_DYN", 0);
     if (!dyn) return nullptr;
     static std::mutex mu;
     static std::unordered_map<hipStream_t, unsigned *> pool;
@@ -1954,7 +1949,7 @@ static unsigned *sched_counters(hipStream_t s)
 const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int cout_pad, bool pool)
 {
     if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || cout_pad < Cout) return nullptr;
-    static const int dma_mode = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+    static const int dma_mode = RPN_LAB_KNOB("RPN_S16_DMA", 1);
     const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
     const bool dma_ok = dma_mode && Cin % 64 == 0 && (long long)B * H * W * Cin * 4 < 0x7fffffffll &&
                         (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
@@ -2044,7 +2039,7 @@ int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)
     // Off by default: the partial sums are added in a different order than the one-chain accumulation, so a batch-1 result
     // would no longer be bit-identical to the same image inside a larger batch (tests/test_gpu_configs.py holds the
     // path to that).  RPN_KSPLIT=1 is the latency option: MobileNetV2 500 x 500, one image: 0.326 -> 0.292 ms.
-    static const int on = getenv("RPN_KSPLIT") ? atoi(getenv("RPN_KSPLIT")) : 0;
+    static const int on = RPN_KNOB("RPN_KSPLIT", 0);
     const char *v = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, false);
     if (!on || !v || strcmp(v, "reg,64") != 0) return 1;
     const long long blocks = (long long)((W + 31) / 32) * ((H + 3) / 4) * B * ((Cout + 63) / 64);

@@ -1121,7 +1121,7 @@ ir_block_x3_kernel(IrX3Args a)
 bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
     if (stride != 1 || cexp != 6 * cin) return false;
-    static const int b45 = getenv("RPN_MN_X3_B45") ? atoi(getenv("RPN_MN_X3_B45")) : 1;     // blocks 4, 5 (32 -> 192 -> 32)
+    static const int b45 = RPN_LAB_KNOB("RPN_MN_X3_B45", 1);     // blocks 4, 5 (32 -> 192 -> 32)
     return (cin == 64 && cout == 64 && residual) || (cin == 64 && cout == 96 && !residual) ||
            (cin == 96 && cout == 96 && residual) || (b45 && cin == 32 && cout == 32 && residual);
 }
@@ -1179,11 +1179,13 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
     a.tiles_y = (H + IR_TH - 1) / IR_TH;
     const long long nblocks = (long long)a.tiles_x * a.tiles_y * B;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+#ifdef RPN_STAMP
     {
         const char *sel = getenv("RPN_IR_STAMP_OP");
         int sc = -1, ss = -1;
         a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == 1 && (cin != 64 || cout == 64);
     }
+#endif
     if (cin == 32) hipLaunchKernelGGL((ir_block_x3_kernel<32, 192, 32, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
     else if (cin == 64 && cout == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 64, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
     else if (cin == 64) hipLaunchKernelGGL((ir_block_x3_kernel<64, 384, 96, false>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
@@ -1194,7 +1196,7 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
 // RPN_MN_HR=0: blocks 1-3 on the two-group pipeline kernel instead of ir_block_hr_kernel
 static int ir_hr_mode()
 {
-    static const int on = getenv("RPN_MN_HR") ? atoi(getenv("RPN_MN_HR")) : 1;
+    static const int on = RPN_LAB_KNOB("RPN_MN_HR", 1);
     return on;
 }
 
@@ -1226,17 +1228,19 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
     a.tiles_y = (OH + IR_TH - 1) / IR_TH;
     const long long nblocks = (long long)a.tiles_x * a.tiles_y * B;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+#ifdef RPN_STAMP
     {   // RPN_IR_STAMP_OP="cin,stride" selects the block that records stamps in a -DRPN_STAMP build ("3,1": the stem)
         const char *sel = getenv("RPN_IR_STAMP_OP");
         int sc = -1, ss = -1;
         a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == stride && (cin != 64 || cout == 64);
     }
+#endif
 #define RPN_IR(KP_, CEXP_, CE_, COUT_, S_, RES_, STEM_)                                                              \
     hipLaunchKernelGGL((ir_block_kernel<KP_, CEXP_, CE_, COUT_, S_, RES_, STEM_>), dim3((unsigned)nblocks),          \
                        dim3(IR_THREADS), 0, s, a)
     if (stem) {
         if (!(cin == 3 && cexp == 32 && cout == 16 && stride == 1 && !residual)) return hipErrorInvalidValue;
-        static const int stem8 = getenv("RPN_MN_STEM8") ? atoi(getenv("RPN_MN_STEM8")) : 1;     // 0: the 4 x 8 tile pipeline
+        static const int stem8 = RPN_LAB_KNOB("RPN_MN_STEM8", 1);     // 0: the 4 x 8 tile pipeline
         if (stem8) {
             const int th = stem8 == 4 ? 4 : 8;      // (4 x 16 tiles, six workgroups per CU: no faster at batch 8, slower at 1024 x 1024)
             a.tiles_x = (OW + ST_TW - 1) / ST_TW;

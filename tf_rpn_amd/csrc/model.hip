@@ -106,16 +106,16 @@ namespace rpn {
 // the other Cin >= 128 layers with 128-wide output tiles.  RPN_SPLIT_MFMA16=0 switches them off (32x32x16 kernels).
 static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
 {
-    static const int mode = getenv("RPN_SPLIT_MFMA16") ? atoi(getenv("RPN_SPLIT_MFMA16")) : 1;
-    static const int dma = getenv("RPN_S16_DMA") ? atoi(getenv("RPN_S16_DMA")) : 1;
+    static const int mode = RPN_LAB_KNOB("RPN_SPLIT_MFMA16", 1);
+    static const int dma = RPN_LAB_KNOB("RPN_S16_DMA", 1);
     (void)H; (void)W; (void)B;
     if (mode == 0 || Cin % 32 != 0) return false;
     // block1_conv2 (64 -> 64, fused pool) stays on the 32x32x16 kernel: alone, the 64-wide persistent tiles are faster
     // (0.34 vs 0.37 ms), but this is the layer the overlapped NMS of the previous step runs beside, and a persistent
     // workgroup that has to share its CU delays a fixed share of the tiles (2737 vs 2814 images/s).  RPN_S16_C64=1
     // (with RPN_S16_DYN=1, the dynamic tile schedule) moves it over: 2800 images/s.
-    static const int c64 = getenv("RPN_S16_C64") ? atoi(getenv("RPN_S16_C64")) : 0;
-    if (Cout <= 64 && !(c64 && dma && Cin % 64 == 0)) return false;
+    static const int c64 = RPN_KNOB("RPN_S16_C64", 0);
+    if (Cout <= 64 && !(c64 != 0 && dma != 0 && Cin % 64 == 0)) return false;
     if (dma && Cin % 64 == 0) return true;
     return Cin >= 128;
 }
@@ -123,7 +123,7 @@ static bool use_mfma16(int Cin, int Cout, int H, int W, int B)
 // RPN_HEAD_SPLITK=0: the head through the generic float32 implicit GEMM (one 128 x 32 tile walking K in 32 steps)
 static bool head_splitk()
 {
-    static const int on = getenv("RPN_HEAD_SPLITK") ? atoi(getenv("RPN_HEAD_SPLITK")) : 1;
+    static const int on = RPN_KNOB("RPN_HEAD_SPLITK", 1);
     return on != 0;
 }
 
@@ -179,7 +179,7 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     // f16x3 only: with bfloat16 halves the first layer's 2^-16 product error, carried through 40 MobileNetV2 layers,
     // measured 1.25e-4 on the objectness (bound 1e-4); with float16 halves it is indistinguishable from exact f32
     op.cin3_mfma = op.cin3 && m->use_split && m->f16 && (Cout == 32 || Cout == 64) &&
-                   !(getenv("RPN_CIN3_MFMA") && atoi(getenv("RPN_CIN3_MFMA")) == 0);
+                   (RPN_LAB_KNOB("RPN_CIN3_MFMA", 1) != 0);
     op.out_f32 = split && force_f32_out;
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
@@ -277,7 +277,7 @@ static void build_vgg16(rpn_model *m)
     int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
     const int cfg[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
     const bool fuse_b1 = m->use_split && m->f16 && !m->keep_all &&
-                         !(getenv("RPN_B1_FUSE") && atoi(getenv("RPN_B1_FUSE")) == 0);
+                         (RPN_KNOB("RPN_B1_FUSE", 1) != 0);
     if (fuse_b1) t = add_vgg_block1(m, t);
     for (int blk = fuse_b1 ? 1 : 0; blk < 5; ++blk) {
         for (int c = 0; c < cfg[blk][0]; ++c) {
@@ -310,7 +310,7 @@ static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, 
     op.R = op.S = 3;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = ACT_LINEAR;
     op.ir_x3 = m->f16 && !stem && ir_block_x3_supported(ti.C, cexp, cout, stride, res) &&
-               !(getenv("RPN_MN_X3") && atoi(getenv("RPN_MN_X3")) == 0);
+               (RPN_KNOB("RPN_MN_X3", 1) != 0);
     op.out = add_tensor(m, name, OH, OW, cout);
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
@@ -337,7 +337,7 @@ static void build_mobilenet_v2(rpn_model *m)
     int t = add_tensor(m, "input", m->img_size, m->img_size, 3, true);
     // One launch per inverted-residual block unless every intermediate activation must exist (keep_all) or
     // RPN_MN_FUSE=0 (the unfused layer-by-layer path: the cross-check of the fused kernels in the tests).
-    const bool fuse = !m->keep_all && !(getenv("RPN_MN_FUSE") && atoi(getenv("RPN_MN_FUSE")) == 0);
+    const bool fuse = !m->keep_all && (RPN_KNOB("RPN_MN_FUSE", 1) != 0);
     const int blocks[13][4] = {{32, 1, 16, 1}, {16, 6, 24, 2}, {24, 6, 24, 1}, {24, 6, 32, 2}, {32, 6, 32, 1},
                                {32, 6, 32, 1}, {32, 6, 64, 2}, {64, 6, 64, 1}, {64, 6, 64, 1}, {64, 6, 64, 1},
                                {64, 6, 96, 1}, {96, 6, 96, 1}, {96, 6, 96, 1}};
@@ -985,9 +985,15 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     double fl = 0.0, by = 0.0;
     const char *k = "maxpool2x2";
     const double in_b = 4.0 * op.H * op.W * op.Cin, out_b = 4.0 * op.OH * op.OW * op.Cout;
+    // a 2x2 max-pool that runs inside the epilogue of the split conv in front of it (rpn_model_forward: fuse_pool) is not a
+    // launch: no kernel, no bytes of its own (the conv's row carries the pooled output)
+    const bool pool_fused_away = op.kind == OP_POOL && op.split && !m->keep_all && i > 0 && m->ops[i - 1].kind == OP_CONV &&
+                                 m->ops[i - 1].split && !m->ops[i - 1].out_f32 && !m->ops[i - 1].cin3 && op.in == m->ops[i - 1].out;
     if (op.kind == OP_TOSPLIT) {
         by = in_b + out_b;
         k = "f32_to_split";
+    } else if (pool_fused_away) {
+        k = "fused:maxpool_split";
     } else if (op.kind == OP_POOL && op.split) {
         by = in_b + out_b;
         k = "maxpool_split";
@@ -1047,6 +1053,16 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     if (flops_per_image) *flops_per_image = fl;
     if (bytes_per_image) *bytes_per_image = by;
     return RPN_OK;
+}
+
+// arithmetic the op's matrix work runs in: RPN_PRECISION_F32 (float32 MFMA / vector ALU) or the model's split precision
+// (three 16-bit MFMAs per product) -- what a roofline report must price the op's flops against
+extern "C" int rpn_model_op_arith(const rpn_model *m, int i)
+{
+    if (!m || i < 0 || i >= (int)m->ops.size()) return -1;
+    const Op &op = m->ops[i];
+    const bool x3 = (op.kind == OP_CONV && (op.split || op.cin3_mfma)) || op.kind == OP_VGGB1 || (op.kind == OP_IRBLOCK && op.ir_x3);
+    return x3 ? (m->f16 ? RPN_PRECISION_F16X3 : RPN_PRECISION_BF16X3) : RPN_PRECISION_F32;
 }
 
 // mean elapsed milliseconds of every op over the kept forwards (synchronises on their last events);

@@ -31,8 +31,21 @@
 #include "rpn_common.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace rpn {
+
+// The thread index as a value the optimiser cannot see through.  Every phase of the NMS kernel maps threads to work in its
+// own way (tid / 16, cslot(tid), 2047 - 2 tid, ...); with the plain threadIdx.x all of those are loop-invariant, get
+// hoisted to the top of the kernel and stay live across the band loop: 46 spilled VGPRs = 180 B of scratch per thread,
+// 11.8 MB written per launch at 64 images (round-2 profile).  Taken fresh at the head of a phase, the derived values
+// die with the phase: no scratch at the same 128-VGPR budget.
+__device__ __forceinline__ int fresh_tid()
+{
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 
 constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
@@ -70,7 +83,9 @@ struct NmsArgs {
     // per-class staging (C > 1): sel index (B,C,max_sel) and count (B,C)
     int *stage_idx;
     int *stage_cnt;
+#ifdef RPN_LAB
     int stop_after;          // timing experiments only (RPN_NMS_STOP): 2 = stop after the first band sort; 0 = run all
+#endif
     int linear_select;       // band threshold by the one-pass linear histogram first (RPN_NMS_LINEAR=0: radix select only)
 };
 
@@ -163,7 +178,7 @@ __device__ __forceinline__ unsigned long long make_key(float s, float thr, int i
 __device__ __forceinline__ void linear_hist_find(const unsigned *hist, int want, int *ctl)
 {
     constexpr int NB = 2048;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = fresh_tid(), lane = tid & 63;
     if (tid < 64) {
         constexpr int per = NB / 64;
         const int top = NB - 1 - lane * per;
@@ -201,7 +216,7 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
                                           unsigned long long *thr_out, int *count, int *bin_out)
 {
     constexpr int NB = 2048;
-    const int tid = threadIdx.x;
+    const int tid = fresh_tid();
     for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
     __syncthreads();
     for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
@@ -280,7 +295,7 @@ __device__ inline bool band_order_linear(const float *__restrict__ sc, int C, in
                                          unsigned long long hi_bound, int d, int n, unsigned *hist, unsigned long long *band,
                                          unsigned *order, unsigned long long *low_out)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = fresh_tid(), lane = tid & 63, wave = tid >> 6;
     unsigned *boff = hist + 2048, *cur = hist + 4096, *scratch = hist + 6144;
     // suffix scan from the top bin: thread t owns bins 2047 - 2t and 2046 - 2t
     const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
@@ -377,6 +392,12 @@ enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by 
 
 // Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the
 // first 64 workgroups, in program order (slot 0 = start; the probe knows the sequence).
+// Laboratory build only (-DRPN_LAB, RPN_NMS_STOP=n): leave the kernel after phase n (outputs are then not written).
+#ifdef RPN_LAB
+#define NMS_STOP_AT(n) do { if (p.stop_after == (n)) return; } while (0)
+#else
+#define NMS_STOP_AT(n) ((void)0)
+#endif
 #ifdef RPN_NMS_STAMP
 __device__ unsigned long long g_nms_stamps[64 * 512];
 #define NMS_STAMP(code)                                                                                       \
@@ -459,7 +480,7 @@ nms_kernel(NmsArgs p)
                                             band_target, band_cap, hist, ctl + CTL_SEL, &band_expected);
         }
         if (thr == 0ull) break;              // nothing left
-        if (p.stop_after == 1) return;
+        NMS_STOP_AT(1);
         NMS_STAMP(2);
 
         int band_n = 0;
@@ -502,14 +523,14 @@ nms_kernel(NmsArgs p)
         }
         __syncthreads();
         NMS_STAMP(3);
-        if (p.stop_after == 3) return;
+        NMS_STOP_AT(3);
         band_n = ctl[CTL_BANDN];
         if (band_n > kBandCap) band_n = kBandCap;    // cannot happen: the select guarantees <= kBandCap
         if (band_n == 0) break;
         if (band_n <= kNmsThreads) {
             // one key per thread; keys -> box indices in place (order aliases band: every key is in a register first)
             const unsigned long long sorted = bitonic1024_desc(tid < band_n ? band[tid] : 0ull, band);
-            if (p.stop_after == 2) return;
+            NMS_STOP_AT(2);
             if (tid < band_n) order[tid] = 0xFFFFFFFFu - (unsigned)(sorted & 0xFFFFFFFFull);
             if (tid == band_n - 1) *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW) = sorted;
             __syncthreads();
@@ -520,7 +541,7 @@ nms_kernel(NmsArgs p)
             for (int i = band_n + tid; i < n_sort; i += kNmsThreads) band[i] = 0ull;
             __syncthreads();
             bitonic_sort_desc(band, n_sort);
-            if (p.stop_after == 2) return;
+            NMS_STOP_AT(2);
             // keys -> 32-bit box indices, in place (read all, barrier, write)
             unsigned idx_reg[kBandCap / kNmsThreads];
 #pragma unroll
@@ -564,7 +585,7 @@ nms_kernel(NmsArgs p)
             }
             __syncthreads();
             NMS_STAMP(5);
-            if (p.stop_after == 4) return;
+            NMS_STOP_AT(4);
 
             // The chunk is walked in 4 groups of 64 candidates (one 64-bit word of the live mask).  Per group:
             // (B) all 16 waves build the suppression rows of the group's LIVE candidates against the live candidates after
@@ -582,6 +603,7 @@ nms_kernel(NmsArgs p)
                 //     boxes part, part + 16, ... (LDS broadcast within a part).  Done per group, so a chunk that completes
                 //     the output after one group tests 64 x nsel pairs, not 256 x nsel.
                 if (nsel > 0) {
+                    const int tid = fresh_tid(), lane = tid & 63;
                     const int il = tid >> 4, part = tid & 15;
                     const int t = gw * 64 + il;
                     bool hit = false;
@@ -630,6 +652,7 @@ nms_kernel(NmsArgs p)
                 // full rows before the walk did it for every live candidate, selected or not.
                 {
                     // 16 threads per row, 4 candidates each: piece (sub & 3) of the group, rows 4 (sub >> 2) .. + 3 of it
+                    const int tid = fresh_tid();
                     const int il = tid >> 4, sub = tid & 15;
                     const int piece = 4 * gw + (sub & 3), jj0 = 4 * (sub >> 2);
                     const int i = gw * 64 + il;
@@ -669,7 +692,7 @@ nms_kernel(NmsArgs p)
                 }
                 __syncthreads();
                 NMS_STAMP(7);
-                if (p.stop_after == 5) return;
+                NMS_STOP_AT(5);
                 if (tid < 64) {
                     const unsigned long long own = mask[lane * kChunkWords + gw];
                     const unsigned own_lo = (unsigned)own, own_hi = (unsigned)(own >> 32);
@@ -720,6 +743,7 @@ nms_kernel(NmsArgs p)
                     // chunk's later groups: item = (selected box, 16-candidate piece); hits go straight into the later
                     // groups' dead words (read by their walks behind at least one more barrier)
                     // (finer items when there are few of them: 8 or 4 candidates per thread instead of 16)
+                    const int tid = fresh_tid();
                     const int c_new = ctl[CTL_NSEL];
                     const int npl = 4 * (kChunkWords - 1 - gw);
                     const int items16 = c_new < max_sel ? (c_new - cur) * npl : 0;    // (output complete: nothing follows)
@@ -755,11 +779,11 @@ nms_kernel(NmsArgs p)
                     if (npl > 0) __syncthreads();                           // uniform: the next group reads its dead word
                 }
                 cur = ctl[CTL_NSEL];
-                if (p.stop_after == 6) return;
+                NMS_STOP_AT(6);
             }
             if (tid == 0) ctl[CTL_POS] = pos + T;
             __syncthreads();
-            if (p.stop_after == 7) return;
+            NMS_STOP_AT(7);
         }
         if (ctl[CTL_NSEL] >= max_sel) break;
         visited = band_n;
@@ -769,7 +793,7 @@ nms_kernel(NmsArgs p)
 
     // ================= 3. outputs =================================================================
     NMS_STAMP(10);
-    if (p.stop_after == 8) return;
+    NMS_STOP_AT(8);
     const int nsel = ctl[CTL_NSEL];
     if (p.C == 1) {
         const int M = p.max_total;
@@ -865,6 +889,24 @@ nms_merge_kernel(NmsArgs p, int n_sort_merge)
     if (tid == 0) p.out_valid[b] = nvalid;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel, raised only when a launch needs more than any launch before it
+// on the same device (hipFuncSetAttribute is a driver call of a few microseconds; the NMS is launched every step).
+struct DynLdsCeiling {
+    std::mutex mu;
+    size_t have[16] = {};
+    hipError_t raise(const void *fn, size_t bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 0 && dev < 16 && have[dev] >= bytes) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess && dev >= 0 && dev < 16) have[dev] = bytes;
+        return e;
+    }
+};
+
 static int next_pow2(int v)
 {
     int n = 2;
@@ -881,9 +923,11 @@ static size_t stage_bytes(int B, int C, int max_sel)
 template <bool DECODE>
 static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    static const int stop = getenv("RPN_NMS_STOP") ? atoi(getenv("RPN_NMS_STOP")) : 0;
+#ifdef RPN_LAB
+    static const int stop = RPN_LAB_KNOB("RPN_NMS_STOP", 0);
     p.stop_after = stop;
-    static const int linear = getenv("RPN_NMS_LINEAR") ? atoi(getenv("RPN_NMS_LINEAR")) : 1;
+#endif
+    static const int linear = RPN_KNOB("RPN_NMS_LINEAR", 1);
     p.linear_select = linear;
     if (p.iou_thr > 0.0f && p.iou_thr < INFINITY) {
         p.iou_lo = p.iou_thr * (1.0f - 0x1p-18f);
@@ -908,8 +952,10 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
                                               align16((size_t)p.B * p.C * p.max_sel * sizeof(int)));
     }
     auto kern = nms_kernel<DECODE>;
-    RPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+    {   // the dynamic-LDS ceiling of a function only ever has to grow: set once per (device, size), not on every launch
+        static DynLdsCeiling ceiling;
+        RPN_HIP_CHECK(ceiling.raise(reinterpret_cast<const void *>(kern), L.total));
+    }
     hipLaunchKernelGGL(kern, dim3(p.B * p.C), dim3(kNmsThreads), L.total, stream, p);
     RPN_CHECK_LAUNCH();
     if (p.C > 1) {
@@ -917,8 +963,10 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
         const size_t lds = (size_t)8 * n_merge + 16;
         if (lds > kLdsLimit)
             return fail(RPN_ERR_UNSUPPORTED, "nms merge: C*max_per_class = %d too large", p.C * p.max_sel);
-        RPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_merge_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            static DynLdsCeiling ceiling;
+            RPN_HIP_CHECK(ceiling.raise(reinterpret_cast<const void *>(nms_merge_kernel), lds));
+        }
         hipLaunchKernelGGL(nms_merge_kernel, dim3(p.B), dim3(kNmsThreads), lds, stream, p, n_merge);
         RPN_CHECK_LAUNCH();
     }

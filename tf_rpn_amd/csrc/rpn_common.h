@@ -4,8 +4,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/rpn_hip.h"
+#include "rpn_knobs.h"
 
 namespace rpn {
 
@@ -28,6 +30,7 @@ bool have_device();
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
 
 }  // namespace rpn
 

@@ -201,7 +201,9 @@ class RPNModel(object):
         L.check(L.lib().rpn_model_set_profiling_rotate(self._h, 1 if on else 0), "rpn_model_set_profiling_rotate")
 
     def ops(self):
-        """[{name, kernel, flops_per_image, bytes_per_image}] in launch order."""
+        """[{name, kernel, flops_per_image, bytes_per_image, arith, launches}] in graph order.  `arith` is the arithmetic the
+        op's matrix work runs in ("f32" | "bf16x3" | "f16x3"); `launches` is 0 for a max-pool that runs inside the previous
+        conv's epilogue (kernel "fused:maxpool_split": no launch, no bytes of its own), else 1."""
         lib = L.lib()
         out = []
         nb, kb = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
@@ -209,8 +211,11 @@ class RPNModel(object):
         for i in range(lib.rpn_model_num_ops(self._h)):
             L.check(lib.rpn_model_op_info(self._h, i, nb, 128, kb, 128, ctypes.byref(fl), ctypes.byref(by)),
                     "rpn_model_op_info")
-            out.append({"name": nb.value.decode(), "kernel": kb.value.decode(), "flops_per_image": fl.value,
-                        "bytes_per_image": by.value})
+            kernel = kb.value.decode()
+            out.append({"name": nb.value.decode(), "kernel": kernel, "flops_per_image": fl.value,
+                        "bytes_per_image": by.value,
+                        "arith": {0: "f32", 1: "bf16x3", 2: "f16x3"}[lib.rpn_model_op_arith(self._h, i)],
+                        "launches": 0 if kernel.startswith("fused:") else 1})
         return out
 
     def profile_ms(self):

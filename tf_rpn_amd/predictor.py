@@ -215,7 +215,10 @@ class Proposer(object):
         behind that stream), concurrently with the convs of batch k+1.  Returns the gathered records of batch k-1
         (None on the first call) after making the current stream wait for them; ``flush_distributed`` returns the
         last batch.  ``gather_bufs``: two (world * B, M*5+1) float32 tensors used alternately.  Every rank must make
-        the same sequence of calls."""
+        the same sequence of calls.
+
+        Lifetime: the returned tensor IS one of the caller's ``gather_bufs`` and is overwritten by the call after the
+        next one; copy it if it must outlive that."""
         import torch.distributed as dist
         prev = getattr(self, "_dist_last", None)
         self.propose_async(local_imgs)
@@ -263,7 +266,11 @@ class Proposer(object):
         ``total`` = global number of images when they were split with ``shard_bounds``: the all-gather needs equal
         sizes, so every rank pads its records to ceil(total / world) rows (zero rows, valid = 0) and the padding is
         dropped after the gather -> (total, M*5+1) in global image order.  Without ``total`` every rank must hold the
-        same number of images -> (world * B_local, M*5+1)."""
+        same number of images -> (world * B_local, M*5+1).
+
+        Lifetime: with a world of one process the result is a fresh copy; otherwise it is ``gather_out`` (or a new
+        tensor when that is None).  The per-rank record buffer packed on the way is persistent scratch of this
+        object and never returned."""
         import torch.distributed as dist
         boxes, scores, valid, _ = self.propose(local_imgs)
         B = int(scores.shape[0])
@@ -277,7 +284,7 @@ class Proposer(object):
         if B < rows:
             rec[B:].zero_()
         if world == 1:
-            return rec[:B]
+            return rec[:B].clone()                    # (not the hot path: never hand out the persistent scratch buffer)
         if gather_out is None:
             gather_out = torch.empty((world * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
         dist.all_gather_into_tensor(gather_out[:world * rows], rec)
@@ -366,21 +373,26 @@ def main(argv=None):
             return
         imgs = torch.from_numpy(np.stack(batch)).cuda()
         n = len(batch)
+
+        def run(prop):                              # ONE pass of the conv stack per batch
+            if args.nms:
+                boxes, scores, valid, _ = prop.propose(imgs)
+                return boxes[:n].cpu().numpy(), scores[:n].cpu().numpy(), valid[:n].cpu().numpy()
+            boxes, _order, scores = prop.top_k(imgs, args.top_k, return_scores=True)
+            boxes, scores = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy()
+            return boxes, scores, np.full((n,), boxes.shape[1])
+
         prop = state["prop"]
-        prop.forward(imgs)
+        boxes, scores, valid = run(prop)
+        # f16x3 only: the range flag of the pass that just ran (the .cpu() copies above already synchronised).  When this
+        # checkpoint's activations leave the float16 range the batch is redone on bfloat16 halves (float32 range), and
+        # the rest of the run stays there.
         if prop.rpn_model.precision == "f16x3" and prop.rpn_model.status(reset=True)["f16_range"]:
-            # this checkpoint's activations leave the float16 range: same path on bfloat16 halves (float32 range)
             print("precision f16x3: activations exceed the float16 range with these weights; switching to bf16x3",
                   file=sys.stderr)
             state["prop"] = prop = Proposer(args.backbone, hyper_params=hyper_params, weights=weights,
                                             precision="bf16x3", max_batch=B)
-        if args.nms:
-            boxes, scores, valid, _ = prop.propose(imgs)
-            boxes, scores, valid = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy(), valid[:n].cpu().numpy()
-        else:
-            boxes, _order, scores = prop.top_k(imgs, args.top_k, return_scores=True)
-            boxes, scores = boxes[:n].cpu().numpy(), scores[:n].cpu().numpy()
-            valid = np.full((n,), boxes.shape[1])
+            boxes, scores, valid = run(prop)
         for i in range(n):
             k = int(valid[i])
             px = np.round(boxes[i, :k] * np.float32(img_size)).astype(int)          # denormalize_bboxes (bbox_utils.py:152-166)
