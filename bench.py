@@ -624,11 +624,7 @@ def main():
         deltas, scores = prop.forward(imgs)
         nms_ev[k][0].record()                     # same stream as the launches (torch's current stream)
         prop_out = prop._boxes[:B], prop._scores[:B], prop._idx[:B], prop._valid[:B]
-        st = _lib.lib().rpn_decode_nms(_lib.ptr(prop.anchors), _lib.ptr(deltas), prop._vptr, _lib.ptr(scores), B,
-                                       prop.total_anchors, M, prop.iou_threshold, prop.score_threshold, 1,
-                                       _lib.ptr(prop_out[0]), _lib.ptr(prop_out[1]), _lib.ptr(prop_out[2]),
-                                       _lib.ptr(prop_out[3]), _lib.vp(0), 0, _lib.stream_ptr())
-        _lib.check(st, "rpn_decode_nms")
+        prop.decode_nms(deltas, scores, B, *prop_out)
         nms_ev[k][1].record()
         if world > 1:
             rec = prop.pack_records(prop_out[0], prop_out[1], prop_out[3], out=prop._record_buffer(2, B))
@@ -670,11 +666,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            _lib.check(_lib.lib().rpn_decode_nms(_lib.ptr(prop.anchors), _lib.ptr(d_), prop._vptr, _lib.ptr(s_), B,
-                                                 prop.total_anchors, M, prop.iou_threshold, prop.score_threshold, 1,
-                                                 _lib.ptr(prop._boxes[:B]), _lib.ptr(prop._scores[:B]),
-                                                 _lib.ptr(prop._idx[:B]), _lib.ptr(prop._valid[:B]), _lib.vp(0), 0,
-                                                 _lib.stream_ptr()), "rpn_decode_nms")
+            prop.decode_nms(d_, s_, B, prop._boxes[:B], prop._scores[:B], prop._idx[:B], prop._valid[:B])
         e1.record()
         torch.cuda.synchronize()
         nms_ms = e0.elapsed_time(e1) / 5

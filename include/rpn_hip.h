@@ -116,7 +116,12 @@ int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, const float *d
  *   d_out_boxes (B,M,4), d_out_scores (B,M), d_out_classes (B,M) float32,
  *   d_out_valid (B) int32, and -- not returned by TF, for parity checks -- d_out_idx (B,M)
  *   int32 box indices (-1 padded; may be NULL).
- *   d_workspace: rpn_nms_workspace_bytes(...) bytes of device scratch (may be NULL if 0).
+ *   d_workspace: rpn_nms_workspace_bytes(...) bytes of device scratch (may be NULL if 0).  For C > 1 the
+ *   staging part is REQUIRED (RPN_ERR_WORKSPACE otherwise).  For few (image, class) pairs with many
+ *   candidates (<= 32 pairs, N >= 16384) the size also covers the "cluster" scratch with which several
+ *   workgroups per pair share the passes over the scores; a call that passes less (or NULL) still
+ *   succeeds with identical results on one workgroup per pair.  rpn_decode_nms takes the same scratch:
+ *   rpn_nms_workspace_bytes(B, A, 1, max_total, max_total).
  * ---------------------------------------------------------------------------------- */
 size_t rpn_nms_workspace_bytes(int B, int N, int C, int max_per_class, int max_total);
 int rpn_combined_nms(const float *d_boxes, const float *d_scores, int B, int N, int q, int C,

@@ -16,5 +16,4 @@ run inst SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_WR
 run write WRITE_SIZE
 cat $OUT/status.txt
 python $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-sed -i 's/if not any(s in k for s in ("rpn::", "conv", "nms")):/if not any(s in k for s in ("rpn::", "conv", "nms", "iou")):/' $GRAFT_REPO_ROOT/scripts/pmc_summary.py
 grep -A25 "iou_map" $OUT/summary.txt | head -60

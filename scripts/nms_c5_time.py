@@ -19,9 +19,10 @@ for bb, B, size, kw in (("mobilenet_v2", 1, 1024, dict(img_size=1024, feature_ma
     A = prop.total_anchors
     ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device="cuda")
     oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    WS = torch.empty((max(16, int(L.lib().rpn_nms_workspace_bytes(B, A, 1, 300, 300))),), dtype=torch.uint8, device="cuda")
     def run():
         L.check(L.lib().rpn_decode_nms(L.ptr(prop.anchors), L.ptr(d), prop._vptr, L.ptr(s), B, A, 300, 0.7, float("-inf"), 1,
-                                       L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
+                                       L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.ptr(WS), WS.numel(), L.stream_ptr()), "nms")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -43,9 +43,10 @@ ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device
 oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
 keep, vptr = L.host_floats(np.float32([0.1, 0.1, 0.2, 0.2]))
 lib = L.lib()
+WS = torch.empty((max(16, int(lib.rpn_nms_workspace_bytes(B, A, 1, 300, 300))),), dtype=torch.uint8, device="cuda")
 for _ in range(3):
     L.check(lib.rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, THR, float("-inf"), 1, L.ptr(ob), L.ptr(osc),
-                               L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
+                               L.ptr(oi), L.ptr(ov), L.ptr(WS), WS.numel(), L.stream_ptr()), "nms")
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (64 * 512))()
 raw = ctypes.CDLL(L.LIB_PATH)

@@ -5,14 +5,14 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
-        k = row.get("Kernel_Name", "")[:70]
+        k = row.get("Kernel_Name", "")[:110]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for path in glob.glob(os.path.join(root, "*", "**", "*kernel_trace.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
-        k = row.get("Kernel_Name", "")[:70]
+        k = row.get("Kernel_Name", "")[:110]
         dur[k].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 for k in sorted(agg, key=lambda k: -sum(dur.get(k, [0]))):
-    if not any(s in k for s in ("rpn::", "conv", "nms")):
+    if not any(s in k for s in ("rpn::", "conv", "nms", "iou")):
         continue
     d = dur.get(k, [])
     print("%s\n   dispatches/pass %d  mean duration %.1f us" % (k, len(d) // max(1, len(glob.glob(os.path.join(root, '*', '**', '*kernel_trace.csv'), recursive=True))), (sum(d) / len(d) / 1e3) if d else 0))

@@ -330,6 +330,35 @@ def test_nms_without_the_linear_histogram_subprocess(mode):
     assert "nms fallback ok" in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["4", "16"])
+def test_nms_cluster_mode_forced_subprocess(size):
+    """RPN_NMS_CLUSTER (read once per process) = k: k workgroups per (image, class) share the first band's passes over the
+    scores wherever they fit -- automatic only for few images with >= 16 384 candidates, forced here so that the small and
+    special problems (ties, duplicates, thresholds on a ratio, several classes, empty slices) go through the cluster
+    barriers too.  Same outputs, bit for bit, as the oracle."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import tests.test_gpu_bbox as t
+        t.test_nms_randomised_shapes_thresholds_and_box_kinds()
+        t.test_nms_ties_and_duplicates_on_raw_anchors()
+        t.test_nms_ratios_on_and_next_to_the_threshold()
+        t.test_nms_multiclass_random()
+        t.test_nms_thresholds_sizes_and_limits()
+        t.test_nms_bunched_and_saturated_scores()
+        t.test_nms_full_size_decoded_anchors("vgg16", 8, 0.7)
+        t.test_decode_nms_fused_equals_two_step("mobilenet_v2", 3)
+        t.test_nms_kernel_against_recalled_tf_unit_test_vectors()
+        print("nms cluster ok")
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPN_NMS_CLUSTER=size), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "nms cluster ok" in r.stdout
+
+
 def test_nms_randomised_shapes_thresholds_and_box_kinds():
     """240 seeded random problems against the oracle, bit for bit: N from 1 to 3000 (partial groups, partial chunks, several
     chunks), output sizes from 1 to 400, thresholds over (0, 1) including dyadic ones that the boxes' ratios hit exactly,

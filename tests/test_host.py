@@ -35,6 +35,37 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.rpn_abi_version() == 1
 
 
+def test_shipped_library_reads_only_the_documented_knobs(lib):
+    """Product vs laboratory: the environment names compiled into librpn_hip.so are exactly the `RPN_KNOB` list of
+    include/rpn_hip.h.  A/B switches and the timing experiments that produce wrong results on purpose (RPN_NMS_STOP,
+    RPN_IOU_EXP, RPN_SPLIT_*, ...) exist only in `make lab` builds (-DRPN_LAB), so a stray environment variable cannot
+    change what the product computes."""
+    header = open(os.path.join(ROOT, "include", "rpn_hip.h")).read()
+    documented = set(re.findall(r"RPN_KNOB (RPN_[A-Z0-9_]+)", header))
+    assert len(documented) >= 8
+    blob = open(L.LIB_PATH, "rb").read()
+    in_binary = {m.group(1).decode() for m in re.finditer(rb"\x00(RPN_[A-Z0-9_]+)(?=\x00)", blob)}
+    assert in_binary == documented, (sorted(in_binary - documented), sorted(documented - in_binary))
+    for name in ("RPN_NMS_STOP", "RPN_IOU_EXP", "RPN_SPLIT_TILE", "RPN_S16_DMA", "RPN_IR_STAMP_OP"):
+        assert name.encode() not in blob
+
+
+def test_nms_kernels_use_no_scratch_memory(lib):
+    """Code-object metadata of the shipped library: the NMS kernels keep everything in registers (round 2: 46 spilled VGPRs =
+    180 B of scratch per thread = 11.8 MB written per launch at 64 images), and no kernel of the library spills more than
+    a handful of registers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import codeobj
+    ks = codeobj.kernels(L.LIB_PATH)
+    nms = {n: k for n, k in ks.items() if "nms_kernel" in n or "nms_merge" in n}
+    assert len(nms) == 3
+    for name, k in nms.items():
+        assert k[".private_segment_fixed_size"] == 0 and k.get(".vgpr_spill_count", 0) == 0, (name, k)
+        assert k[".vgpr_count"] <= 128                       # 1024-thread workgroups: 4 waves per SIMD
+    worst = max(ks.values(), key=lambda k: k[".private_segment_fixed_size"])
+    assert worst[".private_segment_fixed_size"] <= 64, worst[".name"]
+
+
 def test_no_torch_types_in_the_abi():
     header = open(os.path.join(ROOT, "include", "rpn_hip.h")).read()
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)              # comments may mention torch storage

@@ -47,6 +47,15 @@ __device__ __forceinline__ int fresh_tid()
     return t;
 }
 
+// A workgroup-uniform 64-bit value that was read from LDS, moved to scalar registers (two v_readfirstlane): it then costs
+// no vector registers across the band loop.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
 constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
@@ -87,6 +96,11 @@ struct NmsArgs {
     int stop_after;          // timing experiments only (RPN_NMS_STOP): 2 = stop after the first band sort; 0 = run all
 #endif
     int linear_select;       // band threshold by the one-pass linear histogram first (RPN_NMS_LINEAR=0: radix select only)
+    // cluster mode (few images, many candidates): `cluster` workgroups per (image, class) share the passes over the scores
+    // of the FIRST band; cl_ctl / cl_band: the cluster workspace (cluster_layout), zeroed control part
+    int cluster, cl_region;
+    unsigned *cl_ctl;
+    unsigned long long *cl_band;
 };
 
 // Descending bitonic sort of n (power of two) 64-bit keys in LDS by the whole workgroup.
@@ -211,13 +225,20 @@ __device__ __forceinline__ void linear_hist_find(const unsigned *hist, int want,
     }
 }
 
+__device__ __forceinline__ int linear_bin(float s) { return (int)fminf(fmaxf(s * 2048.0f, 0.0f), 2047.0f); }
+// sub-bin of a score inside bin d: floor((score * 2048 - d) * 2048), exact (the difference of two floats in [d, d + 1) and a
+// power-of-two scale); the threshold score of sub-bin k is (2048 d + k) / 2^22
+__device__ __forceinline__ int linear_sub_bin(float s, int d) { return (int)fminf(fmaxf((s * 2048.0f - (float)d) * 2048.0f, 0.0f), 2047.0f); }
+
 __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, int N, float score_thr,
                                           unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
                                           unsigned long long *thr_out, int *count, int *bin_out)
 {
     constexpr int NB = 2048;
     const int tid = fresh_tid();
-    for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
+    // hist[0, 2048): the bins; hist[2048, 4096): the 2048 sub-bins of the TOP bin, filled in the same pass -- a saturated
+    // sigmoid puts most of a head's 61 440 scores there, and the refinement below then needs no pass of its own
+    for (int i = tid; i < 2 * NB; i += kNmsThreads) hist[i] = 0u;
     __syncthreads();
     for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
         float sb[kLoadBatch];
@@ -226,8 +247,11 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
 #pragma unroll
         for (int u = 0; u < kLoadBatch; ++u) {
             const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);     // 0 for NaN / below threshold
-            if (key != 0ull && key < hi_bound)
-                atomicAdd(&hist[(int)fminf(fmaxf(sb[u] * 2048.0f, 0.0f), 2047.0f)], 1u);
+            if (key != 0ull && key < hi_bound) {
+                const int bin = linear_bin(sb[u]);
+                atomicAdd(&hist[bin], 1u);
+                if (bin == NB - 1) atomicAdd(&hist[NB + linear_sub_bin(sb[u], NB - 1)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -250,23 +274,24 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
     // sub = floor((score * 2048 - d) * 2048) (exact: the difference of two floats in [d, d + 1) and a power-of-two scale),
     // instead of handing the whole problem to the three-pass radix select.  Threshold score (2048 d + sub) / 2^22.
     const int above = n - in_d;             // keys in the bins above d: all in the band
-    for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
-    __syncthreads();
-    const float fd = (float)d;
-    for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
-        float sb[kLoadBatch];
+    const unsigned *sub = hist + NB;        // the top bin's sub-bins are there already
+    if (d != NB - 1) {
+        for (int i = tid; i < NB; i += kNmsThreads) hist[i] = 0u;
+        __syncthreads();
+        for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
+            float sb[kLoadBatch];
 #pragma unroll
-        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+            for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
 #pragma unroll
-        for (int u = 0; u < kLoadBatch; ++u) {
-            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
-            const float scaled = sb[u] * 2048.0f;
-            if (key != 0ull && key < hi_bound && (int)fminf(fmaxf(scaled, 0.0f), 2047.0f) == d)
-                atomicAdd(&hist[(int)fminf(fmaxf((scaled - fd) * 2048.0f, 0.0f), 2047.0f)], 1u);
+            for (int u = 0; u < kLoadBatch; ++u) {
+                const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
+                if (key != 0ull && key < hi_bound && linear_bin(sb[u]) == d) atomicAdd(&hist[linear_sub_bin(sb[u], d)], 1u);
+            }
         }
+        __syncthreads();
+        sub = hist;
     }
-    __syncthreads();
-    linear_hist_find(hist, want - above, ctl);
+    linear_hist_find(sub, want - above, ctl);
     __syncthreads();
     const int d2 = ctl[0], n2 = ctl[1];
     __syncthreads();
@@ -278,11 +303,28 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
     return true;
 }
 
-__device__ __forceinline__ int linear_bin(float s) { return (int)fminf(fmaxf(s * 2048.0f, 0.0f), 2047.0f); }
 __device__ __forceinline__ float key_score(unsigned long long key)            // inverse of orderable()
 {
     const unsigned o = (unsigned)(key >> 32);
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// the band's keys by a scan of all N scores (8 loads in flight per thread)
+template <class Fn>
+__device__ __forceinline__ void scan_band_keys(const float *__restrict__ sc, int C, int N, float score_thr, unsigned long long thr,
+                                               unsigned long long hi_bound, Fn fn)
+{
+    const int tid = fresh_tid();
+    for (int base = tid; base < N; base += 8 * kNmsThreads) {
+        float sb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
+            if (key != 0ull && key >= thr && key < hi_bound) fn(key);
+        }
+    }
 }
 
 // The band in descending key order WITHOUT a sorting network, from the linear histogram that chose it: bin b's keys go
@@ -291,8 +333,10 @@ __device__ __forceinline__ float key_score(unsigned long long key)            //
 // scores scatters the band's keys to their bins' segments (per-bin LDS cursors), a second step ranks inside the segments.
 // hist: [0,2048) counts (from band_select_linear), [2048,4096) offsets, [4096,6144) cursors, [6144,6161) scan scratch.
 // Returns false (nothing written) when a bin of the band holds more than 32 keys: the caller then sorts the old way.
-__device__ inline bool band_order_linear(const float *__restrict__ sc, int C, int N, float score_thr, unsigned long long thr,
-                                         unsigned long long hi_bound, int d, int n, unsigned *hist, unsigned long long *band,
+// `for_each_band_key(fn)`: calls fn(key) for this thread's share of the band's keys (every key exactly once over the
+// workgroup): a scan of all N scores, or -- cluster mode -- the list the cluster's ranks compacted into the workspace.
+template <class ForEachKey>
+__device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d, int n, unsigned *hist, unsigned long long *band,
                                          unsigned *order, unsigned long long *low_out)
 {
     const int tid = fresh_tid(), lane = tid & 63, wave = tid >> 6;
@@ -319,19 +363,10 @@ __device__ inline bool band_order_linear(const float *__restrict__ sc, int C, in
     __syncthreads();
     if (scratch[16] != 0u) return false;
     // scatter: the band's keys to their bins' segments
-    for (int base = tid; base < N; base += 8 * kNmsThreads) {
-        float sb[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
-            if (key != 0ull && key >= thr && key < hi_bound) {
-                const int b = linear_bin(sb[u]);
-                band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
-            }
-        }
-    }
+    for_each_band_key([&](unsigned long long key) {
+        const int b = linear_bin(key_score(key));
+        band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
+    });
     __syncthreads();
     // rank inside the bin's segment (keys are unique); up to two keys per thread (n <= 2048)
     unsigned long long key[2] = {0ull, 0ull};
@@ -357,6 +392,207 @@ __device__ inline bool band_order_linear(const float *__restrict__ sc, int C, in
         }
     __syncthreads();
     return true;
+}
+
+
+// Laboratory build only (-DRPN_LAB, RPN_NMS_STOP=n): leave the kernel after phase n (outputs are then not written).
+#ifdef RPN_LAB
+#define NMS_STOP_AT(n) do { if (p.stop_after == (n)) return; } while (0)
+#else
+#define NMS_STOP_AT(n) ((void)0)
+#endif
+#ifdef RPN_NMS_STAMP
+__device__ unsigned long long g_nms_stamps[64 * 512];
+#define NMS_STAMP(code)                                                                                       \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && nms_sidx < 512)                                            \
+            g_nms_stamps[blockIdx.x * 512 + nms_sidx++] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); \
+    } while (0)
+extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), (size_t)n * 8);
+}
+#define NMS_SIDX_PARAM , int &nms_sidx
+#define NMS_SIDX_ARG , nms_sidx
+#else
+#define NMS_STAMP(code) ((void)0)
+#define NMS_SIDX_PARAM
+#define NMS_SIDX_ARG
+#endif
+
+
+// ---- cluster mode: several workgroups per (image, class) for the first band ------------------------------------------
+// One workgroup walks N scores at one compute unit's memory-level parallelism (~7 B / clk: 33 k cycles per pass at 61 440
+// candidates, three passes for a saturated head: histogram, refinement, compaction).  With few images the other 255 CUs
+// idle meanwhile.  In cluster mode G workgroups (blockIdx = pair * G + rank, dispatched together) each take a contiguous
+// slice of the scores: slice histogram in LDS -> device-scope atomic adds into the cluster's global histogram -> cluster
+// barrier -> every workgroup reads the 8 KB sum back and takes the same decision the single workgroup would have taken;
+// the band's keys are compacted per slice into the rank's region of the workspace, and after the last barrier the LEADER
+// (rank 0) orders the band and runs the greedy selection (and any later band) alone; the other ranks have left.
+// Deadlock-free: a waiting workgroup holds its CU, the ones it waits for are already dispatched or are dispatched as
+// soon as ANY CU frees up (other kernels' workgroups always finish), and the host keeps pairs * G <= 128 workgroups.
+constexpr int kClusterMax = 16;
+constexpr int kClCtlWords = 64 + 3 * 2048;      // [0..2] barrier counters, [16 + g] keys of rank g, [64..) three histograms
+
+struct ClusterCtx {
+    int G, g;
+    unsigned *ctr;               // control words of this (image, class) pair
+    unsigned *hist;              // global counters: [0, 2048) bins | [2048, 4096) sub-bins of the top bin | [4096, 6144) refinement
+    unsigned long long *band;    // G regions of `region` keys
+    int region;
+};
+
+// Arrive at cluster barrier `k`; `wait`: and wait for all G workgroups.  Every thread first waits for its own global stores
+// and atomics (vmcnt(0): they are in the L2 / performed), the workgroup barrier then puts them all in front of thread 0's
+// device-scope RELEASE fence (L2 write-back: this XCD's L2 is not coherent with the others') and arrival; thread 0 polls with
+// relaxed loads and issues ONE acquire fence (L1 / L2 invalidate, CU- and XCD-wide) before the closing workgroup barrier.
+// (First version: __threadfence() by all 1024 threads on both sides and an acquire load per poll: ~25 k cycles per barrier.)
+// The wait is BOUNDED (~0.1 s of polling: far beyond any kernel another stream could be holding the CUs with): returns
+// false when a rank never arrived, and the caller then gives the cluster up -- the leader recomputes the band alone, so a
+// lost rank costs time, never a hang or a wrong result.  `flag`: one int of LDS.
+__device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool wait, int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(cl.ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        if (wait) {
+            int spins = 0;
+            while (__hip_atomic_load(cl.ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl.G) {
+                if (++spins > (1 << 17)) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// slice histograms (LDS, NH x 2048 words) -> + global -> barrier -> the cluster's sums back into LDS `hist`.
+// bin_of(score, &second): first bin (< 0: not counted) and, optionally, a second one in [2048, 4096) (< 0: none).
+template <int NH, class BinFn>
+__device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, unsigned *ghist, const float *__restrict__ sc, int C,
+                                                  int lo, int hi, float score_thr, unsigned *hist, int *flag, BinFn bin_of)
+{
+    const int tid = fresh_tid();
+    for (int i = tid; i < NH * 2048; i += kNmsThreads) hist[i] = 0u;
+    __syncthreads();
+    for (int base = lo + tid; base < hi; base += kLoadBatch * kNmsThreads) {
+        float sb[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) {
+            if (sb[u] > score_thr) {                                         // (NaN: not a candidate)
+                int second = -1;
+                const int bin = bin_of(sb[u], second);
+                if (bin >= 0) atomicAdd(&hist[bin], 1u);
+                if (NH > 1 && second >= 0) atomicAdd(&hist[second], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NH * 2048; i += kNmsThreads) {
+        const unsigned v = hist[i];
+        if (v) __hip_atomic_fetch_add(ghist + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!cluster_arrive(cl, k, true, flag)) return false;
+    for (int i = tid; i < NH * 2048; i += kNmsThreads)
+        hist[i] = __hip_atomic_load(ghist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+}
+
+// First band, cluster form of band_select_linear (hi_bound = all keys).  Every rank returns the same value:
+//   0: fall back (the linear histogram does not apply, or a rank never arrived at a barrier) -- the leader runs the regular
+//      single-workgroup path from the start, the others leave;
+//   1: *thr_out / *count / *bin_out as band_select_linear would set them, and every rank has written its slice's band keys
+//      to its region (count in ctr[16 + g]); ranks other than the leader have arrived at barrier 2 and must leave.
+__device__ inline int cluster_first_band(const ClusterCtx &cl, const float *__restrict__ sc, int C, int N, float score_thr,
+                                         int want, int cap, unsigned *hist, int *ctl, unsigned long long *lds_keys,
+                                         unsigned long long *thr_out, int *count, int *bin_out NMS_SIDX_PARAM)
+{
+    const int tid = fresh_tid(), lane = tid & 63;
+    const int per = (N + cl.G - 1) / cl.G;
+    const int lo = min(N, cl.g * per), hi = min(N, lo + per);
+    if (!cluster_histogram<2>(cl, 0, cl.hist, sc, C, lo, hi, score_thr, hist, ctl + 3, [](float s, int &second) {
+            const int bin = linear_bin(s);
+            if (bin == 2047) second = 2048 + linear_sub_bin(s, 2047);
+            return bin;
+        }))
+        return 0;
+    NMS_STAMP(20);
+    linear_hist_find(hist, want, ctl);
+    __syncthreads();
+    const int d = ctl[0], n = ctl[1];
+    const int in_d = d > 0 ? (int)hist[d] : 0;
+    __syncthreads();
+    unsigned long long thr = 0ull;
+    int total = 0, bin = d;
+    if (d == -1) { thr = 0ull; total = 0; }
+    else if (d == -2) { thr = 1ull; total = n; bin = -1; }
+    else if (d == 0) return 0;
+    else if (n <= cap) { thr = (unsigned long long)orderable((float)d * (1.0f / 2048.0f)) << 32; total = n; }
+    else {
+        // the crossing bin holds more than the band may take: refine inside it (band_select_linear's second step; the top
+        // bin's sub-bins came with the first pass)
+        const int above = n - in_d;
+        const unsigned *sub = hist + 2048;
+        if (d != 2047) {
+            if (!cluster_histogram<1>(cl, 1, cl.hist + 4096, sc, C, lo, hi, score_thr, hist, ctl + 3, [=](float s, int &) {
+                    return linear_bin(s) == d ? linear_sub_bin(s, d) : -1;
+                }))
+                return 0;
+            sub = hist;
+        }
+        linear_hist_find(sub, want - above, ctl);
+        __syncthreads();
+        const int d2 = ctl[0], n2 = ctl[1];
+        __syncthreads();
+        bin = -1;
+        if (d2 < 0 || above + n2 > cap) return 0;
+        thr = (unsigned long long)orderable((float)(d * 2048 + d2) * (1.0f / 4194304.0f)) << 32;
+        total = above + n2;
+    }
+    NMS_STAMP(21);
+    *thr_out = thr;
+    *count = total;
+    *bin_out = bin;
+    if (thr == 0ull) return 1;               // no candidate at all: nothing to compact (the leader ends at once)
+    // compact this slice's band keys: LDS first (ballot ranks, one LDS atomic per wave), then the rank's region
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    for (int base = lo + tid; base < hi; base += kLoadBatch * kNmsThreads) {
+        float sb[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) {
+            const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
+            const bool in = key >= thr && key != 0ull;
+            const unsigned long long bal = __ballot(in);
+            if (bal) {
+                int slot0 = 0;
+                if (lane == __ffsll((long long)bal) - 1) slot0 = atomicAdd(&ctl[2], __popcll(bal));
+                slot0 = __shfl(slot0, __ffsll((long long)bal) - 1, 64);
+                const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+                if (in && slot < kBandCap) lds_keys[slot] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const int mine = min(ctl[2], cl.region);
+    unsigned long long *dst = cl.band + (size_t)cl.g * cl.region;
+    for (int i = tid; i < mine; i += kNmsThreads) dst[i] = lds_keys[i];
+    if (tid == 0) cl.ctr[16 + cl.g] = (unsigned)mine;
+    NMS_STAMP(22);
+    const int ok = cluster_arrive(cl, 2, cl.g == 0, ctl + 3) ? 1 : 0;
+    NMS_STAMP(23);
+    return ok;
 }
 
 // LDS carve-up (dynamic, 16-byte aligned)
@@ -392,27 +628,6 @@ enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by 
 
 // Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the
 // first 64 workgroups, in program order (slot 0 = start; the probe knows the sequence).
-// Laboratory build only (-DRPN_LAB, RPN_NMS_STOP=n): leave the kernel after phase n (outputs are then not written).
-#ifdef RPN_LAB
-#define NMS_STOP_AT(n) do { if (p.stop_after == (n)) return; } while (0)
-#else
-#define NMS_STOP_AT(n) ((void)0)
-#endif
-#ifdef RPN_NMS_STAMP
-__device__ unsigned long long g_nms_stamps[64 * 512];
-#define NMS_STAMP(code)                                                                                       \
-    do {                                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < 64 && nms_sidx < 512)                                            \
-            g_nms_stamps[blockIdx.x * 512 + nms_sidx++] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); \
-    } while (0)
-extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), (size_t)n * 8);
-}
-#else
-#define NMS_STAMP(code) ((void)0)
-#endif
-
 template <bool DECODE>
 __global__ void __launch_bounds__(kNmsThreads)
 nms_kernel(NmsArgs p)
@@ -436,8 +651,9 @@ nms_kernel(NmsArgs p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int b = blockIdx.x / p.C;
-    const int c = blockIdx.x - b * p.C;
+    const int pair = (int)blockIdx.x / p.cluster;      // (image, class) pair; p.cluster workgroups each (1 = the normal case)
+    const int b = pair / p.C;
+    const int c = pair - b * p.C;
     const int qc = (p.q == 1) ? 0 : c;
     const int N = p.N, max_sel = p.max_sel;
     const float *__restrict__ sc = p.scores + (size_t)b * N * p.C + c;
@@ -453,6 +669,28 @@ nms_kernel(NmsArgs p)
 
     unsigned long long hi_bound = ~0ull;       // keys of the current band are < hi_bound (exclusive)
     int visited = 0, have_before = 0;          // candidates of the band before this one; boxes selected before it (uniform)
+
+    // cluster mode: the first band's threshold and keys come from all ranks of the cluster (cluster_first_band)
+    ClusterCtx cl{};
+    int cl_state = 0;                          // 1: the first band is in the workspace (cl_thr / cl_count / cl_bin)
+    unsigned long long cl_thr = 0ull;
+    int cl_count = 0, cl_bin = -1;
+    if (p.cluster > 1) {
+        cl.G = p.cluster;
+        cl.g = (int)blockIdx.x % p.cluster;
+        cl.ctr = p.cl_ctl + (size_t)pair * kClCtlWords;
+        cl.hist = cl.ctr + 64;
+        cl.region = p.cl_region;
+        cl.band = p.cl_band + (size_t)pair * p.cluster * p.cl_region;
+        if (p.linear_select) {
+            const int band_target = min(kBandTarget, max(512, 3 * max_sel));
+            const int band_cap = band_target <= 960 ? 1024 : kBandCap;
+            cl_state = cluster_first_band(cl, sc, C, N, p.score_thr, band_target, band_cap, hist, ctl + CTL_SEL, band, &cl_thr,
+                                          &cl_count, &cl_bin NMS_SIDX_ARG);
+        }
+        if (cl.g != 0) return;                 // the leader goes on alone (with the cluster's band, or from scratch)
+        __syncthreads();
+    }
 
     while (true) {
         // ================= 1. pick the next band: keys in [thr, hi_bound) ==========================
@@ -472,32 +710,57 @@ nms_kernel(NmsArgs p)
         const int band_cap = band_target <= 960 ? 1024 : kBandCap;
         unsigned long long thr = 0ull;
         int lin_bin = -1;                    // >= 0: the band was chosen by the linear histogram (still in `hist`) at this bin
-        if (!p.linear_select ||
+        const bool from_cluster = cl_state == 1 && visited == 0;
+        if (from_cluster) {
+            thr = cl_thr;
+            band_expected = cl_count;
+            lin_bin = cl_bin;
+        } else if (!p.linear_select ||
             !band_select_linear(sc, C, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected,
                                 &lin_bin)) {
             lin_bin = -1;
             thr = radix_select<kNmsThreads>([&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound,
                                             band_target, band_cap, hist, ctl + CTL_SEL, &band_expected);
         }
+        thr = uniform_u64(thr);
         if (thr == 0ull) break;              // nothing left
         NMS_STOP_AT(1);
         NMS_STAMP(2);
 
         int band_n = 0;
         bool ordered = false;
+        // cluster mode: key i of the band's list = key (i - first[r]) of rank r's region
+        auto cluster_key = [&](int i) {
+            int r = 0, first = 0;
+            for (; r + 1 < cl.G; ++r) {
+                const int cnt = (int)cl.ctr[16 + r];
+                if (i < first + cnt) break;
+                first += cnt;
+            }
+            return cl.band[(size_t)r * cl.region + (i - first)];
+        };
         if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
-            ordered = band_order_linear(sc, C, N, p.score_thr, thr, hi_bound, lin_bin, band_expected, hist, band, order,
+            if (from_cluster)
+                ordered = band_order_linear([&](auto fn) { for (int i = fresh_tid(); i < band_expected; i += kNmsThreads) fn(cluster_key(i)); },
+                                            lin_bin, band_expected, hist, band, order,
+                                            reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
+            else
+            ordered = band_order_linear([&](auto fn) { scan_band_keys(sc, C, N, p.score_thr, thr, hi_bound, fn); },
+                                        lin_bin, band_expected, hist, band, order,
                                         reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             if (ordered) {
                 band_n = band_expected;
-                hi_bound = *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW);     // the next band continues strictly below
+                hi_bound = uniform_u64(*reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));   // the next band continues strictly below
             }
         }
         if (!ordered) {
 
         // ---- compact the band's keys into LDS, pad to a power of two, sort descending ------------------
-        if (tid == 0) ctl[CTL_BANDN] = 0;
+        if (tid == 0) ctl[CTL_BANDN] = from_cluster ? min(band_expected, kBandCap) : 0;
         __syncthreads();
+        if (from_cluster) {                  // the cluster's ranks compacted their slices already: copy the list
+            for (int i = tid; i < min(band_expected, kBandCap); i += kNmsThreads) band[i] = cluster_key(i);
+        } else
         for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {       // loads batched: kLoadBatch in flight per thread
             float sb[kLoadBatch];
 #pragma unroll
@@ -534,7 +797,7 @@ nms_kernel(NmsArgs p)
             if (tid < band_n) order[tid] = 0xFFFFFFFFu - (unsigned)(sorted & 0xFFFFFFFFull);
             if (tid == band_n - 1) *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW) = sorted;
             __syncthreads();
-            hi_bound = *reinterpret_cast<unsigned long long *>(ctl + CTL_LOW);     // the next band continues strictly below
+            hi_bound = uniform_u64(*reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));   // the next band continues strictly below
         } else {
             int n_sort = 2;
             while (n_sort < band_n) n_sort <<= 1;
@@ -556,7 +819,7 @@ nms_kernel(NmsArgs p)
                 const int i = tid + j * kNmsThreads;
                 if (i < band_n) order[i] = idx_reg[j];
             }
-            hi_bound = lowest;                       // the next band continues strictly below this one
+            hi_bound = uniform_u64(lowest);          // the next band continues strictly below this one
         }
         }   // !ordered
         if (tid == 0) ctl[CTL_POS] = 0;
@@ -642,9 +905,13 @@ nms_kernel(NmsArgs p)
                             if ((bal >> (16 * q)) & 0xFFFFull) bits |= 1ull << (4 * (tid >> 6) + q);
                         atomicOr(&deadw[gw], bits);
                     }
-                    __syncthreads();
                     NMS_STAMP(6);
                 }
+                // No barrier between (A), (B1) and the (B2) of the group before: all three only OR bits into dead words or
+                // write this group's rows; (B1) reads the dead word merely to SKIP work (a candidate that is dead, or whose
+                // death is not visible yet, may sit in a suppressor set: the walk only ever looks at live candidates' sets
+                // and only at their live / selected members).  One barrier in front of the walk closes the interval, so the
+                // latency-bound pieces (B1, B2) run under the issue-bound one (A): 4 barrier intervals per group -> 2.
                 // (B1) the group's own 64 x 64 block only: for each live candidate i the candidates BEFORE it that suppress it
                 // (its suppressor set: the walk below resolves the group from these, in parallel; the test is symmetric in
                 // its two boxes).  16 threads per row, 4 candidates each.  What the group's SELECTED boxes suppress in the
@@ -776,7 +1043,7 @@ nms_kernel(NmsArgs p)
                         }
                         if (bits) atomicOr(&deadw[piece >> 2], (unsigned long long)bits << ((piece & 3) * 16 + jj0));
                     }
-                    if (npl > 0) __syncthreads();                           // uniform: the next group reads its dead word
+                    // (no barrier: the next group's walk reads its dead word behind the barrier that follows its (B1))
                 }
                 cur = ctl[CTL_NSEL];
                 NMS_STOP_AT(6);
@@ -920,6 +1187,32 @@ static size_t stage_bytes(int B, int C, int max_sel)
     return align16((size_t)B * C * max_sel * sizeof(int)) + align16((size_t)B * C * sizeof(int));
 }
 
+// Cluster mode (cluster_first_band): workgroups per (image, class) pair.  Automatic for few pairs with many candidates
+// (<= 32 pairs, >= 16 384 candidates: slices of >= 2048 scores, at most 128 workgroups in all -- half the chip, so that
+// every workgroup of a cluster is resident or next in line while the others wait for it).  RPN_NMS_CLUSTER=1 turns it
+// off, = 2 .. 16 forces that size wherever it fits (tests run the small problems through it that way).
+static int cluster_size(int pairs, int N)
+{
+    static const int knob = RPN_KNOB("RPN_NMS_CLUSTER", 0);
+    if (knob == 1 || pairs <= 0) return 1;
+    int G = 1;
+    if (knob >= 2) {
+        G = knob < kClusterMax ? knob : kClusterMax;
+        while (G > 1 && (pairs * G > 128 || N < 64 * G)) --G;
+    } else if (pairs <= 32 && N >= 16384) {
+        G = kClusterMax;
+        while (G > 1 && (pairs * G > 128 || N / G < 2048)) G >>= 1;
+    }
+    return G;
+}
+static int cluster_region(int G, int N) { const int per = (N + G - 1) / G; return per < kBandCap ? per : kBandCap; }
+static size_t cluster_ctl_bytes(int pairs) { return align16((size_t)pairs * kClCtlWords * sizeof(unsigned)); }
+static size_t cluster_bytes(int pairs, int G, int N)
+{
+    if (G <= 1) return 0;
+    return cluster_ctl_bytes(pairs) + align16((size_t)pairs * G * cluster_region(G, N) * sizeof(unsigned long long));
+}
+
 template <bool DECODE>
 static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hipStream_t stream)
 {
@@ -943,20 +1236,31 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     if (L.total > kLdsLimit)
         return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,
                     kLdsLimit);
+    const size_t stage = stage_bytes(p.B, p.C, p.max_sel);
     if (p.C > 1) {
-        const size_t need = stage_bytes(p.B, p.C, p.max_sel);
-        if (!d_workspace || workspace_bytes < need)
-            return fail(RPN_ERR_WORKSPACE, "nms: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        if (!d_workspace || workspace_bytes < stage)
+            return fail(RPN_ERR_WORKSPACE, "nms: workspace of %zu bytes needed, %zu given", stage, workspace_bytes);
         p.stage_idx = reinterpret_cast<int *>(d_workspace);
         p.stage_cnt = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(d_workspace) +
                                               align16((size_t)p.B * p.C * p.max_sel * sizeof(int)));
+    }
+    // cluster mode needs its own scratch behind the staging area; a caller that passes less simply gets one workgroup per
+    // pair (same results, the passes over the scores are not shared)
+    p.cluster = cluster_size(p.B * p.C, p.N);
+    if (p.cluster > 1 && (!d_workspace || workspace_bytes < stage + cluster_bytes(p.B * p.C, p.cluster, p.N))) p.cluster = 1;
+    if (p.cluster > 1) {
+        unsigned char *base = reinterpret_cast<unsigned char *>(d_workspace) + stage;
+        p.cl_ctl = reinterpret_cast<unsigned *>(base);
+        p.cl_band = reinterpret_cast<unsigned long long *>(base + cluster_ctl_bytes(p.B * p.C));
+        p.cl_region = cluster_region(p.cluster, p.N);
+        RPN_HIP_CHECK(hipMemsetAsync(p.cl_ctl, 0, cluster_ctl_bytes(p.B * p.C), stream));   // counters + the two histograms
     }
     auto kern = nms_kernel<DECODE>;
     {   // the dynamic-LDS ceiling of a function only ever has to grow: set once per (device, size), not on every launch
         static DynLdsCeiling ceiling;
         RPN_HIP_CHECK(ceiling.raise(reinterpret_cast<const void *>(kern), L.total));
     }
-    hipLaunchKernelGGL(kern, dim3(p.B * p.C), dim3(kNmsThreads), L.total, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.B * p.C * p.cluster), dim3(kNmsThreads), L.total, stream, p);
     RPN_CHECK_LAUNCH();
     if (p.C > 1) {
         const int n_merge = next_pow2(p.C * p.max_sel);
@@ -979,10 +1283,9 @@ using namespace rpn;
 
 extern "C" size_t rpn_nms_workspace_bytes(int B, int N, int C, int max_per_class, int max_total)
 {
-    (void)N;
     (void)max_total;
-    if (B <= 0 || C <= 1 || max_per_class <= 0) return 0;
-    return stage_bytes(B, C, max_per_class);
+    if (B <= 0 || C < 1 || max_per_class <= 0) return 0;
+    return stage_bytes(B, C, max_per_class) + cluster_bytes(B * C, cluster_size(B * C, N), N);
 }
 
 extern "C" int rpn_combined_nms(const float *d_boxes, const float *d_scores, int B, int N, int q, int C,

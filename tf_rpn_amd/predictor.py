@@ -54,6 +54,10 @@ class Proposer(object):
         self._valid = torch.zeros((max_batch,), dtype=torch.int32, device=dev)
         _keep, self._vptr = L.host_floats(self.variances)
         self._vkeep = _keep
+        # NMS scratch (rpn_nms_workspace_bytes): non-zero for few images with many anchors, where several workgroups per
+        # image share the passes over the scores.  One buffer: a Proposer's NMS launches are ordered on one stream.
+        self._nms_ws_bytes = int(L.lib().rpn_nms_workspace_bytes(self.max_batch, self.total_anchors, 1, M, M))
+        self._nms_ws = torch.empty((max(self._nms_ws_bytes, 16),), dtype=torch.uint8, device=dev)
         # optional 2-stage pipeline across batches: the NMS of batch k (one workgroup per image: 8 of 256 CUs)
         # runs on a side stream while the conv stack of batch k+1 runs on the main stream.  Head outputs and
         # proposal buffers are double buffered; ordering is by HIP events only (no host synchronisation).
@@ -90,6 +94,15 @@ class Proposer(object):
         self.rpn_model.forward_into(imgs, reg, cls)                           # predictor.py:50
         return reg.view(B, -1, 4), cls.view(B, -1)                             # predictor.py:52-53
 
+    def decode_nms(self, deltas, scores, B, ob, osc, oi, ov):
+        """Fused ``deltas *= variances`` -> decode -> NMS(topn) of (B,A,4) / (B,A) head outputs on the current stream
+        (predictor.py:55-56 + utils/bbox_utils.py:48-70 -> rpn_decode_nms)."""
+        st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(deltas), self._vptr, L.ptr(scores), B,
+                                    self.total_anchors, self.topn, self.iou_threshold, self.score_threshold, 1,
+                                    L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.ptr(self._nms_ws), self._nms_ws_bytes,
+                                    L.stream_ptr())
+        L.check(st, "rpn_decode_nms")
+
     def _check_imgs(self, imgs):
         """The C side only sees a raw pointer: refuse anything that is not a contiguous CUDA float32
         (B, img_size, img_size, 3) batch with B <= max_batch (a wrong dtype / layout would be read out of bounds)."""
@@ -110,10 +123,7 @@ class Proposer(object):
         B = int(imgs.shape[0])
         deltas, scores = self.forward(imgs)
         ob, osc, oi, ov = self._boxes[:B], self._scores[:B], self._idx[:B], self._valid[:B]
-        st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(deltas), self._vptr, L.ptr(scores), B,
-                                    self.total_anchors, self.topn, self.iou_threshold, self.score_threshold, 1,
-                                    L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr())
-        L.check(st, "rpn_decode_nms")
+        self.decode_nms(deltas, scores, B, ob, osc, oi, ov)
         return ob, osc, ov, oi
 
     def propose_async(self, imgs):
@@ -143,11 +153,7 @@ class Proposer(object):
                     buf["go"] = torch.cuda.Event()
                 buf["go"].record(self._nms_stream)
                 self._nms_go = buf["go"]
-            st = L.lib().rpn_decode_nms(L.ptr(self.anchors), L.ptr(reg.view(B, -1, 4)), self._vptr,
-                                        L.ptr(cls.view(B, -1)), B, self.total_anchors, self.topn, self.iou_threshold,
-                                        self.score_threshold, 1, L.ptr(ob), L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0,
-                                        L.stream_ptr())
-            L.check(st, "rpn_decode_nms")
+            self.decode_nms(reg.view(B, -1, 4), cls.view(B, -1), B, ob, osc, oi, ov)
             buf["nms_done"].record(self._nms_stream)
         buf["used"] = True
         self._last = buf

@@ -195,9 +195,11 @@ def decode_and_nms(anchors, deltas, scores, variances, max_total_size, iou_thres
     if variances is not None:
         _keep, vptr = L.host_floats(variances)
     if B > 0 and M > 0:
+        ws_bytes = int(L.lib().rpn_nms_workspace_bytes(B, A, 1, M, M))
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device="cuda")
         st = L.lib().rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, M, float(iou_threshold),
                                     float(score_threshold), int(bool(clip_boxes)), L.ptr(out_boxes),
-                                    L.ptr(out_scores), L.ptr(out_idx), L.ptr(out_valid), ctypes.c_void_p(0), 0,
+                                    L.ptr(out_scores), L.ptr(out_idx), L.ptr(out_valid), L.ptr(ws), ws_bytes,
                                     L.stream_ptr())
         L.check(st, "decode_and_nms")
     return tuple(L.from_device(t, was_np) for t in (out_boxes, out_scores, out_idx, out_valid))
