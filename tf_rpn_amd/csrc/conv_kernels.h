@@ -89,6 +89,19 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
                               const void *we, const float *be, const float *wd, const float *bd, const void *wp,
                               const float *bp, float scale_e, float scale_p, float *out, unsigned *status, hipStream_t s);
 
+// f16x3 variant of the high-resolution blocks 1-3 (Cin = 16 / 24; mnv2_block_kernels.hip: ir_block_hrx3_kernel): the
+// expand GEMM's K is zero-padded to one 32-deep step, so the fragment images are LARGER than the float32 matrices --
+// ir_hrx3_*_floats give their sizes in floats.
+bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual);
+size_t ir_hrx3_expand_floats(int cexp);
+size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride);
+void pack_ir_hrx3_expand(const float *w, int cin, int cexp, int stride, int shift, unsigned short *dst);
+void pack_ir_hrx3_project(const float *w, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst);
+hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
+                                int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
+                                const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
+                                hipStream_t s);
+
 // Device word into which the split-format writers launched from THIS host thread flag float16 range violations
 // (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.
 void set_range_status(unsigned *p);

@@ -1118,6 +1118,282 @@ ir_block_x3_kernel(IrX3Args a)
     }
 }
 
+// ---- f16x3 variant of the high-resolution blocks (blocks 1-3: Cin = 16 / 24) -------------------------------------------
+// ir_block_hr_kernel with both GEMMs on v_mfma_f32_16x16x32_f16 (hi + lo float16 operands, three MFMAs per product, float32
+// accumulation: the arithmetic of ir_block_x3_kernel).  rocprofv3 on the float32 form (profiles/r03_mn8_pmc.txt): the waves
+// spend 44-48 % of their life stalled at ISSUE and the matrix pipe is busy 30-35 % -- the float32 MFMA (32 cycles per
+// 16 x 16 x 4 step) shares the SIMD's issue with the depthwise's vector work.  Here
+//   * the expand GEMM's K = Cin (16 / 24) is one 32-deep step (zero-padded): 3 MFMAs of 16 cycles per 16 px x 16 channels
+//     instead of 4 / 6 of 32.  Its A operand -- the wave's halo pixels as hi / lo fragments -- is built ONCE from global
+//     memory (a lane = (pixel, 8 channels): two 16-byte loads) and stays in registers across the chunks: no input tile in LDS;
+//   * the depthwise (float32, vector ALU) splits its outputs into the projection's fragment-major A image (lane pairs
+//     exchange halves by DPP: one dword store per output);
+//   * the projection takes ceil(CE / 32) steps of 3 MFMAs per 16 x 16 block; B fragments of both GEMMs come straight from the
+//     host-packed fragment-major images in global memory (L2-resident: every workgroup reads the same few KB).
+// Same tiles (4 x 8 outputs, 256 threads, every wave in every phase, two barriers per chunk) and chunk sizes as the f32 form.
+struct IrHrX3Args {
+    const float *x;
+    float *out;
+    const u32x4 *we;      // [chunk][nb CE/16][hi|lo][64 lanes]: expand weights * 2^shift_e, K zero-padded to 32
+    const u32x4 *wp;      // [chunk][nb COUTP/16][ks][hi|lo][64 lanes]: projection weights * 2^shift_p, chunk rows padded to 32 ks
+    const float *be, *wd, *bd, *bp;
+    float scale_e, scale_p;
+    int B, H, W, OH, OW, pad, tiles_x, tiles_y;
+    unsigned *status;
+};
+
+template <int CIN, int CEXP, int CE, int COUT, int S, bool RES>
+__global__ void __launch_bounds__(HR_THREADS)
+ir_block_hrx3_kernel(IrHrX3Args a)
+{
+    constexpr int TH = 4, NPX = TH * HR_T;                               // 32 output pixels
+    constexpr int IH = (TH - 1) * S + 3, IW = (HR_T - 1) * S + 3, NH = IH * IW;
+    constexpr int MB = (NH + 15) / 16, MH = MB * 16, MBW = (MB + 3) / 4;
+    constexpr int SEP = CE + 4;
+    constexpr int NBE = CE / 16, NCHUNK = CEXP / CE;
+    constexpr int KSP = (CE + 31) / 32;                                  // projection k-steps per chunk
+    constexpr int COUTP = (COUT + 15) / 16 * 16, NBO = COUTP / 16, NJ = (NBO + 1) / 2;
+    constexpr int DG = CE == 16 ? 16 : (CE == 32 ? 8 : 4);               // depthwise pixel groups
+    constexpr int PXG = NPX / DG;                                         // output pixels per depthwise thread
+    constexpr int DROWS = PXG <= HR_T ? 1 : PXG / HR_T, DCOLS = PXG <= HR_T ? PXG : HR_T;
+    static_assert(CIN % 8 == 0 && CIN <= 32 && SEP % 8 == 4 && CEXP % CE == 0 && CE % 16 == 0 && CE <= 48 && DG * CE <= HR_THREADS,
+                  "layout");
+    static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
+    __shared__ __attribute__((aligned(16))) float Es[MH * SEP];
+    __shared__ u32x4 DsF[2 * KSP * 2 * 64];                               // [mb 2][ks][hi|lo][lane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int img = t / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * HR_T;
+    const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;              // halo origin on the input grid
+    const int pmb = wave & 1, pnb0 = wave >> 1;                          // projection: M-block, first N-block (stride 2)
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * CIN;
+
+    // the padding channels of the last projection k-step (CE = 16 / 48) are never written by the depthwise: zero once
+    if constexpr (CE % 32 != 0)
+        for (int i = tid; i < 2 * KSP * 2 * 64; i += HR_THREADS) DsF[i] = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- A operand of the expand GEMM: this wave's halo pixels (M-blocks wave, wave + 4, ...) as hi / lo fragments ----------
+    u32x4 xh[MBW], xl[MBW];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int mbi = 0; mbi < MBW; ++mbi) {
+        const int m = (wave + 4 * mbi) * 16 + lr;
+        const int hy = m / IW, hx = m - hy * IW;
+        const int gy = gy0 + hy, gx = gx0 + hx;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (m < NH && 8 * lk < CIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(xin + ((size_t)gy * a.W + gx) * CIN + 8 * lk);
+            const float4 v1 = *reinterpret_cast<const float4 *>(xin + ((size_t)gy * a.W + gx) * CIN + 8 * lk + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
+        float mx = 0.0f;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mx = fmaxf(mx, fabsf(v[j]));
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+        if (a.status && !(mx <= 65504.0f)) atomicOr(a.status, 1u);       // (NaN included)
+        xh[mbi] = __builtin_bit_cast(u32x4, hi);
+        xl[mbi] = __builtin_bit_cast(u32x4, lo);
+        // which of this lane's expand OUTPUTS (rows 4 lk + i of the M-block) are pixels inside the image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mo = (wave + 4 * mbi) * 16 + 4 * lk + i;
+            const int oy = mo / IW, ox = mo - oy * IW;
+            if (mo < NH && gy0 + oy >= 0 && gy0 + oy < a.H && gx0 + ox >= 0 && gx0 + ox < a.W) vmask |= 1u << (mbi * 4 + i);
+        }
+    }
+    const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
+    const int dy0 = (dg * PXG) / HR_T, dx0 = (dg * PXG) % HR_T;
+    f32x4 pacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        // ---- E(c): (halo pixels x 32) * We[:, chunk] -> * 2^-shift + bias, ReLU6, zero outside the image -> Es ------------
+        {
+            u32x4 wh[NBE], wl[NBE];
+            float be_r[NBE];
+#pragma unroll
+            for (int nb = 0; nb < NBE; ++nb) {
+                wh[nb] = a.we[((size_t)(c * NBE + nb) * 2 + 0) * 64 + lane];
+                wl[nb] = a.we[((size_t)(c * NBE + nb) * 2 + 1) * 64 + lane];
+                be_r[nb] = a.be[c * CE + nb * 16 + lr];
+            }
+#pragma unroll
+            for (int mbi = 0; mbi < MBW; ++mbi) {
+                const int mb = wave + 4 * mbi;
+                if (MB % 4 == 0 || mb < MB) {
+#pragma unroll
+                    for (int nb = 0; nb < NBE; ++nb) {
+                        const f32x4 e = mfma_x3(xh[mbi], xl[mbi], wh[nb], wl[nb], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            Es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
+                                ((vmask >> (mbi * 4 + i)) & 1u) ? relu6f(e[i] * a.scale_e + be_r[nb]) : 0.0f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- D(c): depthwise 3x3 + bias + ReLU6 (float32), hi / lo float16 into the projection's A image ---------------------
+        if (dg < DG) {
+            float wd_r[10];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wd_r[k] = a.wd[(size_t)k * CEXP + c * CE + dc];
+            wd_r[9] = a.bd[c * CE + dc];
+            unsigned *dw32 = reinterpret_cast<unsigned *>(DsF);
+            const int ks = dc >> 5, kq = (dc >> 3) & 3, jp = (dc & 7) >> 1, odd = dc & 1;
+#pragma unroll
+            for (int ry = 0; ry < DROWS; ++ry) {
+                const int py = dy0 + ry;
+                constexpr int WW = (DCOLS - 1) * S + 3;
+                float win[3][WW];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < WW; ++x) win[r][x] = Es[((py * S + r) * IW + dx0 * S + x) * SEP + dc];
+#pragma unroll
+                for (int px = 0; px < DCOLS; ++px) {
+                    float acc = wd_r[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_r[r * 3 + q], acc);
+                    const float v = relu6f(acc);
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const unsigned hu = __builtin_bit_cast(unsigned short, h), lu = __builtin_bit_cast(unsigned short, l);
+                    // lanes (2t, 2t+1) = channels (2t, 2t+1): the even lane writes the pair's hi dword, the odd lane its lo dword
+                    const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
+                    const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
+                    const int p = py * HR_T + dx0 + px;
+                    dw32[(((p >> 4) * KSP + ks) * 2 + odd) * 256 + (kq * 16 + (p & 15)) * 4 + jp] = word;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P(c): acc (16 px of M-block pmb x COUT) += D (16 x CE) * Wp[chunk] ---------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+            const u32x4 dhi = DsF[((pmb * KSP + ks) * 2 + 0) * 64 + lane], dlo = DsF[((pmb * KSP + ks) * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = pnb0 + 2 * j;
+                if (NBO % 2 == 0 || nb < NBO) {
+                    const size_t blk = (((size_t)c * NBO + nb) * KSP + ks) * 2;
+                    pacc[j] = mfma_x3(dhi, dlo, a.wp[blk * 64 + lane], a.wp[(blk + 1) * 64 + lane], pacc[j]);
+                }
+            }
+        }
+        // (the next chunk's E writes Es, its D writes DsF behind the barrier after E: P(c) has read DsF by then -- every wave
+        // passes that barrier only after its own P(c))
+    }
+    // ---- * 2^-shift + bias (+ the block input) -> NHWC ---------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nb = pnb0 + 2 * j;
+        const int co = nb * 16 + lr;
+        if ((NBO % 2 == 0 || nb < NBO) && co < COUT) {
+            const float bias = a.bp[co];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = pmb * 16 + 4 * lk + i;
+                const int py = p >> 3, px = p & 7;
+                const int oy = oy0 + py, ox = ox0 + px;
+                if (oy < a.OH && ox < a.OW) {
+                    float v = pacc[j][i] * a.scale_p + bias;
+                    if constexpr (RES) v += xin[((size_t)oy * a.W + ox) * CIN + co];      // (L2-hot: this tile just read it)
+                    a.out[(((size_t)img * a.OH + oy) * a.OW + ox) * COUT + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// chunk size (expanded channels per step) of the high-resolution f16x3 blocks: the f32 form's
+static int ir_hrx3_ce(int cin, int stride) { return (cin == 24 && stride == 1) ? 48 : 16; }
+
+bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual)
+{
+    return (cin == 16 && cexp == 96 && cout == 24 && stride == 2 && !residual) ||
+           (cin == 24 && cexp == 144 && cout == 24 && stride == 1 && residual) ||
+           (cin == 24 && cexp == 144 && cout == 32 && stride == 2 && !residual);
+}
+
+size_t ir_hrx3_expand_floats(int cexp) { return (size_t)32 * cexp; }                      // K padded to 32: CEXP x 128 bytes
+size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride)
+{
+    const int ce = ir_hrx3_ce(cin, stride), ksp = (ce + 31) / 32, nbo = (cout + 15) / 16;
+    return (size_t)(cexp / ce) * nbo * ksp * 2 * 64 * 4;
+}
+
+void pack_ir_hrx3_expand(const float *w /* [cin][cexp] */, int cin, int cexp, int stride, int shift, unsigned short *dst)
+{
+    const int CE = ir_hrx3_ce(cin, stride), NBE = CE / 16;
+    const float mul = ldexpf(1.0f, shift);
+    for (int c = 0; c < cexp / CE; ++c)
+        for (int nb = 0; nb < NBE; ++nb)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * (ln >> 4) + j, n = c * CE + nb * 16 + (ln & 15);
+                    const float v = k < cin ? w[(size_t)k * cexp + n] * mul : 0.0f;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const size_t blk = (size_t)(c * NBE + nb) * 2;
+                    memcpy(dst + (blk * 64 + ln) * 8 + j, &h, 2);
+                    memcpy(dst + ((blk + 1) * 64 + ln) * 8 + j, &l, 2);
+                }
+}
+
+void pack_ir_hrx3_project(const float *w /* [cexp][coutp] */, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst)
+{
+    const int CE = ir_hrx3_ce(cin, stride), KSP = (CE + 31) / 32, coutp = (cout + 15) / 16 * 16, NBO = coutp / 16;
+    const float mul = ldexpf(1.0f, shift);
+    for (int c = 0; c < cexp / CE; ++c)
+        for (int nb = 0; nb < NBO; ++nb)
+            for (int ks = 0; ks < KSP; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = 32 * ks + 8 * (ln >> 4) + j, n = nb * 16 + (ln & 15);
+                        const float v = kk < CE ? w[(size_t)(c * CE + kk) * coutp + n] * mul : 0.0f;
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)(v - (float)h);
+                        const size_t blk = (((size_t)c * NBO + nb) * KSP + ks) * 2;
+                        memcpy(dst + (blk * 64 + ln) * 8 + j, &h, 2);
+                        memcpy(dst + ((blk + 1) * 64 + ln) * 8 + j, &l, 2);
+                    }
+}
+
+hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
+                                int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
+                                const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
+                                hipStream_t s)
+{
+    if (!ir_block_hrx3_supported(cin, cexp, cout, stride, residual)) return hipErrorInvalidValue;
+    IrHrX3Args a{};
+    a.x = x; a.out = out; a.we = reinterpret_cast<const u32x4 *>(we); a.wp = reinterpret_cast<const u32x4 *>(wp);
+    a.be = be; a.wd = wd; a.bd = bd; a.bp = bp; a.scale_e = scale_e; a.scale_p = scale_p;
+    a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.pad = pad; a.status = status;
+    a.tiles_x = (OW + HR_T - 1) / HR_T;
+    a.tiles_y = (OH + 3) / 4;
+    const long long nb = (long long)a.tiles_x * a.tiles_y * B;
+    if (nb <= 0 || nb > 0x7fffffffll) return hipErrorInvalidValue;
+    if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 48, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 16, 32, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
 bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
     if (stride != 1 || cexp != 6 * cin) return false;

@@ -68,6 +68,7 @@ struct Op {
     int ir_pad = 0;                    // top/left padding of the depthwise (stem: of Conv1)
     size_t ir_off[6] = {0, 0, 0, 0, 0, 0};   // we, be, wd, bd, wp, bp (floats into the weight blob)
     bool ir_x3 = false;                // F16X3 only: the block's two GEMMs on the 16-bit MFMA (hi + lo float16 operands)
+    bool ir_hrx3 = false;              // ... the high-resolution form (blocks 1-3: ir_block_hrx3_kernel; implies ir_x3)
     float ir_scale[2] = {1.0f, 1.0f};  // ... 2^-shift of the pre-scaled expand / projection weights
     // OP_VGGB1 (VGG16 block 1 in one launch) reuses ir_off[0..3] = w1, b1, w2, b2 and ir_scale[0..1] = the two 2^-shift
 };
@@ -311,6 +312,9 @@ static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, 
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = ACT_LINEAR;
     op.ir_x3 = m->f16 && !stem && ir_block_x3_supported(ti.C, cexp, cout, stride, res) &&
                (RPN_KNOB("RPN_MN_X3", 1) != 0);
+    op.ir_hrx3 = m->f16 && !stem && ir_block_hrx3_supported(ti.C, cexp, cout, stride, res) &&
+                 (RPN_KNOB("RPN_MN_X3", 1) != 0) && (RPN_LAB_KNOB("RPN_MN_HRX3", 1) != 0);
+    if (op.ir_hrx3) op.ir_x3 = true;
     op.out = add_tensor(m, name, OH, OW, cout);
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
@@ -496,8 +500,12 @@ static void plan_weights(rpn_model *m)
             }
         } else if (op.kind == OP_IRBLOCK) {
             const size_t kp = op.ir_stem ? 28 : (size_t)op.Cin, coutp = ((size_t)op.Cout + 15) / 16 * 16;
-            const size_t sizes[6] = {kp * op.cexp, (size_t)op.cexp, (size_t)9 * op.cexp, (size_t)op.cexp,
-                                     (size_t)op.cexp * coutp, coutp};
+            size_t sizes[6] = {kp * op.cexp, (size_t)op.cexp, (size_t)9 * op.cexp, (size_t)op.cexp,
+                               (size_t)op.cexp * coutp, coutp};
+            if (op.ir_hrx3) {                                             // zero-padded fragment images: larger than the matrices
+                sizes[0] = ir_hrx3_expand_floats(op.cexp);
+                sizes[4] = ir_hrx3_project_floats(op.Cin, op.cexp, op.Cout, op.stride);
+            }
             op.w_off = off;
             for (int i = 0; i < 6; ++i) {
                 op.ir_off[i] = off;
@@ -678,7 +686,13 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             w.resize(rows * p.Cout);
             for (size_t k = 0; k < rows; ++k)
                 for (int n = 0; n < p.Cout; ++n) w[k * p.Cout + n] = kernel[k * p.Cout + n] * scale[n];
-            if (op.ir_x3) {                                // hi + lo float16 fragments, same byte count
+            if (op.ir_hrx3) {
+                const int sh = split_weight_shift(w.data(), w.size(), true);
+                std::vector<float> packed(ir_hrx3_expand_floats(p.Cout));
+                pack_ir_hrx3_expand(w.data(), p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                w.swap(packed);
+                op.ir_scale[0] = ldexpf(1.0f, -sh);
+            } else if (op.ir_x3) {                         // hi + lo float16 fragments, same byte count
                 const int sh = split_weight_shift(w.data(), w.size(), true);
                 std::vector<float> packed(w.size());
                 pack_ir_x3_expand(w.data(), p.Cin, p.Cout, sh, reinterpret_cast<unsigned short *>(packed.data()));
@@ -696,7 +710,13 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             w.assign((size_t)p.Cin * coutp, 0.0f);
             for (int k = 0; k < p.Cin; ++k)
                 for (int n = 0; n < p.Cout; ++n) w[(size_t)k * coutp + n] = kernel[(size_t)k * p.Cout + n] * scale[n];
-            if (op.ir_x3) {                                // (Cout % 16 == 0 for these blocks: coutp == Cout)
+            if (op.ir_hrx3) {
+                const int sh = split_weight_shift(w.data(), w.size(), true);
+                std::vector<float> packed(ir_hrx3_project_floats(op.Cin, p.Cin, p.Cout, op.stride));
+                pack_ir_hrx3_project(w.data(), op.Cin, p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                w.swap(packed);
+                op.ir_scale[1] = ldexpf(1.0f, -sh);
+            } else if (op.ir_x3) {                         // (Cout % 16 == 0 for these blocks: coutp == Cout)
                 const int sh = split_weight_shift(w.data(), w.size(), true);
                 std::vector<float> packed(w.size());
                 pack_ir_x3_project(w.data(), p.Cin, p.Cout, sh, reinterpret_cast<unsigned short *>(packed.data()));
@@ -905,7 +925,12 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                                   wb + op.ir_off[3], op.ir_scale[1], tensor_ptr(m, op.out, d_imgs), B, op.H, op.W, m->f16, s);
         } else if (op.kind == OP_IRBLOCK) {
             const float *wb = m->d_weights;
-            if (op.ir_x3)
+            if (op.ir_hrx3)
+                e = launch_ir_block_hrx3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_pad, op.OH, op.OW,
+                                         wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
+                                         wb + op.ir_off[4], wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1],
+                                         tensor_ptr(m, op.out, d_imgs), m->d_status, s);
+            else if (op.ir_x3)
                 e = launch_ir_block_x3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.ir_res, wb + op.ir_off[0],
                                        wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3], wb + op.ir_off[4],
                                        wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1], tensor_ptr(m, op.out, d_imgs),
@@ -1039,7 +1064,7 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         by = in_b + out_b + 4.0 * (kin * op.cexp + 10.0 * op.cexp + (double)op.cexp * op.Cout + op.Cout);
         static thread_local char kir[64];
         if (op.ir_stem) snprintf(kir, sizeof kir, "ir_block<stem,32,16,s1>");
-        else snprintf(kir, sizeof kir, "ir_block%s<%d,%d,%d,s%d%s>", op.ir_x3 ? "_f16x3" : "", op.Cin, op.cexp, op.Cout, op.stride,
+        else snprintf(kir, sizeof kir, "ir_block%s<%d,%d,%d,s%d%s>", op.ir_hrx3 ? "_hr_f16x3" : (op.ir_x3 ? "_f16x3" : ""), op.Cin, op.cexp, op.Cout, op.stride,
                       op.ir_res ? ",res" : "");
         k = kir;
     } else if (op.kind == OP_DWCONV) {

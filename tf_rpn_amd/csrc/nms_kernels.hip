@@ -71,7 +71,8 @@ constexpr int kChunkWords = kChunk / 64;
 __device__ __forceinline__ int cslot2(int jj, int piece) { return (jj << 4) | (piece ^ (jj & 12)); }
 __device__ __forceinline__ int cslot(int j) { return cslot2(j & 15, j >> 4); }
 constexpr size_t kLdsLimit = 160 * 1024;
-constexpr int kLoadBatch = 8;          // score loads in flight per thread in the passes over all N scores
+constexpr int kLoadBatch = 9;          // score loads in flight per thread in the passes over all N scores (9 x 1024 threads cover the 8649 / 9216 anchors of one 500 x 500 image in one round)
+constexpr int kScoreCacheMax = 16384;  // scores per (image, class) pair that the LDS cache may hold          // score loads in flight per thread in the passes over all N scores
 
 struct NmsArgs {
     const float *boxes;      // (B,N,q,4)            [plain]   | deltas (B,N,4) [decode]
@@ -98,6 +99,7 @@ struct NmsArgs {
     int linear_select;       // band threshold by the one-pass linear histogram first (RPN_NMS_LINEAR=0: radix select only)
     // cluster mode (few images, many candidates): `cluster` workgroups per (image, class) share the passes over the scores
     // of the FIRST band; cl_ctl / cl_band: the cluster workspace (cluster_layout), zeroed control part
+    int cache_n;             // scores of a pair cached in LDS after the first pass (0: none; >= N when granted)
     int cluster, cl_region;
     unsigned *cl_ctl;
     unsigned long long *cl_band;
@@ -187,42 +189,67 @@ __device__ __forceinline__ unsigned long long make_key(float s, float thr, int i
 // threshold score d / 2048 (exact in float; score >= d / 2048 <=> floor(score * 2048) >= d), i.e. the key threshold
 // orderable(d / 2048) << 32.  Returns false -- caller falls back to the radix select -- when that bin holds more than
 // the band may take, or is bin 0 (which also collects the scores below 0).  hist: 2048 words; ctl: 4 ints.
-// wave 0: the bin where the count from the top bin down reaches `want` -> ctl[0] (-1: no keys at all, -2: fewer than
-// `want` in all), ctl[1] = keys in the bins >= it (or the total).  Lane l owns bins 2047 - 32 l .. - 31.
-__device__ __forceinline__ void linear_hist_find(const unsigned *hist, int want, int *ctl)
+// All threads: exclusive suffix sums of the 2048 counts, top bin first (sfx[b] = keys in the bins above b; thread t owns bins
+// 2047 - 2t and 2046 - 2t: a wave scan + 16 wave totals), and the bin where the count from the top reaches `want` ->
+// ctl[0] (-1: no keys at all, -2: fewer than `want` in all), ctl[1] = keys in the bins >= it (or the total).  `scan`: 17
+// words of LDS.  The caller puts a barrier behind it.  band_order_linear takes its segment offsets from the same `sfx`.
+// (First version: wave 0 alone, lane l summing bins 2047 - 32 l .. serially -- 64 lanes on one LDS bank -- ~4 k cycles.)
+__device__ __forceinline__ void hist_suffix_find(const unsigned *h, unsigned *sfx, int want, int *ctl, unsigned *scan)
 {
-    constexpr int NB = 2048;
-    const int tid = fresh_tid(), lane = tid & 63;
-    if (tid < 64) {
-        constexpr int per = NB / 64;
-        const int top = NB - 1 - lane * per;
-        unsigned mine = 0u;
-        for (int k = 0; k < per; ++k) mine += hist[top - k];
-        unsigned incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        const unsigned total = __shfl(incl, 63, 64);
-        const unsigned excl = incl - mine;
-        const bool cross = (int)excl < want && (int)incl >= want;
-        const unsigned long long bal = __ballot(cross);
-        if (total == 0u) {
-            if (lane == 0) { ctl[0] = -1; ctl[1] = 0; }
-        } else if (bal == 0ull) {           // fewer than `want` keys in all: take everything
-            if (lane == 0) { ctl[0] = -2; ctl[1] = (int)total; }
-        } else if (cross) {
-            unsigned run = excl;
-            int d = top;
-            for (int k = 0; k < per; ++k) {
-                d = top - k;
-                run += hist[d];
-                if ((int)run >= want) break;
-            }
-            ctl[0] = d;
-            ctl[1] = (int)run;              // keys in bins >= d
-        }
+    const int tid = fresh_tid(), lane = tid & 63, wave = tid >> 6;
+    const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
+    const unsigned c0 = h[b0], c1 = h[b1];
+    unsigned incl = c0 + c1;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
+    if (lane == 63) scan[wave] = incl;
+    __syncthreads();
+    unsigned wpre = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned v = scan[w];
+        total += v;
+        if (w < wave) wpre += v;
+    }
+    const unsigned excl = wpre + incl - (c0 + c1);
+    sfx[b0] = excl;
+    sfx[b1] = excl + c0;
+    if (total == 0u) {
+        if (tid == 0) { ctl[0] = -1; ctl[1] = 0; }
+    } else if ((int)total < want) {         // fewer than `want` keys in all: take everything
+        if (tid == 0) { ctl[0] = -2; ctl[1] = (int)total; }
+    } else if ((int)excl < want && (int)(excl + c0) >= want) {
+        ctl[0] = b0;
+        ctl[1] = (int)(excl + c0);          // keys in bins >= b0
+    } else if ((int)(excl + c0) < want && (int)(excl + c0 + c1) >= want) {
+        ctl[0] = b1;
+        ctl[1] = (int)(excl + c0 + c1);
+    }
+}
+
+// The scores of one (image, class) pair as the passes read them: from global memory (stride C), or -- once the first
+// pass over all of them has copied them there -- from an LDS cache (p.cache_n scores; the host grants it when they fit:
+// N <= 16 384 beside the kernel's other LDS).  A pass by one workgroup runs at one compute unit's memory-level parallelism
+// (~7 B / clk: 5 k cycles for 8649 scores, NOTES.md); every pass after the first then costs LDS latency instead.
+// Global reads go through a raw buffer descriptor (4 scalar registers) with a 32-bit byte offset: a plain pointer costs
+// each read loop a loop-invariant 64-bit address pair per thread, which the register allocator parks in scratch.
+struct ScoreSrc {
+    __amdgpu_buffer_rsrc_t rs;   // the pair's scores: N floats at a stride of C
+    int stride_bytes;            // 4 * C
+    float *cache;                // null: no cache
+    bool cached;                 // the cache has been filled
+    __device__ __forceinline__ float operator()(int i) const
+    {
+        return cached ? cache[i] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride_bytes, 0, 0));
+    }
+};
+__device__ __forceinline__ ScoreSrc make_score_src(const float *g, int N, int C, float *cache)
+{
+    const long long bytes = (long long)N * C * 4;
+    return ScoreSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g), (short)0, (int)(bytes > 0x7fffffffll ? 0x7fffffff : bytes), 0x00020000),
+                    4 * C, cache, false};
 }
 
 __device__ __forceinline__ int linear_bin(float s) { return (int)fminf(fmaxf(s * 2048.0f, 0.0f), 2047.0f); }
@@ -230,7 +257,7 @@ __device__ __forceinline__ int linear_bin(float s) { return (int)fminf(fmaxf(s *
 // power-of-two scale); the threshold score of sub-bin k is (2048 d + k) / 2^22
 __device__ __forceinline__ int linear_sub_bin(float s, int d) { return (int)fminf(fmaxf((s * 2048.0f - (float)d) * 2048.0f, 0.0f), 2047.0f); }
 
-__device__ inline bool band_select_linear(const float *__restrict__ sc, int C, int N, float score_thr,
+__device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
                                           unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
                                           unsigned long long *thr_out, int *count, int *bin_out)
 {
@@ -239,11 +266,17 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
     // hist[0, 2048): the bins; hist[2048, 4096): the 2048 sub-bins of the TOP bin, filled in the same pass -- a saturated
     // sigmoid puts most of a head's 61 440 scores there, and the refinement below then needs no pass of its own
     for (int i = tid; i < 2 * NB; i += kNmsThreads) hist[i] = 0u;
+    const bool fill = sc.cache != nullptr && !sc.cached;          // this pass also copies the scores into the LDS cache
     __syncthreads();
     for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
         float sb[kLoadBatch];
 #pragma unroll
-        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc(base + u * kNmsThreads) : NAN;
+        if (fill) {
+#pragma unroll
+            for (int u = 0; u < kLoadBatch; ++u)
+                if (base + u * kNmsThreads < N) sc.cache[base + u * kNmsThreads] = sb[u];
+        }
 #pragma unroll
         for (int u = 0; u < kLoadBatch; ++u) {
             const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);     // 0 for NaN / below threshold
@@ -255,7 +288,8 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
         }
     }
     __syncthreads();
-    linear_hist_find(hist, want, ctl);
+    if (fill) sc.cached = true;
+    hist_suffix_find(hist, hist + 4096, want, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
     __syncthreads();
     const int d = ctl[0], n = ctl[1];
     const int in_d = d > 0 ? (int)hist[d] : 0;
@@ -281,7 +315,7 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
         for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
             float sb[kLoadBatch];
 #pragma unroll
-            for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+            for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc(base + u * kNmsThreads) : NAN;
 #pragma unroll
             for (int u = 0; u < kLoadBatch; ++u) {
                 const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
@@ -291,7 +325,7 @@ __device__ inline bool band_select_linear(const float *__restrict__ sc, int C, i
         __syncthreads();
         sub = hist;
     }
-    linear_hist_find(sub, want - above, ctl);
+    hist_suffix_find(sub, hist + 4096, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
     __syncthreads();
     const int d2 = ctl[0], n2 = ctl[1];
     __syncthreads();
@@ -311,14 +345,14 @@ __device__ __forceinline__ float key_score(unsigned long long key)            //
 
 // the band's keys by a scan of all N scores (8 loads in flight per thread)
 template <class Fn>
-__device__ __forceinline__ void scan_band_keys(const float *__restrict__ sc, int C, int N, float score_thr, unsigned long long thr,
+__device__ __forceinline__ void scan_band_keys(const ScoreSrc &sc, int N, float score_thr, unsigned long long thr,
                                                unsigned long long hi_bound, Fn fn)
 {
     const int tid = fresh_tid();
     for (int base = tid; base < N; base += 8 * kNmsThreads) {
         float sb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+        for (int u = 0; u < 8; ++u) sb[u] = (base + u * kNmsThreads < N) ? sc(base + u * kNmsThreads) : NAN;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
@@ -331,7 +365,7 @@ __device__ __forceinline__ void scan_band_keys(const float *__restrict__ sc, int
 // to positions [off(b), off(b) + count(b)), off(b) = keys in the bins above b (a suffix scan over the 2048 counts); inside
 // a bin (4 keys on average at 8649 anchors) a key's place is the number of larger keys in its bin.  One pass over the
 // scores scatters the band's keys to their bins' segments (per-bin LDS cursors), a second step ranks inside the segments.
-// hist: [0,2048) counts (from band_select_linear), [2048,4096) offsets, [4096,6144) cursors, [6144,6161) scan scratch.
+// hist: [0,2048) counts (from band_select_linear), [4096,6144) offsets (hist_suffix_find), [6144,8192) cursors.
 // Returns false (nothing written) when a bin of the band holds more than 32 keys: the caller then sorts the old way.
 // `for_each_band_key(fn)`: calls fn(key) for this thread's share of the band's keys (every key exactly once over the
 // workgroup): a scan of all N scores, or -- cluster mode -- the list the cluster's ranks compacted into the workspace.
@@ -339,29 +373,18 @@ template <class ForEachKey>
 __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d, int n, unsigned *hist, unsigned long long *band,
                                          unsigned *order, unsigned long long *low_out)
 {
-    const int tid = fresh_tid(), lane = tid & 63, wave = tid >> 6;
-    unsigned *boff = hist + 2048, *cur = hist + 4096, *scratch = hist + 6144;
-    // suffix scan from the top bin: thread t owns bins 2047 - 2t and 2046 - 2t
+    const int tid = fresh_tid();
+    // segment offsets = the suffix sums hist_suffix_find left behind when it chose bin d (keys in the bins above b)
+    unsigned *boff = hist + 4096, *cur = hist + 6144;
+    unsigned *flag = hist + 2048;             // (the top bin's sub-bins are not needed any more)
     const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
-    const unsigned c0 = b0 >= d ? hist[b0] : 0u, c1 = b1 >= d ? hist[b1] : 0u;
-    unsigned incl = c0 + c1;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) scratch[wave] = incl;
-    if (tid == 0) scratch[16] = 0u;
+    if (tid == 0) *flag = 0u;
     cur[b0] = 0u;
     cur[b1] = 0u;
     __syncthreads();
-    unsigned wpre = 0u;
-    for (int w = 0; w < wave; ++w) wpre += scratch[w];
-    const unsigned excl = wpre + incl - (c0 + c1);
-    boff[b0] = excl;
-    boff[b1] = excl + c0;
-    if (c0 > 32u || c1 > 32u) atomicOr(&scratch[16], 1u);
+    if ((b0 >= d && hist[b0] > 32u) || (b1 >= d && hist[b1] > 32u)) atomicOr(flag, 1u);
     __syncthreads();
-    if (scratch[16] != 0u) return false;
+    if (*flag != 0u) return false;
     // scatter: the band's keys to their bins' segments
     for_each_band_key([&](unsigned long long key) {
         const int b = linear_bin(key_score(key));
@@ -475,7 +498,7 @@ __device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool
 // slice histograms (LDS, NH x 2048 words) -> + global -> barrier -> the cluster's sums back into LDS `hist`.
 // bin_of(score, &second): first bin (< 0: not counted) and, optionally, a second one in [2048, 4096) (< 0: none).
 template <int NH, class BinFn>
-__device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, unsigned *ghist, const float *__restrict__ sc, int C,
+__device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, unsigned *ghist, const ScoreSrc &sc,
                                                   int lo, int hi, float score_thr, unsigned *hist, int *flag, BinFn bin_of)
 {
     const int tid = fresh_tid();
@@ -484,7 +507,7 @@ __device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, u
     for (int base = lo + tid; base < hi; base += kLoadBatch * kNmsThreads) {
         float sb[kLoadBatch];
 #pragma unroll
-        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc(base + u * kNmsThreads) : NAN;
 #pragma unroll
         for (int u = 0; u < kLoadBatch; ++u) {
             if (sb[u] > score_thr) {                                         // (NaN: not a candidate)
@@ -512,21 +535,21 @@ __device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, u
 //      single-workgroup path from the start, the others leave;
 //   1: *thr_out / *count / *bin_out as band_select_linear would set them, and every rank has written its slice's band keys
 //      to its region (count in ctr[16 + g]); ranks other than the leader have arrived at barrier 2 and must leave.
-__device__ inline int cluster_first_band(const ClusterCtx &cl, const float *__restrict__ sc, int C, int N, float score_thr,
+__device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &sc, int N, float score_thr,
                                          int want, int cap, unsigned *hist, int *ctl, unsigned long long *lds_keys,
                                          unsigned long long *thr_out, int *count, int *bin_out NMS_SIDX_PARAM)
 {
     const int tid = fresh_tid(), lane = tid & 63;
     const int per = (N + cl.G - 1) / cl.G;
     const int lo = min(N, cl.g * per), hi = min(N, lo + per);
-    if (!cluster_histogram<2>(cl, 0, cl.hist, sc, C, lo, hi, score_thr, hist, ctl + 3, [](float s, int &second) {
+    if (!cluster_histogram<2>(cl, 0, cl.hist, sc, lo, hi, score_thr, hist, ctl + 3, [](float s, int &second) {
             const int bin = linear_bin(s);
             if (bin == 2047) second = 2048 + linear_sub_bin(s, 2047);
             return bin;
         }))
         return 0;
     NMS_STAMP(20);
-    linear_hist_find(hist, want, ctl);
+    hist_suffix_find(hist, hist + 4096, want, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
     __syncthreads();
     const int d = ctl[0], n = ctl[1];
     const int in_d = d > 0 ? (int)hist[d] : 0;
@@ -543,13 +566,13 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const float *__re
         const int above = n - in_d;
         const unsigned *sub = hist + 2048;
         if (d != 2047) {
-            if (!cluster_histogram<1>(cl, 1, cl.hist + 4096, sc, C, lo, hi, score_thr, hist, ctl + 3, [=](float s, int &) {
+            if (!cluster_histogram<1>(cl, 1, cl.hist + 4096, sc, lo, hi, score_thr, hist, ctl + 3, [=](float s, int &) {
                     return linear_bin(s) == d ? linear_sub_bin(s, d) : -1;
                 }))
                 return 0;
             sub = hist;
         }
-        linear_hist_find(sub, want - above, ctl);
+        hist_suffix_find(sub, hist + 4096, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
         __syncthreads();
         const int d2 = ctl[0], n2 = ctl[1];
         __syncthreads();
@@ -569,7 +592,7 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const float *__re
     for (int base = lo + tid; base < hi; base += kLoadBatch * kNmsThreads) {
         float sb[kLoadBatch];
 #pragma unroll
-        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc[(size_t)(base + u * kNmsThreads) * C] : NAN;
+        for (int u = 0; u < kLoadBatch; ++u) sb[u] = (base + u * kNmsThreads < hi) ? sc(base + u * kNmsThreads) : NAN;
 #pragma unroll
         for (int u = 0; u < kLoadBatch; ++u) {
             const unsigned long long key = make_key(sb[u], score_thr, base + u * kNmsThreads);
@@ -599,10 +622,10 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const float *__re
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 struct LdsLayout {
-    size_t band, hist, sel_c, sel_idx, cbox, mask, dead, picked, ctl, total;
+    size_t band, hist, sel_c, sel_idx, cbox, mask, dead, picked, ctl, scache, total;
 };
 
-__host__ __device__ inline LdsLayout lds_layout(int max_sel)
+__host__ __device__ inline LdsLayout lds_layout(int max_sel, int cache_n)
 {
     LdsLayout l;
     size_t o = 0;
@@ -618,13 +641,15 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel)
     l.mask = o;    o = align16(o + (size_t)8 * 64 * kChunkWords);       // [64 rows of the current group][4] u64
     l.dead = o;    o = align16(o + (size_t)8 * kChunkWords);            // 4 u64 words
     l.picked = o;  o = align16(o + (size_t)4 * kChunk);
-    l.ctl = o;     o = align16(o + 64);
+    l.ctl = o;     o = align16(o + 256);     // 64 ints: CTL_* | [16, 33) scan scratch | [36, 53) cluster prefix
+    l.scache = o;  o = align16(o + (size_t)4 * cache_n);
     l.total = o;
     return l;
 }
 
 // ctl words
-enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by radix_select */, CTL_LOW = 8 /* u64 */ };
+enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by the band selection (+ its scan scratch at
+       CTL_SEL + 12 .. + 28) */, CTL_LOW = 8 /* u64 */, CTL_CLPRE = 36 /* 17 ints: first key of each cluster rank's region */ };
 
 // Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the
 // first 64 workgroups, in program order (slot 0 = start; the probe knows the sequence).
@@ -636,7 +661,7 @@ nms_kernel(NmsArgs p)
     int nms_sidx = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(p.max_sel);
+    const LdsLayout L = lds_layout(p.max_sel, p.cache_n);
     unsigned long long *band = reinterpret_cast<unsigned long long *>(smem + L.band);
     unsigned *order = reinterpret_cast<unsigned *>(smem + L.band);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
@@ -658,8 +683,9 @@ nms_kernel(NmsArgs p)
     const int N = p.N, max_sel = p.max_sel;
     const float *__restrict__ sc = p.scores + (size_t)b * N * p.C + c;
     const int C = p.C;
+    ScoreSrc src = make_score_src(sc, N, C, p.cache_n >= N ? reinterpret_cast<float *>(smem + L.scache) : nullptr);
 
-    if (tid < 16) ctl[tid] = 0;
+    if (tid < 64) ctl[tid] = 0;
     for (int i = tid; i < max_sel + 32; i += kNmsThreads) {
         sel_c4[i] = float4{0.f, 0.f, 0.f, 0.f};
         sel_a[i] = INFINITY;
@@ -685,7 +711,7 @@ nms_kernel(NmsArgs p)
         if (p.linear_select) {
             const int band_target = min(kBandTarget, max(512, 3 * max_sel));
             const int band_cap = band_target <= 960 ? 1024 : kBandCap;
-            cl_state = cluster_first_band(cl, sc, C, N, p.score_thr, band_target, band_cap, hist, ctl + CTL_SEL, band, &cl_thr,
+            cl_state = cluster_first_band(cl, src, N, p.score_thr, band_target, band_cap, hist, ctl + CTL_SEL, band, &cl_thr,
                                           &cl_count, &cl_bin NMS_SIDX_ARG);
         }
         if (cl.g != 0) return;                 // the leader goes on alone (with the cluster's band, or from scratch)
@@ -716,10 +742,10 @@ nms_kernel(NmsArgs p)
             band_expected = cl_count;
             lin_bin = cl_bin;
         } else if (!p.linear_select ||
-            !band_select_linear(sc, C, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected,
+            !band_select_linear(src, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected,
                                 &lin_bin)) {
             lin_bin = -1;
-            thr = radix_select<kNmsThreads>([&](int i) { return make_key(sc[(size_t)i * C], p.score_thr, i); }, N, hi_bound,
+            thr = radix_select<kNmsThreads>([&](int i) { return make_key(src(i), p.score_thr, i); }, N, hi_bound,
                                             band_target, band_cap, hist, ctl + CTL_SEL, &band_expected);
         }
         thr = uniform_u64(thr);
@@ -730,14 +756,23 @@ nms_kernel(NmsArgs p)
         int band_n = 0;
         bool ordered = false;
         // cluster mode: key i of the band's list = key (i - first[r]) of rank r's region
-        auto cluster_key = [&](int i) {
-            int r = 0, first = 0;
-            for (; r + 1 < cl.G; ++r) {
-                const int cnt = (int)cl.ctr[16 + r];
-                if (i < first + cnt) break;
-                first += cnt;
+        if (from_cluster) {                  // ctl[CTL_CLPRE + r] = list position of rank r's first key
+            if (tid < 64) {
+                const int cnt = lane < cl.G ? (int)cl.ctr[16 + lane] : 0;
+                int incl = cnt;
+                for (int off = 1; off < kClusterMax; off <<= 1) {
+                    const int v = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += v;
+                }
+                if (lane < kClusterMax) ctl[CTL_CLPRE + lane] = incl - cnt;
             }
-            return cl.band[(size_t)r * cl.region + (i - first)];
+            __syncthreads();
+        }
+        auto cluster_key = [&](int i) {
+            int r = 0;
+#pragma unroll
+            for (int q = 1; q < kClusterMax; ++q) r += (q < cl.G && i >= ctl[CTL_CLPRE + q]) ? 1 : 0;   // regions are in list order
+            return cl.band[(size_t)r * cl.region + (i - ctl[CTL_CLPRE + r])];
         };
         if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
             if (from_cluster)
@@ -745,7 +780,7 @@ nms_kernel(NmsArgs p)
                                             lin_bin, band_expected, hist, band, order,
                                             reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             else
-            ordered = band_order_linear([&](auto fn) { scan_band_keys(sc, C, N, p.score_thr, thr, hi_bound, fn); },
+            ordered = band_order_linear([&](auto fn) { scan_band_keys(src, N, p.score_thr, thr, hi_bound, fn); },
                                         lin_bin, band_expected, hist, band, order,
                                         reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             if (ordered) {
@@ -766,7 +801,7 @@ nms_kernel(NmsArgs p)
 #pragma unroll
             for (int u = 0; u < kLoadBatch; ++u) {
                 const int i = base + u * kNmsThreads;
-                sb[u] = i < N ? sc[(size_t)i * C] : NAN;
+                sb[u] = i < N ? src(i) : NAN;
             }
 #pragma unroll
             for (int u = 0; u < kLoadBatch; ++u) {
@@ -1232,7 +1267,14 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     const bool fast = p.iou_thr >= 1e-6f && p.iou_thr <= 1e6f;
     p.iou_eps = fast ? p.iou_thr * 0x1p-18f : 0.0f;
     p.m0 = fast ? INFINITY : 0.0f;
-    const LdsLayout L = lds_layout(p.max_sel);
+    // LDS score cache: when the pair's scores fit beside the rest (and the first pass is the linear histogram's, by one
+    // workgroup: not in cluster mode, whose first pass is shared)
+    p.cache_n = 0;
+    p.cluster = cluster_size(p.B * p.C, p.N);
+    if (p.cluster > 1 && (!d_workspace || workspace_bytes < stage_bytes(p.B, p.C, p.max_sel) + cluster_bytes(p.B * p.C, p.cluster, p.N)))
+        p.cluster = 1;
+    if (p.linear_select && p.cluster == 1 && p.N <= kScoreCacheMax && lds_layout(p.max_sel, p.N).total <= kLdsLimit) p.cache_n = p.N;
+    const LdsLayout L = lds_layout(p.max_sel, p.cache_n);
     if (L.total > kLdsLimit)
         return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,
                     kLdsLimit);
@@ -1246,8 +1288,6 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     }
     // cluster mode needs its own scratch behind the staging area; a caller that passes less simply gets one workgroup per
     // pair (same results, the passes over the scores are not shared)
-    p.cluster = cluster_size(p.B * p.C, p.N);
-    if (p.cluster > 1 && (!d_workspace || workspace_bytes < stage + cluster_bytes(p.B * p.C, p.cluster, p.N))) p.cluster = 1;
     if (p.cluster > 1) {
         unsigned char *base = reinterpret_cast<unsigned char *>(d_workspace) + stage;
         p.cl_ctl = reinterpret_cast<unsigned *>(base);
