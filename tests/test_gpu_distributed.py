@@ -30,6 +30,7 @@ def test_two_ranks_on_one_gpu_match_single_process(total, tmp_path):
     assert rc == 0
     # single process, all images in one batch (the default path is bit-identical across batch sizes)
     hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    train_utils.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)      # (the table is a mutated global: put it back)
     weights = synthetic_weights("vgg16", hp, seed=5)
     imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11)).cuda()
     prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=total, iou_threshold=0.7)

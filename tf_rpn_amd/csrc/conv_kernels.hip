@@ -108,8 +108,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// The second launch bound (a minimum of 2 waves per SIMD) is what keeps the register allocation lean: without it hipcc
+// unrolls and prefetches every fragment read of a slice into 164 VGPRs + 64 AGPRs -- two 4-wave workgroups per CU, the
+// matrix pipe busy 78 % of the time with the waves parked at the slice barrier for 18 % of theirs (profiles/r03_f32_pmc.txt).
+// With it the 128 x 128 tile takes 104 VGPRs, accumulators included: up to four workgroups per CU (33 KB of LDS each) whose
+// barrier waits cover one another.  Same instruction sequence per accumulator, same bits: 705 -> 722 images/s.
 template <int WM, int WN, int MI, int NI, bool GENERIC>
-__global__ void __launch_bounds__(kConvThreads)
+__global__ void __launch_bounds__(kConvThreads, 2)
 conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
     static_assert(WM * WN == 4 && WM * MI * 32 == BM, "tile shape");

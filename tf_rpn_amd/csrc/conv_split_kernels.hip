@@ -610,6 +610,10 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float
                                                  int stamp_base = -1 /* -DRPN_STAMP builds: first of 4 stamp slots */)
 {
     (void)stamp_base;
+    // the lane index as an opaque value: the epilogue's lane arithmetic (e / PP, e % PP, staging addresses) is otherwise
+    // loop-invariant in the persistent kernel's tile loop, gets hoisted in front of it and is carried through the tap loop
+    // in registers the 256-VGPR kernel does not have (5 were spilled to scratch)
+    asm volatile("" : "+v"(lane));
     constexpr int MT = RW * 2;
     constexpr int CW = 16 * NJ;                        // channels per wave
     constexpr int STAGE_LD = CW + kStagePad;
