@@ -39,13 +39,33 @@ def stats(csv_path, out):
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]), r["MinNs"], r["MaxNs"]])
 
 
-def traffic(prefix, out, note):
+def bench_name(k):
+    """rocprofv3 kernel name -> the kernel name bench.py prints for the op (both POOL instantiations together)."""
+    import re
+    prec = lambda f16: "f16x3" if f16 == "true" else "bf16x3"
+    m = re.search(r"conv3x3_split16_dma_kernel<(true|false), (true|false), (\d+)>", k)
+    if m: return "conv3x3_split16_dma<%s,%s>" % (prec(m.group(1)), m.group(3))
+    m = re.search(r"conv3x3_split16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", k)
+    if m: return "conv3x3_split16<%s,%d>" % (prec(m.group(4)), 64 * int(m.group(2)))
+    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), true>", k)
+    if m: return "vgg_block1<%s>" % prec(m.group(5))
+    m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(, false)?>", k)
+    if m: return "conv3x3_split<%s>" % prec(m.group(5))
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
+    return short(k)
+
+
+def traffic(prefix, out, note, workload=None, subdirs=None, rename=False):
+    """subdirs: (fetch dir, write dir) relative to src (default: <prefix>_fetch / <prefix>_write); rename: key the kernels by
+    bench.py's op-table names (bench.py reads `hbm_bytes_per_launch` back under those); workload: what the passes ran."""
     acc = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": [], "dur": []})
-    for cname in ("fetch", "write"):
-        for path in glob.glob(os.path.join(src, "%s_%s" % (prefix, cname), "**", "*counter_collection.csv"), recursive=True):
+    dirs = subdirs or ("%s_fetch" % prefix, "%s_write" % prefix)
+    for d in dirs:
+        for path in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
                 if ours(r["Kernel_Name"]) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    k = short(r["Kernel_Name"])
+                    k = bench_name(r["Kernel_Name"]) if rename else short(r["Kernel_Name"])
                     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     acc[k]["dur"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     res = {}
@@ -59,21 +79,40 @@ def traffic(prefix, out, note):
                       "hbm_GBps": round((fetch + write) / dur, 1), "frac_of_8TBps": round((fetch + write) / dur / 8000.0, 4),
                       "launches_sampled": len(d["FETCH_SIZE"])}
     if res:
-        json.dump({"source": note, "kernels": res}, open(os.path.join(dst, out), "w"), indent=1)
+        doc = {"source": note, "kernels": res}
+        if workload:
+            doc["workload"] = workload
+        json.dump(doc, open(os.path.join(dst, out), "w"), indent=1)
 
 
 copy("bench_default.json", "%s_f16x3_bench_default.json" % tag)
 copy("bench_default_layers.txt", "%s_f16x3_bench_layers.txt" % tag)
-for cfg in ("c4", "c5", "mn8"):
+for cfg in ("c4", "c5", "mn8", "f32"):
     copy("bench_%s.json" % cfg, "%s_%s_bench.json" % (tag, cfg))
     copy("bench_%s_layers.txt" % cfg, "%s_%s_bench_layers.txt" % (tag, cfg))
 copy("bbox_c3.json", "%s_c3_bbox_kernels.json" % tag)
-stats(os.path.join(src, "stats", "stats_kernel_stats.csv"), "%s_f16x3_bench_kernel_stats.csv" % tag)   # scripts/round2_final.sh
+for part in ("A", "B"):
+    copy("device_%s.txt" % part, "%s_device_%s.txt" % (tag, part))
 stats(os.path.join(src, "c3_stats", "c3_kernel_stats.csv"), "%s_c3_kernel_stats.csv" % tag)
-stats(os.path.join(src, "mn8_stats", "mn8_kernel_stats.csv"), "%s_mn8_kernel_stats.csv" % tag)
-stats(os.path.join(src, "c5_stats", "c5_kernel_stats.csv"), "%s_c5_kernel_stats.csv" % tag)
 traffic("c3", "%s_c3_traffic.json" % tag,
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) of scripts/bench_bbox.py: B=64, A=8649 (vgg16) and 9216 (mobilenet_v2), G=42")
-traffic("mn8", "%s_mn8_traffic.json" % tag,
-        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --backbone mobilenet_v2 --steps 5 (B=8, 500x500)")
-print(sorted(os.listdir(dst)))
+# counter passes of scripts/pmc_passes.sh: <run>/{mfma,wait,lds,insts,fetch,write,stats}
+import subprocess
+for run, name, wl in (("vgg_f16x3", "f16x3", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f16x3"}),
+                      ("vgg_f32", "f32", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f32"}),
+                      ("mn8", "mn8", {"backbone": "mobilenet_v2", "img_size": 500, "batch": 8, "precision": "f16x3"}),
+                      ("c5", "c5", {"backbone": "mobilenet_v2", "img_size": 1024, "batch": 1, "precision": "f16x3"})):
+    d = os.path.join(src, run)
+    if not os.path.isdir(d):
+        continue
+    stats(os.path.join(d, "stats", "stats_kernel_stats.csv"), "%s_%s_bench_kernel_stats.csv" % (tag, name))
+    traffic(run, "%s_%s_traffic.json" % (tag, name),
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) of bench.py --steps 3 --warmup 1 on this workload",
+            workload=wl, subdirs=(os.path.join(run, "fetch"), os.path.join(run, "write")), rename=True)
+    summ = os.path.join(d, "summary.txt")
+    if os.path.exists(summ):
+        table = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_table.py"), summ], capture_output=True, text=True).stdout
+        head = open(os.path.join(root, "scripts", "pmc_table.py")).read().split('"""')[1]
+        open(os.path.join(dst, "%s_%s_pmc.txt" % (tag, name)), "w").write(
+            "rocprofv3 --pmc passes (separate, kernel-trace only) of bench.py --steps 3 --warmup 1, workload %s\n%s\n%s" % (json.dumps(wl), head, table))
+print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))

@@ -195,6 +195,32 @@ def test_model_batch_invariance_full_size():
     assert torch.isfinite(reg).all() and torch.isfinite(cls).all()
 
 
+@pytest.mark.parametrize("img,fm", [(500, 32), (1024, 64)])
+def test_mobilenet_v2_batch_invariance_across_ksplit_factors(img, fm):
+    """MobileNetV2, f16x3: the fused blocks on small grids split their expanded channels over 3 or 6 workgroups per tile
+    (one 500 x 500 image: 32 tiles -> 6; one 1024 x 1024 image: 128 -> 3), large grids do not.  The projection tree is the
+    same for every factor, so image i alone (split) must give BIT-identical outputs to image i inside a batch (not split,
+    or split by another factor)."""
+    hp = bo.get_hyper_params("mobilenet_v2", img_size=img, feature_map_shape=fm)
+    B = 8 if img == 500 else 3
+    model = RPNModel("mobilenet_v2", hp, precision="f16x3", max_batch=B)
+    model.set_weights(synthetic_weights("mobilenet_v2", hp, seed=1))
+    imgs = torch.rand((B, img, img, 3), generator=torch.Generator().manual_seed(0)).cuda()
+    reg, cls = model.predict_on_batch(imgs)
+    reg, cls = reg.clone(), cls.clone()
+    for i in (0, B - 1):
+        r1, c1 = model.predict_on_batch(imgs[i:i + 1].contiguous())
+        assert torch.equal(r1[0], reg[i]) and torch.equal(c1[0], cls[i])
+        r2, c2 = model.predict_on_batch(imgs[i:i + 1].contiguous())          # and run to run (the tickets are left at zero)
+        assert torch.equal(r2[0], r1[0]) and torch.equal(c2[0], c1[0])
+    if B >= 3:
+        r3, c3 = model.predict_on_batch(imgs[:2].contiguous())                # another grid size, maybe another factor
+        assert torch.equal(r3, reg[:2]) and torch.equal(c3, cls[:2])
+    assert torch.isfinite(reg).all() and not model.status()["f16_range"]
+    ref = cv.rpn_forward("mobilenet_v2", imgs[:1].cpu().numpy(), synthetic_weights("mobilenet_v2", hp, seed=1), dtype=torch.float64)
+    assert np.abs(reg[:1].cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls[:1].cpu().numpy() - ref[1]).max() <= 1e-4
+
+
 def test_forward_requires_all_weights():
     hp = bo.get_hyper_params("vgg16", img_size=64, feature_map_shape=4)
     model = RPNModel("vgg16", hp, max_batch=1)

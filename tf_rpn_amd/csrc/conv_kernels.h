@@ -85,9 +85,14 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
 bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual);
 void pack_ir_x3_expand(const float *w, int K, int CEXP, int shift, unsigned short *dst);
 void pack_ir_x3_project(const float *w, int CEXP, int COUT, int shift, unsigned short *dst);
+// scratch: ir_block_x3_scratch_floats() zero-initialised floats (partials + tickets of the K-split used on small grids), or
+// null = never split.  The kernel leaves the tickets at zero.
+size_t ir_block_x3_scratch_floats();
+int ir_block_x3_ksplit(long long tiles);
 hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int cexp, int cout, bool residual,
                               const void *we, const float *be, const float *wd, const float *bd, const void *wp,
-                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, hipStream_t s);
+                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, float *scratch,
+                              hipStream_t s);
 
 // f16x3 variant of the high-resolution blocks 1-3 (Cin = 16 / 24; mnv2_block_kernels.hip: ir_block_hrx3_kernel): the
 // expand GEMM's K is zero-padded to one 32-deep step, so the fragment images are LARGER than the float32 matrices --

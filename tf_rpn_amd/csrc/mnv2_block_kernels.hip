@@ -854,6 +854,12 @@ struct IrX3Args {
     int B, H, W, tiles_x, tiles_y;
     unsigned *status;     // float16 range flag (block input beyond 65504), or null
     int stamp;
+    // K-split for small grids (one image: 32 tiles on 256 CUs): `ksplit` workgroups per tile (1 | 2 | 3 | 6) each take a run of
+    // the expanded-channel chunks; their partial projections go to `part` ([tile][ksplit][32 px][COUT] floats) and the
+    // workgroup that arrives last (tickets[tile], left at zero) adds them in the FIXED order every launch uses -- see the kernel
+    int ksplit;
+    float *part;
+    unsigned *tickets;
 };
 
 __device__ __forceinline__ f32x4 mfma_x3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 blo, f32x4 c)
@@ -887,7 +893,20 @@ ir_block_x3_kernel(IrX3Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const int stid = tid;                                     // weight staging is done by the MATRIX waves here (they have the slack)
-    int t = blockIdx.x;
+    // Projection sums are ALWAYS formed as a fixed tree over six equal runs ("leaves") of the chunks:
+    //     total = ((leaf0 + leaf1) + (leaf2 + leaf3)) + (leaf4 + leaf5),   each leaf an MFMA chain from zero over its chunks.
+    // One workgroup per tile (ksplit = 1) folds the leaves as it goes; with ksplit = 3 a workgroup computes one pair, with 6 one
+    // leaf, with 2 the first two pairs' sum | the third pair, and the last arriver finishes the same tree from the stored partials.  Every split factor therefore gives the same
+    // bits -- the grid-dependent choice (few tiles: one image) cannot make a batch-1 result differ from the same image inside
+    // a larger batch (test_model_batch_invariance*).
+    constexpr int LEAF = NCHUNK / 6;
+    static_assert(NCHUNK % 6 == 0, "the projection tree has six leaves");
+    const int ksplit = a.ksplit;
+    const int tile = (int)blockIdx.x / ksplit, part_h = (int)blockIdx.x - tile * ksplit;
+    // this workgroup's chunks [c0, c0 + nch): equal runs, except ksplit = 2 = the tree's (leaf0..3 | leaf4..5)
+    const int nch = ksplit == 2 ? (part_h == 0 ? 4 * LEAF : 2 * LEAF) : NCHUNK / ksplit;
+    const int c0 = ksplit == 2 ? part_h * 4 * LEAF : part_h * nch;
+    int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -926,7 +945,7 @@ ir_block_x3_kernel(IrX3Args a)
         for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
         wd_nxt[9] = a.bd[c * CE + dn];
     };
-    if (wave < 4) we_fetch(0);
+    if (wave < 4) we_fetch(c0);
 
     // ---- 1. input tile: float32 NHWC -> hi / lo float16, fragment-major ---------------------------------------------
     {
@@ -962,39 +981,39 @@ ir_block_x3_kernel(IrX3Args a)
             if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) vmask |= 1u << i;
         }
         we_store(0);
-        if (NCHUNK > 1) we_fetch(1);                         // put in place at the start of step 0
+        if (nch > 1) we_fetch(c0 + 1);                       // put in place at the start of step 0
     }
     __syncthreads();
     IR_STAMP(0, 1);
 
-    f32x4 pacc[NJ];
+    f32x4 pacc[NJ], ppair[NJ], ptot[NJ];                     // the current leaf; the current pair of leaves; the tree so far
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) pacc[j] = ppair[j] = ptot[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bias_nxt[NBE];
 #pragma unroll
-    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[nb * 16 + lr];
+    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[c0 * CE + nb * 16 + lr];
     const int mbp = wave & 1, nbp = (wave >> 1) & 1;
 
-    for (int it = 0; it < NCHUNK + 2; ++it) {
+    for (int it = 0; it < nch + 2; ++it) {
         if (wave < 4) {
             // Weight staging, one step ahead of its use and one step behind its loads: what was requested at the start of
             // the previous step (We(it+1), Wp(it-1)) has had a whole step to arrive and is put in place now, then the next
             // requests go out.  Done by the matrix waves: on the 16-bit MFMA their step is shorter than the service waves'.
-            if (it + 1 < NCHUNK) we_store((it + 1) & 1);
-            if (it >= 1 && it <= NCHUNK) wp_store((it - 1) & 1);
+            if (it + 1 < nch) we_store((it + 1) & 1);
+            if (it >= 1 && it <= nch) wp_store((it - 1) & 1);
             // the expand bias of the NEXT chunk is requested BEFORE the weight fragments: vmcnt retires loads in order, and
             // the register copy that hands it to the next step sits at the end of E -- behind the weight requests it would
             // wait for all of them (measured: +1.1 k cycles per step)
             float biasv[NBE];
 #pragma unroll
             for (int nb = 0; nb < NBE; ++nb) biasv[nb] = bias_nxt[nb];
-            if (it + 1 < NCHUNK) {
+            if (it + 1 < nch) {
 #pragma unroll
-                for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[(it + 1) * CE + nb * 16 + lr];
+                for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[(c0 + it + 1) * CE + nb * 16 + lr];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (it + 2 < NCHUNK) we_fetch(it + 2);
-            if (it < NCHUNK) wp_fetch(it);
+            if (it + 2 < nch) we_fetch(c0 + it + 2);
+            if (it < nch) wp_fetch(c0 + it);
             // operands of P(it-2) first: they are ready when the step starts, and their LDS latency then hides behind E
             u32x4 dhi, dlo, pb[NJ][2];
             if (it >= 2) {
@@ -1009,7 +1028,7 @@ ir_block_x3_kernel(IrX3Args a)
                     pb[j][1] = wps[(nb * 2 + 1) * 64 + lane];
                 }
             }
-            if (it < NCHUNK) {
+            if (it < nch) {
                 // ---- E(it): one M-block (16 halo pixels) x 2 N-blocks x KS k-steps x 3 MFMAs ---------------------------
                 const u32x4 *wes = WeS[it & 1];
                 u32x4 xa[KS][2], wb[KS][NBE][2];
@@ -1044,6 +1063,16 @@ ir_block_x3_kernel(IrX3Args a)
                 // ---- P(it-2): acc (32 px x COUT) += D (32 x 32) * Wp[chunk it-2] ---------------------------------------------
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) pacc[j] = mfma_x3(dhi, dlo, pb[j][0], pb[j][1], pacc[j]);
+                const int cg = c0 + it - 2;                     // the chunk just projected: a leaf ends behind every LEAF-th
+                if ((cg + 1) % LEAF == 0) {
+                    const int leaf = cg / LEAF;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        ppair[j] = ((leaf & 1) && ksplit != 6) ? ppair[j] + pacc[j] : pacc[j];    // (ksplit = 6: the one leaf, as it is)
+                        if (leaf & 1) ptot[j] = leaf == 1 ? ppair[j] : ptot[j] + ppair[j];
+                        pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
             IR_STAMP(0, 3 + 4 * it);
         } else {
@@ -1054,9 +1083,9 @@ ir_block_x3_kernel(IrX3Args a)
             for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
             IR_STAMP(4, 66 + 4 * it);
             __builtin_amdgcn_sched_barrier(0);
-            if (it < NCHUNK) wd_fetch(it);
+            if (it < nch) wd_fetch(c0 + it);
             IR_STAMP(4, 65 + 4 * it);
-            if (it >= 1 && it <= NCHUNK) {
+            if (it >= 1 && it <= nch) {
                 // ---- D(it-1): depthwise 3x3 + bias + ReLU6, then hi / lo float16 into P's A-operand image ----------------
                 const int c = it - 1;
                 const float *es = Es[c & 1] + dn;
@@ -1098,6 +1127,53 @@ ir_block_x3_kernel(IrX3Args a)
         IR_STAMP(0, 5 + 4 * it);
     }
 
+    if (ksplit > 1) {
+        // ---- K-split: this workgroup's pair (ksplit = 3) or leaf (6) -> `part`; the last arriver adds them in tree order -------
+        // Visibility WITHOUT cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility, second form): every handed-off
+        // word is written with a device-scope (sc1, write-through) store and read with a device-scope load; a storing wave
+        // drains its stores (vmcnt(0)) in front of the workgroup barrier that precedes the ticket.  (First version: an
+        // agent-scope release in front of the ticket and an acquire behind it -- an L2 write-back and an L2 invalidate per
+        // workgroup, with hundreds of workgroups of the same kernel still computing out of that L2: configs[4] 0.384 -> 0.455 ms.)
+        float *mine = a.part + ((size_t)tile * ksplit + part_h) * (32 * COUT);
+        if (wave < 4) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int co = (nbp + 2 * j) * 16 + lr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __hip_atomic_store(mine + (mbp * 16 + 4 * lk + i) * COUT + co, (ksplit == 2 && part_h == 0) ? ptot[j][i] : ppair[j][i],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __shared__ unsigned last_flag;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)ksplit - 1u ? 1u : 0u;
+            if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            last_flag = last;
+        }
+        __syncthreads();
+        if (last_flag == 0u) return;
+        if (wave < 4) {
+            const float *base = a.part + (size_t)tile * ksplit * (32 * COUT);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int co = (nbp + 2 * j) * 16 + lr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (mbp * 16 + 4 * lk + i) * COUT + co;
+                    float q[6];
+#pragma unroll
+                    for (int h = 0; h < 6; ++h)
+                        q[h] = h < ksplit ? __hip_atomic_load(base + (size_t)h * (32 * COUT) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                    ptot[j][i] = ksplit == 2 ? q[0] + q[1]
+                                             : (ksplit == 3 ? (q[0] + q[1]) + q[2] : ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
+                }
+            }
+        }
+    }
     if (wave < 4) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1109,7 +1185,7 @@ ir_block_x3_kernel(IrX3Args a)
                 const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
                 if (oy < a.H && ox < a.W) {
                     const size_t pix = ((size_t)img * a.H + oy) * a.W + ox;
-                    float v = pacc[j][i] * a.scale_p + bias;
+                    float v = ptot[j][i] * a.scale_p + bias;
                     if constexpr (RES) v += a.x[pix * KP + co];           // the block input (L2-hot: this tile just read it)
                     a.out[pix * COUT + co] = v;
                 }
@@ -1442,9 +1518,23 @@ void pack_ir_x3_project(const float *w /* [CEXP][COUT] */, int CEXP, int COUT, i
                 }
 }
 
+// K-split factor of a fused f16x3 block on a grid of `tiles` 4 x 8 tiles: 6 workgroups per tile when the tiles cover at
+// most a sixth of the CUs (one 500 x 500 image: 32 tiles), 3 up to a third of them, else 1.  Speed only: the projection tree is the same for every factor (ir_block_x3_kernel).
+int ir_block_x3_ksplit(long long tiles)
+{
+    static const int forced = RPN_LAB_KNOB("RPN_MN_KSPLIT", 0);       // 1 | 3 | 6: force a factor (A/B timing)
+    if (forced == 1 || forced == 2 || forced == 3 || forced == 6) return forced;
+    // ... as long as tiles x factor workgroups still fit the 256 CUs in one round (beyond that the parts queue up behind one
+    // another and the split only adds its fixed costs: configs[4] at 3 x 128 workgroups 0.385 -> 0.41 ms)
+    // (the uneven 2-way form -- 256 workgroups for configs[4]'s 128 tiles -- measured no gain there: laboratory knob only)
+    return tiles <= 42 ? 6 : (tiles <= 85 ? 3 : 1);
+}
+size_t ir_block_x3_scratch_floats() { return (size_t)128 * 6 * 32 * 96 + 1024; }    // partials of <= 128 tiles x 6 parts x 32 px x 96 ch, then 1024 tickets
+
 hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int cexp, int cout, bool residual,
                               const void *we, const float *be, const float *wd, const float *bd, const void *wp,
-                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, hipStream_t s)
+                              const float *bp, float scale_e, float scale_p, float *out, unsigned *status, float *scratch,
+                              hipStream_t s)
 {
     if (!ir_block_x3_supported(cin, cexp, cout, 1, residual)) return hipErrorInvalidValue;
     IrX3Args a{};
@@ -1453,8 +1543,13 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
     a.B = B; a.H = H; a.W = W; a.status = status;
     a.tiles_x = (W + IR_TW - 1) / IR_TW;
     a.tiles_y = (H + IR_TH - 1) / IR_TH;
-    const long long nblocks = (long long)a.tiles_x * a.tiles_y * B;
-    if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * B;
+    if (tiles <= 0 || tiles > 0x7fffffffll) return hipErrorInvalidValue;
+    a.ksplit = scratch ? ir_block_x3_ksplit(tiles) : 1;
+    if (a.ksplit > 1 && (tiles > 1024 || (size_t)tiles * a.ksplit * 32 * cout > (size_t)128 * 6 * 32 * 96)) a.ksplit = 1;
+    a.part = scratch;
+    a.tickets = scratch ? reinterpret_cast<unsigned *>(scratch + (size_t)128 * 6 * 32 * 96) : nullptr;
+    const long long nblocks = tiles * a.ksplit;
 #ifdef RPN_STAMP
     {
         const char *sel = getenv("RPN_IR_STAMP_OP");

@@ -88,6 +88,7 @@ struct rpn_model {
     size_t weight_floats = 0, arena_floats = 0;   // arena: per-image floats
     float *d_weights = nullptr, *d_arena = nullptr;
     unsigned *d_status = nullptr;          // RPN_STATUS_* flags raised by the kernels (sticky until rpn_model_status resets)
+    float *d_ksplit = nullptr;             // MobileNetV2 f16x3 blocks on small grids: partial projections + tickets (launch_ir_block_x3)
     const float *last_input = nullptr;
     double flops = 0.0;
     // optional per-op timing: one hipEvent before the first op and one after every op
@@ -530,6 +531,14 @@ static int ensure_device(rpn_model *m)
         RPN_HIP_CHECK(hipMalloc(&m->d_status, 64));
         RPN_HIP_CHECK(hipMemset(m->d_status, 0, 64));
     }
+    if (!m->d_ksplit) {
+        bool any = false;
+        for (const Op &op : m->ops) any = any || (op.kind == OP_IRBLOCK && op.ir_x3 && !op.ir_hrx3);
+        if (any) {
+            RPN_HIP_CHECK(hipMalloc(&m->d_ksplit, ir_block_x3_scratch_floats() * sizeof(float)));
+            RPN_HIP_CHECK(hipMemset(m->d_ksplit, 0, ir_block_x3_scratch_floats() * sizeof(float)));
+        }
+    }
     return RPN_OK;
 }
 
@@ -573,6 +582,7 @@ extern "C" void rpn_model_destroy(rpn_model *m)
     if (m->d_weights) (void)hipFree(m->d_weights);
     if (m->d_arena) (void)hipFree(m->d_arena);
     if (m->d_status) (void)hipFree(m->d_status);
+    if (m->d_ksplit) (void)hipFree(m->d_ksplit);
     for (auto &ev : m->events) (void)hipEventDestroy(ev);
     delete m;
 }
@@ -934,7 +944,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 e = launch_ir_block_x3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.ir_res, wb + op.ir_off[0],
                                        wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3], wb + op.ir_off[4],
                                        wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1], tensor_ptr(m, op.out, d_imgs),
-                                       m->d_status, s);
+                                       m->d_status, m->d_ksplit, s);
             else
             e = launch_ir_block(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_stem, op.ir_pad,
                                 op.OH, op.OW, wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
