@@ -465,11 +465,13 @@ struct ClusterCtx {
     int region;
 };
 
-// Arrive at cluster barrier `k`; `wait`: and wait for all G workgroups.  Every thread first waits for its own global stores
-// and atomics (vmcnt(0): they are in the L2 / performed), the workgroup barrier then puts them all in front of thread 0's
-// device-scope RELEASE fence (L2 write-back: this XCD's L2 is not coherent with the others') and arrival; thread 0 polls with
-// relaxed loads and issues ONE acquire fence (L1 / L2 invalidate, CU- and XCD-wide) before the closing workgroup barrier.
-// (First version: __threadfence() by all 1024 threads on both sides and an acquire load per poll: ~25 k cycles per barrier.)
+// Arrive at cluster barrier `k`; `wait`: and wait for all G workgroups.  Hand-off WITHOUT cache-wide fences
+// (MI355X_MICROARCH.md, inter-workgroup visibility, second form): every word one workgroup hands to another is written with a
+// device-scope (sc1, write-through) store or atomic and read with a device-scope load; every storing thread drains its stores
+// (vmcnt(0)) in front of the workgroup barrier that precedes thread 0's arrival (a relaxed device-scope atomic); thread 0 polls
+// with relaxed device-scope loads.  (First version: __threadfence() by all 1024 threads on both sides and an acquire load per
+// poll: ~25 k cycles per barrier; one release / acquire fence pair by thread 0: ~4-6 k -- an L2 write-back and invalidate
+// each, which also evict what the kernels of the other stream are working from.)
 // The wait is BOUNDED (~0.1 s of polling: far beyond any kernel another stream could be holding the CUs with): returns
 // false when a rank never arrived, and the caller then gives the cluster up -- the leader recomputes the band alone, so a
 // lost rank costs time, never a hang or a wrong result.  `flag`: one int of LDS.
@@ -478,7 +480,6 @@ __device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(cl.ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
         if (wait) {
@@ -487,7 +488,6 @@ __device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool
                 if (++spins > (1 << 17)) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         *flag = ok;
     }
@@ -610,8 +610,8 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &s
     __syncthreads();
     const int mine = min(ctl[2], cl.region);
     unsigned long long *dst = cl.band + (size_t)cl.g * cl.region;
-    for (int i = tid; i < mine; i += kNmsThreads) dst[i] = lds_keys[i];
-    if (tid == 0) cl.ctr[16 + cl.g] = (unsigned)mine;
+    for (int i = tid; i < mine; i += kNmsThreads) __hip_atomic_store(dst + i, lds_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(cl.ctr + 16 + cl.g, (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     NMS_STAMP(22);
     const int ok = cluster_arrive(cl, 2, cl.g == 0, ctl + 3) ? 1 : 0;
     NMS_STAMP(23);
@@ -758,7 +758,7 @@ nms_kernel(NmsArgs p)
         // cluster mode: key i of the band's list = key (i - first[r]) of rank r's region
         if (from_cluster) {                  // ctl[CTL_CLPRE + r] = list position of rank r's first key
             if (tid < 64) {
-                const int cnt = lane < cl.G ? (int)cl.ctr[16 + lane] : 0;
+                const int cnt = lane < cl.G ? (int)__hip_atomic_load(cl.ctr + 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 int incl = cnt;
                 for (int off = 1; off < kClusterMax; off <<= 1) {
                     const int v = __shfl_up(incl, off, 64);
@@ -772,7 +772,7 @@ nms_kernel(NmsArgs p)
             int r = 0;
 #pragma unroll
             for (int q = 1; q < kClusterMax; ++q) r += (q < cl.G && i >= ctl[CTL_CLPRE + q]) ? 1 : 0;   // regions are in list order
-            return cl.band[(size_t)r * cl.region + (i - ctl[CTL_CLPRE + r])];
+            return __hip_atomic_load(cl.band + (size_t)r * cl.region + (i - ctl[CTL_CLPRE + r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
             if (from_cluster)
