@@ -1308,6 +1308,363 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
 #undef RPN_DMA_B
 }
 
+// (LABORATORY BUILD ONLY, -DRPN_LAB: measured SLOWER than the 8-wave form and not part of the product library -- see the note at
+// the end of this comment and NOTES.md.)
+#ifdef RPN_LAB
+// ---- 16x16x32-MFMA variant: persistent workgroups, LDS-DMA pipeline, ONE WAVE PER SIMD, epilogue under the next tile's taps ----
+// conv3x3_split16_dma_kernel<.., 128> loses ~9 % of the VGG16 step to its epilogue (-DRPN_EXP_NO_EPILOGUE): at the end of a tile
+// all eight waves stage and store 128 KB while the matrix pipes idle, and that store phase is bounded by store ISSUE on the CU
+// (~14 B / clk with 16-byte stores), not by HBM and not by workgroups colliding (a staggered start changes nothing).  Hiding it
+// needs an MFMA stream that stays resident while the stores drain, i.e. a second accumulator set: 64 more registers per wave
+// that the 8-wave form (256 registers per wave at two waves per SIMD) does not have.  Here the same 8 x 32 px x 128 ch tile runs
+// on FOUR waves (one per SIMD, up to 512 registers): a wave owns 4 rows x 32 px x 64 channels = 32 accumulator tiles
+// (128 registers) and works a tap in four quarter-steps of 24 MFMAs (one pixel row each; row fragments double-buffered A / B,
+// the next tap's weights and row 0 read during the fourth).  At the end of a tile the accumulators are COPIED to a second set
+// and the tap stream continues into the next tile at once; the finished tile leaves in 8 micro-steps (4 with the fused pool),
+// one per tap of the next tile's first slice: 16 px x 64 ch per wave -> + bias, activation -> a wave-private staging area that
+// lives BEHIND halo buffer 1 (17 KB: nothing of the pipeline overlays it) -> hi / lo split -> four 16-byte stores per lane,
+// scheduled among the first two quarter-steps' MFMAs.  The stores are issued IN FRONT of the interval's DMAs, so the interval's
+// counted wait -- vmcnt(number of its own DMAs) -- retires them together with the previous interval's DMAs whatever their number.
+// Same products, accumulated in the same order as the 8-wave form: the same bits.
+// Static tile schedule only (RPN_S16_DYN keeps the 8-wave kernel).
+// Measured (VGG16, batch 8, same device, RPN_S16_W4 = 0 | 1): parity tests green at the first run (same bits as the 8-wave form,
+// repeats bit-identical), but 2 880 -> 2 660 images/s: block2_conv2 0.302 -> 0.337 ms, block4_conv2 0.283 -> 0.314.  With the
+// epilogue left synchronous at the tile end (-DRPN_EXP_W4_SYNC_EPI) the same kernel runs 0.332 / 0.307 ms: the four-wave TAP LOOP by
+// itself is 8-10 % slower than the eight-wave one -- with one wave per SIMD nothing covers a wave's own counted waits and the
+// barrier skew of every tap -- and that is more than the epilogue it could hide.
+template <bool F16, bool POOL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv3x3_split16_dma4_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int BN = 128, TH = 8, NW = 4, RW = 4, MT = 8, NJ = 4, PPP = 8;
+    constexpr int B_PER_WAVE = BN * PPP / 64 / NW;     // 4 weight DMA instructions per wave and tap
+    constexpr int HP = (TH + 2) * HW;                  // 340 halo pixels
+    constexpr int A_INSTR = (HP * PPP + 63) / 64;      // 43 wave-instructions (1 KB each) per halo tile
+    constexpr int ABUF = A_INSTR * 64;
+    constexpr int A_PER_WAVE = 11;                     // (the one surplus instruction of the last round duplicates piece 0)
+    constexpr int BSLOT = BN * PPP;
+    constexpr int B_AT = ABUF, DUMP = B_AT + 3 * BSLOT, A1_AT = DUMP + 64;
+    constexpr int STAGE_AT = A1_AT + ABUF;             // staging: 4 waves x 16 px x 68 floats, behind halo buffer 1
+    constexpr int STAGE_LD = 16 * NJ + kStagePad;
+    constexpr int STAGE_PIECES = NW * 16 * STAGE_LD * 4 / 16;
+    constexpr int LDS_UINT4 = STAGE_AT + STAGE_PIECES;
+    static_assert((A_INSTR + NW - 1) / NW == A_PER_WAVE && LDS_UINT4 * 16 <= 160 * 1024, "tile shape");
+
+    __shared__ uint4 lds[LDS_UINT4];
+    u32x4 *As = reinterpret_cast<u32x4 *>(lds);       // halo buffer b at As + b * A1_AT
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(lds) + B_AT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, kg = lane >> 4;
+
+    const int m_tiles = tiles_x * tiles_y * a.B;
+    const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+    const int NTl = (n_tiles + XN - 1) / XN, MTl = (m_tiles + XM - 1) / XM;
+    const int xcd = blockIdx.x & 7;
+    const int slot_stride = gridDim.x >> 3;
+    const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride, BN};
+
+    const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
+    const int total_taps = chunks * 9;
+    const int in_pix_stride = (a.Cin >> 4) * 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.x), (short)0, (int)((size_t)a.B * a.H * a.W * in_pix_stride * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
+    const int w_tap_bytes = a.cout_pad * 128;
+
+#define halo_goff4(J, IM, Y0, X0) halo_source_offset<NW, A_INSTR, HP * PPP>((J), wave, lane, (IM), (Y0), (X0), a.H, a.W, in_pix_stride)
+    const unsigned b_voff = (unsigned)(((B_PER_WAVE * wave) * 64 + lane) * 16);
+#define RPN4_DMA_A(J, GOFF, SOFF, BUF)                                                                            \
+    {                                                                                                             \
+        const int k0_ = (J) * NW + wave, k_ = k0_ < A_INSTR ? k0_ : k0_ - A_INSTR;                                \
+        u32x4 *dst_ = As + (BUF) * A1_AT + k_ * 64;                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, RPN_LDS_PTR(dst_), 16, (GOFF), (SOFF), 0, 0);             \
+    }
+#define RPN4_DMA_B(SOFF, SLOT)                                                                                    \
+    {                                                                                                             \
+        u32x4 *dst_ = Bs + (SLOT) * BSLOT + (B_PER_WAVE * wave) * 64;                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 0, 0);             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 1024, 0);          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 2048, 0);          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, RPN_LDS_PTR(dst_), 16, b_voff, (SOFF), 3072, 0);          \
+    }
+
+    int a_off[3][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = 16 * hf + lr + s3;
+            a_off[s3][hf] = hx * PPP + (kg ^ ((hx >> 1) & 7));
+        }
+    int b_off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = wn * (16 * NJ) + j * 16 + lr;
+        b_off[j] = n * PPP + (kg ^ ((n >> 1) & 7));
+    }
+
+    int img = 0, oy0 = 0, ox0 = 0, n0 = 0;
+    int cur = walk.next(blockIdx.x >> 3, img, oy0, ox0, n0);
+    if (cur < 0) return;
+
+    u32x4 fxA[4], fxB[4], fw[2][2 * NJ];              // fx: [16-px half * 2 + (0 hi | 1 lo)] of one pixel row;  fw: [set][j * 2 + (0 hi | 1 lo)]
+#define RPN4_X_ADDR(BUF, ROW, S, I, II)                                                                          \
+    (As[(BUF) * A1_AT + (RW * wm + (ROW) + (I)) * HW * PPP + (a_off[S][(II) >> 1] ^ (((II) & 1) ? 4 : 0))])
+#define RPN4_W_ADDR(S, II) (Bs[(S) * BSLOT + (b_off[(II) >> 1] ^ (((II) & 1) ? 4 : 0))])
+
+    // ---- prologue (first tile only): halo tile of slice 0, weights of taps 0..2, first fragments of tap 0 -------
+    unsigned a_goff[A_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) a_goff[j] = halo_goff4(j, img, oy0, ox0);
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) RPN4_DMA_A(j, a_goff[j], 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) RPN4_DMA_B(t * w_tap_bytes + n0 * (PPP * 16), t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) fw[0][i] = RPN4_W_ADDR(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fxA[i] = RPN4_X_ADDR(0, 0, 0, 0, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // ring slot 0 may now be overwritten (tap 3)
+
+    // the finished tile whose epilogue is pending: its accumulators and where they go
+    f32x4 done[MT][NJ];
+    float d_bias[NJ];
+    int d_img = 0, d_oy0 = 0, d_ox0 = 0, d_n0 = 0;
+    bool pending = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) done[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) d_bias[j] = 0.0f;
+    float *stage = reinterpret_cast<float *>(lds + STAGE_AT) + wave * (16 * STAGE_LD);
+    const long long out_bytes = (long long)a.B * (POOL ? a.H >> 1 : a.H) * (POOL ? a.W >> 1 : a.W) * a.Cout * 4;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)out_bytes, 0x00020000);
+    const float act_lo = a.act == ACT_LINEAR ? -INFINITY : 0.0f;
+    const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
+    const int cout_chunks = a.Cout >> 4;
+    constexpr int PP = 16 * NJ / 4;                   // 16-byte pieces (or float4s) per pixel of the wave's 64 channels
+
+    // micro-step STEP of the pending epilogue, part 1: 16 px x 64 ch (one row half; POOL: 8 pooled px of a row pair's half)
+    // -> * scale + bias, activation -> the wave's staging area
+#define RPN4_EPI_STAGE(STEP)                                                                                       \
+    {                                                                                                              \
+        if constexpr (POOL) {                                                                                      \
+            const int st_ = (STEP) & 3, rp_ = st_ >> 1, h_ = st_ & 1;      /* (& 3: dead unrolled copies stay in range) */                                                      \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                         \
+                _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2) {                                                 \
+                    const float v0 = fmaxf(done[(2 * rp_) * 2 + h_][j][2 * r2], done[(2 * rp_) * 2 + h_][j][2 * r2 + 1]);            \
+                    const float v1 = fmaxf(done[(2 * rp_ + 1) * 2 + h_][j][2 * r2], done[(2 * rp_ + 1) * 2 + h_][j][2 * r2 + 1]);    \
+                    stage[(2 * kg + r2) * STAGE_LD + j * 16 + lr] =                                                \
+                        fminf(fmaxf(fmaxf(v0, v1) * a.out_scale + d_bias[j], act_lo), act_hi);                     \
+                }                                                                                                  \
+        } else {                                                                                                   \
+            const int st_ = (STEP) & 7, r_ = st_ >> 1, h_ = st_ & 1;                                                       \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                         \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+                    stage[(4 * kg + e) * STAGE_LD + j * 16 + lr] =                                                 \
+                        fminf(fmaxf(done[r_ * 2 + h_][j][e] * a.out_scale + d_bias[j], act_lo), act_hi);           \
+        }                                                                                                          \
+        wave_sync();                                                                                               \
+    }
+    // ... part 2: staging area -> hi / lo split (or float32) -> 16-byte stores.  Through a raw buffer descriptor with 32-bit
+    // byte offsets (the launcher checks that the output tensor stays below 2 GiB): pixels or channels beyond the tensor get an
+    // out-of-range offset, which the hardware drops -- no branch, and no 64-bit address pair per lane and round for the register
+    // allocator to carry across the tap loop (the first version spilled 42 of them).
+#define RPN4_EPI_STORE(STEP)                                                                                       \
+    {                                                                                                              \
+        constexpr int NPX_ = POOL ? 8 : 16;                                                                        \
+        const int st_ = (STEP) & (POOL ? 3 : 7), h_ = st_ & 1;                                                     \
+        const int OHo_ = POOL ? a.H >> 1 : a.H, OWo_ = POOL ? a.W >> 1 : a.W;                                      \
+        const int oy_ = POOL ? (d_oy0 + RW * wm + 2 * (st_ >> 1)) >> 1 : d_oy0 + RW * wm + (st_ >> 1);             \
+        const int oxb_ = POOL ? (d_ox0 >> 1) + 8 * h_ : d_ox0 + 16 * h_;                                           \
+        const int nbase_ = d_n0 + wn * (16 * NJ);                                                                  \
+        const int row_ = (d_img * OHo_ + oy_) * OWo_;                                                              \
+        int ln_ = lane;                                                                                            \
+        asm volatile("" : "+v"(ln_));                                                                              \
+        _Pragma("unroll") for (int rd = 0; rd < NPX_ * PP / 64; ++rd) {                                            \
+            const int e = rd * 64 + ln_;                                                                           \
+            const int px = e / PP, q = e % PP;                                                                     \
+            const int ox = oxb_ + px;                                                                              \
+            if (a.out_f32) {                                                                                       \
+                const int n = nbase_ + 4 * q;                                                                      \
+                const bool ok = oy_ < OHo_ && ox < OWo_ && n < a.Cout;                                             \
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&stage[px * STAGE_LD + 4 * q]);                   \
+                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? ((row_ + ox) * a.Cout + n) * 4 : (int)0x80000000, 0, 0);   \
+            } else {                                                                                               \
+                const int cl = q >> 2, pc = q & 3;                                                                 \
+                const int n = nbase_ + cl * 16;                                                                    \
+                const bool ok = oy_ < OHo_ && ox < OWo_ && n < a.Cout;                                             \
+                float xs[8];                                                                                       \
+                const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];                                \
+                const float4 v0 = *reinterpret_cast<const float4 *>(src);                                          \
+                const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);                                      \
+                xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;                                            \
+                xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;                                            \
+                const uint4 pv = split_piece<F16>(xs, (pc & 1) != 0, ok ? a.status : nullptr);                     \
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pv.x, pv.y, pv.z, pv.w}, orsrc,                       \
+                    ok ? (((row_ + ox) * cout_chunks + (n >> 4)) * 4 + pc) * 16 : (int)0x80000000, 0, 0);          \
+            }                                                                                                      \
+        }                                                                                                          \
+        wave_sync();                                                                                               \
+    }
+    constexpr int EPI_STEPS = POOL ? 4 : 8;
+
+    // one pixel row (quarter-step): 24 MFMAs of row Q on fragment set F, accumulating into acc[2 Q .. 2 Q + 1][*]
+#define RPN4_ROW_MFMA(Q, F)                                                                                        \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2 * NJ; ++i)                                                         \
+            acc[2 * (Q) + i / NJ][i % NJ] = mfma16<F16>(F[2 * (i / NJ) + 1], fw[CS][2 * (i % NJ)], acc[2 * (Q) + i / NJ][i % NJ]);   \
+        _Pragma("unroll") for (int i = 0; i < 2 * NJ; ++i) {                                                       \
+            acc[2 * (Q) + i / NJ][i % NJ] = mfma16<F16>(F[2 * (i / NJ)], fw[CS][2 * (i % NJ) + 1], acc[2 * (Q) + i / NJ][i % NJ]);   \
+            acc[2 * (Q) + i / NJ][i % NJ] = mfma16<F16>(F[2 * (i / NJ)], fw[CS][2 * (i % NJ)], acc[2 * (Q) + i / NJ][i % NJ]);       \
+        }                                                                                                          \
+    }
+
+    int gt = 3;                                        // next tap to DMA, counted from the current tile's tap 0
+    for (;;) {
+        int nimg = 0, noy0 = 0, nox0 = 0, nn0 = 0;
+        const int nxt = walk.next(cur + slot_stride, nimg, noy0, nox0, nn0);
+        f32x4 acc[MT][NJ];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int pair = 0; pair < (chunks >> 1); ++pair) {
+#ifdef RPN_EXP_W4_SYNC_EPI
+            const bool epi = false;
+#else
+            const bool epi = pending && pair == 0;    // this slice carries the previous tile's epilogue
+#endif
+#pragma unroll
+            for (int T = 0; T < 18; ++T) {            // tap T of this pair of slices; everything below is static in T
+                const int c2 = T / 9, s9 = T % 9;
+                const int CS = T & 1, CB = c2 & 1, CR = s9 / 3, CC = s9 % 3;                       // this tap
+                const int NS = (T + 1) & 1, NB = ((T + 1) / 9) & 1, NR = ((T + 1) % 9) / 3, NC = ((T + 1) % 9) % 3;   // next
+                const int nA = s9 < 5 ? 2 : (s9 == 5 ? 1 : 0);                                     // halo pieces issued in this tap
+                if (T == 9 && nxt >= 0 && pair == (chunks >> 1) - 1) {    // last slice of the tile: from here on the halo
+#pragma unroll
+                    for (int j = 0; j < A_PER_WAVE; ++j) a_goff[j] = halo_goff4(j, nimg, noy0, nox0);   // of the NEXT tile
+                }
+                // ---- quarter 0: row 0 (fxA); reads row 1 -> fxB.  Epilogue micro-step T - 1, part 1, among its MFMAs --------
+                if (T >= 1 && T <= EPI_STEPS && epi) RPN4_EPI_STAGE(T - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fxB[i] = RPN4_X_ADDR(CB, CR, CC, 1, i);
+                RPN4_ROW_MFMA(0, fxA);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- quarter 1: row 1 (fxB); reads row 2 -> fxA.  Epilogue part 2: the stores, IN FRONT of this tap's DMAs ----
+                if (T >= 1 && T <= EPI_STEPS && epi) RPN4_EPI_STORE(T - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fxA[i] = RPN4_X_ADDR(CB, CR, CC, 2, i);
+                RPN4_ROW_MFMA(1, fxB);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // weights of tap t+3: this tile's, or the first taps of the next tile (or a harmless re-load)
+                    int tap = gt, nb = n0;
+                    if (gt >= total_taps) {
+                        if (nxt >= 0) { tap = gt - total_taps; nb = nn0; }
+                        else tap = total_taps - 1;
+                    }
+                    RPN4_DMA_B(tap * w_tap_bytes + nb * (PPP * 16), s9 % 3);
+                    ++gt;
+                }
+                if (nA > 0) {               // halo pieces of the next slice: this tile's, or slice 0 of the next tile
+                    const int nc = 2 * pair + c2 + 1;
+                    const int soff = nc < chunks ? nc * 128 : (nxt >= 0 ? 0 : (chunks - 1) * 128);
+                    if (s9 < 5) {
+                        RPN4_DMA_A(2 * s9, a_goff[2 * s9], soff, (c2 + 1) & 1);
+                        RPN4_DMA_A(2 * s9 + 1, a_goff[2 * s9 + 1], soff, (c2 + 1) & 1);
+                    } else {
+                        RPN4_DMA_A(10, a_goff[10], soff, (c2 + 1) & 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- quarter 2: row 2 (fxA); reads row 3 -> fxB -------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fxB[i] = RPN4_X_ADDR(CB, CR, CC, 3, i);
+                RPN4_ROW_MFMA(2, fxA);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- quarter 3: row 3 (fxB); the next tap's weights and row 0 arrive meanwhile --------------------------------
+#pragma unroll
+                for (int i = 0; i < 2 * NJ; ++i) fw[NS][i] = RPN4_W_ADDR(NC, i);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fxA[i] = RPN4_X_ADDR(NB, NR, NC, 0, i);
+                RPN4_ROW_MFMA(3, fxB);
+                __builtin_amdgcn_sched_barrier(0);
+                // leave exactly this interval's own DMAs in flight (the epilogue's stores were issued in front of them)
+                if (nA == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (nA == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // a tile with ONE pair of slices (Cin = 64) only carries the epilogue's micro-steps that fit its 18 taps: all of them
+        // (8 <= 17); the pending tile is finished before its registers are overwritten
+        // ---- tile done: hand the accumulators over, go on with the next tile ------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) done[m][j] = acc[m][j];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * (16 * NJ) + j * 16 + lr;
+            d_bias[j] = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+        }
+        d_img = img; d_oy0 = oy0; d_ox0 = ox0; d_n0 = n0;
+        pending = true;
+#ifdef RPN_EXP_W4_SYNC_EPI
+        RPN4_EPI_STAGE(0); RPN4_EPI_STORE(0);
+        RPN4_EPI_STAGE(1); RPN4_EPI_STORE(1);
+        RPN4_EPI_STAGE(2); RPN4_EPI_STORE(2);
+        RPN4_EPI_STAGE(3); RPN4_EPI_STORE(3);
+        if constexpr (!POOL) {
+            RPN4_EPI_STAGE(4); RPN4_EPI_STORE(4);
+            RPN4_EPI_STAGE(5); RPN4_EPI_STORE(5);
+            RPN4_EPI_STAGE(6); RPN4_EPI_STORE(6);
+            RPN4_EPI_STAGE(7); RPN4_EPI_STORE(7);
+        }
+        pending = false;
+#endif
+        if (nxt < 0) break;
+        cur = nxt; img = nimg; oy0 = noy0; ox0 = nox0; n0 = nn0;
+        gt -= total_taps;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs still target this workgroup's LDS
+    // the last tile's epilogue, nothing left to hide it under
+    if (pending) {
+        RPN4_EPI_STAGE(0); RPN4_EPI_STORE(0);
+        RPN4_EPI_STAGE(1); RPN4_EPI_STORE(1);
+        RPN4_EPI_STAGE(2); RPN4_EPI_STORE(2);
+        RPN4_EPI_STAGE(3); RPN4_EPI_STORE(3);
+        if constexpr (!POOL) {
+            RPN4_EPI_STAGE(4); RPN4_EPI_STORE(4);
+            RPN4_EPI_STAGE(5); RPN4_EPI_STORE(5);
+            RPN4_EPI_STAGE(6); RPN4_EPI_STORE(6);
+            RPN4_EPI_STAGE(7); RPN4_EPI_STORE(7);
+        }
+    }
+#undef RPN4_ROW_MFMA
+#undef RPN4_EPI_STORE
+#undef RPN4_EPI_STAGE
+#undef RPN4_X_ADDR
+#undef RPN4_W_ADDR
+#undef RPN4_DMA_A
+#undef RPN4_DMA_B
+#undef halo_goff4
+}
+#endif  // RPN_LAB
+
 static inline unsigned short f32_to_bf16_rne(float f);
 static inline float bf16_to_f32(unsigned short h);
 
@@ -2004,6 +2361,20 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
                        n_tiles)
 #define RPN_L16D_BN(F16_, POOL_)                                                                                     \
     if (BN == 128) RPN_L16D(F16_, POOL_, 128); else RPN_L16D(F16_, POOL_, 64)
+#ifdef RPN_LAB
+        // 128-wide tiles: the one-wave-per-SIMD kernel whose epilogue runs under the next tile's taps (static schedule only;
+        // slower than this one: laboratory builds only, RPN_S16_W4=1)
+        static const int w4 = RPN_LAB_KNOB("RPN_S16_W4", 0);
+        const long long out_bytes4 = (long long)B * (pool ? H >> 1 : H) * (pool ? W >> 1 : W) * Cout * 4;
+        if (BN == 128 && w4 && !a.sched && out_bytes4 < 0x7fffffffll) {
+#define RPN_L16D4(F16_, POOL_)                                                                                       \
+    hipLaunchKernelGGL((conv3x3_split16_dma4_kernel<F16_, POOL_>), dim3(pgrid), dim3(256), 0, s, a, tiles_x, tiles_y, n_tiles)
+            if (f16) { if (pool) { RPN_L16D4(true, true); } else { RPN_L16D4(true, false); } }
+            else { if (pool) { RPN_L16D4(false, true); } else { RPN_L16D4(false, false); } }
+#undef RPN_L16D4
+            return hipGetLastError();
+        }
+#endif
         if (f16) { if (pool) { RPN_L16D_BN(true, true); } else { RPN_L16D_BN(true, false); } }
         else { if (pool) { RPN_L16D_BN(false, true); } else { RPN_L16D_BN(false, false); } }
 #undef RPN_L16D_BN
