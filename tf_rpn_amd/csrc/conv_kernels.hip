@@ -292,7 +292,9 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
         const bool more = step + 1 < nsteps;
+#ifndef RPN_EXP_F32_NOGATHER
         if (more) load_global(step + 1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float av[MI], bv[NI];
@@ -306,10 +308,24 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+#ifdef RPN_EXP_F32_NOGATHER      /* timing experiment only (results are wrong): no global loads, no LDS writes, no barrier in the loop */
+        (void)more;
+#else
         if (more) store_lds(cur ^ 1);
+#ifdef RPN_EXP_F32_HALFBAR       /* timing experiment only (results are wrong): a barrier every second slice */
+        if (step & 1)
+#endif
         __syncthreads();
         cur ^= 1;
+#endif
     }
+#ifdef RPN_EXP_F32_NOEPI         /* timing experiment only: the accumulators are kept alive, nothing is written */
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
 
     // ---- epilogue: bias + residual + activation, NHWC stores (32 lanes = 128 contiguous bytes) --
 #pragma unroll
