@@ -329,7 +329,8 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
     __syncthreads();
     const int d2 = ctl[0], n2 = ctl[1];
     __syncthreads();
-    *bin_out = -1;                          // (the band is not ordered from this histogram)
+    // the band can be ordered from a histogram only when it is the top bin's sub-bins >= d2 (no bins above it): 4096 + d2
+    *bin_out = (d == NB - 1 && d2 >= 0) ? 4096 + d2 : -1;
     // (bin 2047 and its sub-bin 2047 also collect the scores >= 1 -- a saturated sigmoid: still exactly {score >= threshold})
     if (d2 < 0 || above + n2 > cap) return false;
     *thr_out = (unsigned long long)orderable((float)(d * 2048 + d2) * (1.0f / 4194304.0f)) << 32;
@@ -369,25 +370,26 @@ __device__ __forceinline__ void scan_band_keys(const ScoreSrc &sc, int N, float 
 // Returns false (nothing written) when a bin of the band holds more than 32 keys: the caller then sorts the old way.
 // `for_each_band_key(fn)`: calls fn(key) for this thread's share of the band's keys (every key exactly once over the
 // workgroup): a scan of all N scores, or -- cluster mode -- the list the cluster's ranks compacted into the workspace.
-template <class ForEachKey>
-__device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d, int n, unsigned *hist, unsigned long long *band,
-                                         unsigned *order, unsigned long long *low_out)
+// `counts` / `bin_of`: the 2048 counts the band was chosen from and the bin of a key in them -- the linear bins, or (a band that is
+// the top bin's sub-bins >= d: a saturated head) the top bin's sub-bins; the suffix sums at hist + 4096 are those of `counts`.
+template <class ForEachKey, class BinOf>
+__device__ inline bool band_order_linear(ForEachKey for_each_band_key, BinOf bin_of, const unsigned *counts, int d, int n, unsigned *hist,
+                                         unsigned *flag, unsigned long long *band, unsigned *order, unsigned long long *low_out)
 {
     const int tid = fresh_tid();
     // segment offsets = the suffix sums hist_suffix_find left behind when it chose bin d (keys in the bins above b)
     unsigned *boff = hist + 4096, *cur = hist + 6144;
-    unsigned *flag = hist + 2048;             // (the top bin's sub-bins are not needed any more)
     const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
     if (tid == 0) *flag = 0u;
     cur[b0] = 0u;
     cur[b1] = 0u;
     __syncthreads();
-    if ((b0 >= d && hist[b0] > 32u) || (b1 >= d && hist[b1] > 32u)) atomicOr(flag, 1u);
+    if ((b0 >= d && counts[b0] > 32u) || (b1 >= d && counts[b1] > 32u)) atomicOr(flag, 1u);
     __syncthreads();
     if (*flag != 0u) return false;
     // scatter: the band's keys to their bins' segments
     for_each_band_key([&](unsigned long long key) {
-        const int b = linear_bin(key_score(key));
+        const int b = bin_of(key);
         band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
     });
     __syncthreads();
@@ -399,8 +401,8 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d, in
         const int i = tid + u * kNmsThreads;
         if (i < n) {
             key[u] = band[i];
-            const int b = linear_bin(key_score(key[u]));
-            const int seg0 = (int)boff[b], cnt = (int)hist[b];
+            const int b = bin_of(key[u]);
+            const int seg0 = (int)boff[b], cnt = (int)counts[b];
             int rank = 0;
             for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key[u] ? 1 : 0;
             pos[u] = seg0 + rank;
@@ -576,7 +578,7 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &s
         __syncthreads();
         const int d2 = ctl[0], n2 = ctl[1];
         __syncthreads();
-        bin = -1;
+        bin = (d == 2047 && d2 >= 0) ? 4096 + d2 : -1;        // (as band_select_linear: the top bin's sub-bins can order the band)
         if (d2 < 0 || above + n2 > cap) return 0;
         thr = (unsigned long long)orderable((float)(d * 2048 + d2) * (1.0f / 4194304.0f)) << 32;
         total = above + n2;
@@ -649,7 +651,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel, int cache_n)
 
 // ctl words
 enum { CTL_NSEL = 0, CTL_BANDN = 1, CTL_POS = 2, CTL_SEL = 4 /* 4 words used by the band selection (+ its scan scratch at
-       CTL_SEL + 12 .. + 28) */, CTL_LOW = 8 /* u64 */, CTL_CLPRE = 36 /* 17 ints: first key of each cluster rank's region */ };
+       CTL_SEL + 12 .. + 28) */, CTL_LOW = 8 /* u64 */, CTL_OFLAG = 10 /* band_order_linear's "a segment is too long" flag */, CTL_CLPRE = 36 /* 17 ints: first key of each cluster rank's region */ };
 
 // Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the
 // first 64 workgroups, in program order (slot 0 = start; the probe knows the sequence).
@@ -775,13 +777,18 @@ nms_kernel(NmsArgs p)
             return __hip_atomic_load(cl.band + (size_t)r * cl.region + (i - ctl[CTL_CLPRE + r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
+            const bool by_sub = lin_bin >= 4096;             // ordered by the top bin's sub-bins (from sub-bin lin_bin - 4096)
+            const unsigned *counts = by_sub ? hist + 2048 : hist;
+            const int d_ord = by_sub ? lin_bin - 4096 : lin_bin;
+            auto bin_of = [&](unsigned long long key) { return by_sub ? linear_sub_bin(key_score(key), 2047) : linear_bin(key_score(key)); };
+            unsigned *oflag = reinterpret_cast<unsigned *>(ctl + CTL_OFLAG);
             if (from_cluster)
                 ordered = band_order_linear([&](auto fn) { for (int i = fresh_tid(); i < band_expected; i += kNmsThreads) fn(cluster_key(i)); },
-                                            lin_bin, band_expected, hist, band, order,
+                                            bin_of, counts, d_ord, band_expected, hist, oflag, band, order,
                                             reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             else
             ordered = band_order_linear([&](auto fn) { scan_band_keys(src, N, p.score_thr, thr, hi_bound, fn); },
-                                        lin_bin, band_expected, hist, band, order,
+                                        bin_of, counts, d_ord, band_expected, hist, oflag, band, order,
                                         reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             if (ordered) {
                 band_n = band_expected;
