@@ -325,7 +325,7 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
         __syncthreads();
         sub = hist;
     }
-    hist_suffix_find(sub, hist + 4096, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
+    hist_suffix_find(sub, sub == hist ? hist + 4096 : hist + 6144, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
     __syncthreads();
     const int d2 = ctl[0], n2 = ctl[1];
     __syncthreads();
@@ -370,30 +370,44 @@ __device__ __forceinline__ void scan_band_keys(const ScoreSrc &sc, int N, float 
 // Returns false (nothing written) when a bin of the band holds more than 32 keys: the caller then sorts the old way.
 // `for_each_band_key(fn)`: calls fn(key) for this thread's share of the band's keys (every key exactly once over the
 // workgroup): a scan of all N scores, or -- cluster mode -- the list the cluster's ranks compacted into the workspace.
-// `counts` / `bin_of`: the 2048 counts the band was chosen from and the bin of a key in them -- the linear bins, or (a band that is
-// the top bin's sub-bins >= d: a saturated head) the top bin's sub-bins; the suffix sums at hist + 4096 are those of `counts`.
-template <class ForEachKey, class BinOf>
-__device__ inline bool band_order_linear(ForEachKey for_each_band_key, BinOf bin_of, const unsigned *counts, int d, int n, unsigned *hist,
+// Two levels: hist[0, 2048) are the linear bins' counts, hist[2048, 4096) the counts of the TOP bin's 2048 sub-bins (filled in the same
+// pass); hist[4096, 6144) / [6144, 8192) their exclusive suffix sums (hist_suffix_find).  A key's segment index is its linear bin, or --
+// `use_sub`: the top bin holds more than 32 keys, a saturated head -- 2048 + its sub-bin when it lies in the top bin (whose keys come
+// first).  The band = the main bins >= d_main (without the top bin when use_sub) + the sub-bins >= d_sub.  Cursors: the upper half of
+// the `band` area (n <= 2048 keys use the lower half).
+template <class ForEachKey>
+__device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d_main, int d_sub, bool use_sub, int n, unsigned *hist,
                                          unsigned *flag, unsigned long long *band, unsigned *order, unsigned long long *low_out)
 {
     const int tid = fresh_tid();
-    // segment offsets = the suffix sums hist_suffix_find left behind when it chose bin d (keys in the bins above b)
-    unsigned *boff = hist + 4096, *cur = hist + 6144;
+    const unsigned *counts = hist, *boff = hist + 4096;
+    unsigned *cur = reinterpret_cast<unsigned *>(band + 2048);
+    auto seg_of = [&](unsigned long long key) {
+        const float sc = key_score(key);
+        const int mb = linear_bin(sc);
+        return (use_sub && mb == 2047) ? 2048 + linear_sub_bin(sc, 2047) : mb;
+    };
     const int b0 = 2047 - 2 * tid, b1 = 2046 - 2 * tid;
     if (tid == 0) *flag = 0u;
-    cur[b0] = 0u;
-    cur[b1] = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[tid + i * kNmsThreads] = 0u;
     __syncthreads();
-    if ((b0 >= d && counts[b0] > 32u) || (b1 >= d && counts[b1] > 32u)) atomicOr(flag, 1u);
+    // Keys are ranked inside their segment by counting the larger ones: a loop of the segment's length per key.  Up to kSegMax
+    // keys that is still cheaper than compaction + the 1024-key network (~31 k cycles) -- and it is what a saturated head needs:
+    // hundreds of scores that are EXACTLY 1.0 share one sub-bin whatever the binning, and are ordered by their index alone.
+    constexpr unsigned kSegMax = 768u;
+    bool fat = (b0 >= d_main && !(use_sub && b0 == 2047) && counts[b0] > kSegMax) || (b1 >= d_main && counts[b1] > kSegMax);
+    if (use_sub) fat = fat || (b0 >= d_sub && counts[2048 + b0] > kSegMax) || (b1 >= d_sub && counts[2048 + b1] > kSegMax);
+    if (fat) atomicOr(flag, 1u);
     __syncthreads();
     if (*flag != 0u) return false;
-    // scatter: the band's keys to their bins' segments
+    // scatter: the band's keys to their segments
     for_each_band_key([&](unsigned long long key) {
-        const int b = bin_of(key);
+        const int b = seg_of(key);
         band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
     });
     __syncthreads();
-    // rank inside the bin's segment (keys are unique); up to two keys per thread (n <= 2048)
+    // rank inside the segment (keys are unique); up to two keys per thread (n <= 2048)
     unsigned long long key[2] = {0ull, 0ull};
     int pos[2] = {-1, -1};
 #pragma unroll
@@ -401,7 +415,7 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, BinOf bin
         const int i = tid + u * kNmsThreads;
         if (i < n) {
             key[u] = band[i];
-            const int b = bin_of(key[u]);
+            const int b = seg_of(key[u]);
             const int seg0 = (int)boff[b], cnt = (int)counts[b];
             int rank = 0;
             for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key[u] ? 1 : 0;
@@ -574,7 +588,7 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &s
                 return 0;
             sub = hist;
         }
-        hist_suffix_find(sub, hist + 4096, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
+        hist_suffix_find(sub, sub == hist ? hist + 4096 : hist + 6144, want - above, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
         __syncthreads();
         const int d2 = ctl[0], n2 = ctl[1];
         __syncthreads();
@@ -777,18 +791,23 @@ nms_kernel(NmsArgs p)
             return __hip_atomic_load(cl.band + (size_t)r * cl.region + (i - ctl[CTL_CLPRE + r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         if (lin_bin > 0 && band_expected <= 2 * kNmsThreads && p.linear_select != 2) {
-            const bool by_sub = lin_bin >= 4096;             // ordered by the top bin's sub-bins (from sub-bin lin_bin - 4096)
-            const unsigned *counts = by_sub ? hist + 2048 : hist;
-            const int d_ord = by_sub ? lin_bin - 4096 : lin_bin;
-            auto bin_of = [&](unsigned long long key) { return by_sub ? linear_sub_bin(key_score(key), 2047) : linear_bin(key_score(key)); };
+            // the band: main bins >= lin_bin, or (lin_bin >= 4096: the selection refined inside the top bin) the top bin's
+            // sub-bins >= lin_bin - 4096.  A top bin of more than 32 keys (a saturated head) is ordered by its sub-bins either way.
+            const bool refined_top = lin_bin >= 4096;
+            const bool use_sub = refined_top || hist[2047] > 32u;       // (a top bin of a few keys is one segment like any other)
+            if (use_sub && !refined_top) {       // the sub-bins' suffix sums (the refined selection left them at hist + 6144)
+                hist_suffix_find(hist + 2048, hist + 6144, 0x3fffffff, ctl + CTL_SEL, reinterpret_cast<unsigned *>(ctl + CTL_SEL) + 12);
+                __syncthreads();
+            }
+            const int d_main = refined_top ? 2048 : lin_bin, d_sub = refined_top ? lin_bin - 4096 : 0;
             unsigned *oflag = reinterpret_cast<unsigned *>(ctl + CTL_OFLAG);
             if (from_cluster)
                 ordered = band_order_linear([&](auto fn) { for (int i = fresh_tid(); i < band_expected; i += kNmsThreads) fn(cluster_key(i)); },
-                                            bin_of, counts, d_ord, band_expected, hist, oflag, band, order,
+                                            d_main, d_sub, use_sub, band_expected, hist, oflag, band, order,
                                             reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             else
             ordered = band_order_linear([&](auto fn) { scan_band_keys(src, N, p.score_thr, thr, hi_bound, fn); },
-                                        bin_of, counts, d_ord, band_expected, hist, oflag, band, order,
+                                        d_main, d_sub, use_sub, band_expected, hist, oflag, band, order,
                                         reinterpret_cast<unsigned long long *>(ctl + CTL_LOW));
             if (ordered) {
                 band_n = band_expected;
