@@ -32,6 +32,8 @@
  *                                 bitonic sort only; 2: histogram select, sorted the old way
  *   RPN_KNOB RPN_NMS_CLUSTER (0 = automatic)  workgroups per (image, class) that share the NMS band selection
  *                                 when few images have many anchors; 1: always one workgroup
+ *   RPN_KNOB RPN_NMS_PRUNE   (1)  NMS candidates meet only the selected boxes whose AREA allows the IoU threshold
+ *                                 (area-ordered copy of the selected list); 0: the whole list
  *   RPN_KNOB RPN_MN_FUSE     (1)  MobileNetV2: one launch per inverted-residual block; 0: layer by layer
  *   RPN_KNOB RPN_MN_X3       (1)  MobileNetV2 under f16x3: 16-bit MFMA GEMMs inside the fused blocks; 0: f32 MFMA
  * Kernel / tile selection switches for A/B timing and the timing experiments whose results are

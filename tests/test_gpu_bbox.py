@@ -298,6 +298,75 @@ def test_nms_ratios_on_and_next_to_the_threshold():
                iou_threshold=0.7, clip_boxes=False)
 
 
+def _nested_families(rng, thr, n_fam=640):
+    """Families (outer box, inner box nested in it): the IoU of a nested pair IS its area ratio, set to thr * (1 + k 2^-20)
+    for k over a range that straddles both the threshold and the area-pruning bound thr * (1 - 2^-19); families sit at
+    magnitudes 2^-9 .. 2^2 (areas 2^-22 .. 2^4: below the first area bin, inside the table, above its last bin)."""
+    rows = []
+    for f in range(n_fam):
+        mag = np.float32(2.0 ** rng.randint(-9, 3))
+        y, x = (np.float32(rng.uniform(0, 40, size=2)) * mag).astype(np.float32)
+        h, w = (np.float32(rng.uniform(0.5, 1.0, size=2)) * mag).astype(np.float32)
+        k = rng.randint(-48, 49)
+        r = np.float32(thr) * np.float32(1 + k * 2.0 ** -20)
+        if f % 3 == 0:                                   # ratio split over both sides
+            fy = np.float32(np.sqrt(r)); fx = np.float32(r / fy)
+        else:
+            fy = np.float32(1); fx = r
+        rows.append(([y, x, y + h, x + w], [y, x, y + h * fy, x + w * fx]))
+    return rows
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.95])
+def test_nms_area_pruning_bounds_on_nested_boxes(thr):
+    """The tests against the boxes selected in earlier chunks skip pairs whose areas differ by more than the threshold allows
+    (nms_kernels.hip, prune_bin).  Sharpest case: nested boxes, whose IoU equals the area ratio -- ratios on both sides of the
+    threshold and of the pruning bound, at every magnitude of the area-bin table, with the partner selected several chunks
+    (256 candidates) earlier: first the outer boxes lead (a candidate smaller than the selected box), then the inner ones."""
+    rng = np.random.RandomState(41)
+    fam = _nested_families(rng, thr)
+    n = len(fam)
+    for inner_first in (False, True):
+        first = np.float32([f[1 if inner_first else 0] for f in fam])
+        second = np.float32([f[0 if inner_first else 1] for f in fam])
+        boxes = np.concatenate([first, second])[None]
+        base = cases.permutation_scores(rng, 1, 2 * n)[0]
+        order = np.sort(base)[::-1]
+        scores = np.empty(2 * n, np.float32)
+        scores[rng.permutation(n)] = order[:n]                     # the leaders take the n best scores
+        scores[n + rng.permutation(n)] = order[n:]
+        got = _check_nms(boxes[:, :, None, :], scores[None, :, None], max_output_size_per_class=1200, max_total_size=1200,
+                         iou_threshold=thr, clip_boxes=False)
+        assert n // 2 < got[3][0] < 2 * n                        # (some partners are suppressed, some are not)
+
+
+@pytest.mark.gpu
+def test_nms_without_area_pruning_subprocess():
+    """RPN_NMS_PRUNE=0 (read once per process): every candidate is tested against the whole selected list, as before the area
+    bins existed.  Same outputs as the oracle on C3-shaped input and on the nested-box families."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import cases
+        from oracle import bbox_oracle as bo
+        from tests.test_gpu_bbox import _check_nms, VAR, test_nms_area_pruning_bounds_on_nested_boxes
+        anchors = bo.generate_anchors(bo.get_hyper_params("vgg16")); A = len(anchors)
+        deltas = np.random.RandomState(2).standard_normal((4, A, 4)).astype(np.float32)
+        boxes = bo.get_bboxes_from_deltas(anchors, bo.scale_deltas(deltas, VAR))
+        scores = cases.permutation_scores(np.random.RandomState(3), 4, A)
+        for thr in (0.5, 0.7):
+            _check_nms(boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                       iou_threshold=thr)
+        test_nms_area_pruning_bounds_on_nested_boxes(0.7)
+        print("nms unpruned ok")
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPN_NMS_PRUNE="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "nms unpruned ok" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_nms_without_the_linear_histogram_subprocess(mode):

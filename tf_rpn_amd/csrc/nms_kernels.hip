@@ -103,7 +103,29 @@ struct NmsArgs {
     int cluster, cl_region;
     unsigned *cl_ctl;
     unsigned long long *cl_band;
+    // area pruning of the tests against the boxes selected in earlier chunks (prune_bin): 0 = off
+    int prune;
+    float prune_lo, prune_hi;   // a pair can only pass the IoU test if area_a * prune_lo <= area_b <= area_a * prune_hi
 };
+
+// ---- area pruning ------------------------------------------------------------------------------------------------
+// IoU(a, b) <= min(area) / max(area), in float32 arithmetic as well: the intersection's height (width) is the rounded
+// difference of a min and a max of the corners, so it is at most either box's own rounded height (width) -- rounding is
+// monotone -- and inter = fl(ih * iw) <= min(area_a, area_b); uni = fl(fl(area_a + area_b) - inter) >= max(area) * (1 - 3 *
+// 2^-24); so TF's quotient fl(inter / uni) <= min / max * (1 + 2^-21).  A pair with min(area) < thr * (1 - 2^-19) * max(area)
+// is therefore "not suppressed" without being tested.  The selected boxes are kept a second time ORDERED BY AREA BIN
+// (quarter octaves: the float's exponent and two mantissa bits, 64 bins from 2^-14 up; everything smaller shares bin 0,
+// everything larger -- and the +inf key of boxes without area, and NaN -- bin 63), with the bins' start offsets; a candidate
+// of area a tests the contiguous run of bins [bin(a * prune_lo), bin(a * prune_hi)] only.  bin() is monotone and the two
+// products are rounded by 2^-24 against 2^-19 of slack in the factors, so every selected box within the ratio is in the run.
+// RPN proposals come from anchors of several scales: at IoU 0.7 a candidate meets about a third of the selected list.
+constexpr int kPruneBins = 64;
+constexpr int kPruneBase = (127 - 14) * 4;
+__device__ __forceinline__ int prune_bin(float area)
+{
+    const int k = (int)(__float_as_uint(area) >> 21) - kPruneBase;     // (a NaN with the sign bit set: > 63 as well)
+    return min(max(k, 0), kPruneBins - 1);
+}
 
 // Descending bitonic sort of n (power of two) 64-bit keys in LDS by the whole workgroup.
 __device__ void bitonic_sort_desc(unsigned long long *keys, int n)
@@ -638,10 +660,10 @@ __device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &s
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 struct LdsLayout {
-    size_t band, hist, sel_c, sel_idx, cbox, mask, dead, picked, ctl, scache, total;
+    size_t band, hist, sel_c, sel_idx, cbox, mask, dead, picked, ctl, scache, srt, pbin, total;
 };
 
-__host__ __device__ inline LdsLayout lds_layout(int max_sel, int cache_n)
+__host__ __device__ inline LdsLayout lds_layout(int max_sel, int cache_n, int prune)
 {
     LdsLayout l;
     size_t o = 0;
@@ -659,6 +681,10 @@ __host__ __device__ inline LdsLayout lds_layout(int max_sel, int cache_n)
     l.picked = o;  o = align16(o + (size_t)4 * kChunk);
     l.ctl = o;     o = align16(o + 256);     // 64 ints: CTL_* | [16, 33) scan scratch | [36, 53) cluster prefix
     l.scache = o;  o = align16(o + (size_t)4 * cache_n);
+    // area pruning: the selected boxes a second time, ordered by area bin (same padding rule as sel_c), and per bin the
+    // count [64] | start offset [65] | placement cursor [64]
+    l.srt = o;     if (prune) o = align16(o + (size_t)16 * (max_sel + 32)) + align16((size_t)4 * (max_sel + 32));
+    l.pbin = o;    if (prune) o = align16(o + (size_t)4 * (3 * kPruneBins + 4));
     l.total = o;
     return l;
 }
@@ -677,7 +703,7 @@ nms_kernel(NmsArgs p)
     int nms_sidx = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const LdsLayout L = lds_layout(p.max_sel, p.cache_n);
+    const LdsLayout L = lds_layout(p.max_sel, p.cache_n, p.prune);
     unsigned long long *band = reinterpret_cast<unsigned long long *>(smem + L.band);
     unsigned *order = reinterpret_cast<unsigned *>(smem + L.band);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + L.hist);
@@ -689,6 +715,9 @@ nms_kernel(NmsArgs p)
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem + L.mask);
     unsigned long long *deadw = reinterpret_cast<unsigned long long *>(smem + L.dead);
     int *ctl = reinterpret_cast<int *>(smem + L.ctl);
+    float4 *srt_c4 = reinterpret_cast<float4 *>(smem + L.srt);               // (p.prune only)
+    float *srt_a = reinterpret_cast<float *>(smem + L.srt + align16((size_t)16 * (p.max_sel + 32)));
+    int *pcnt = reinterpret_cast<int *>(smem + L.pbin), *pstart = pcnt + kPruneBins, *pcur = pstart + kPruneBins + 1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -705,7 +734,12 @@ nms_kernel(NmsArgs p)
     for (int i = tid; i < max_sel + 32; i += kNmsThreads) {
         sel_c4[i] = float4{0.f, 0.f, 0.f, 0.f};
         sel_a[i] = INFINITY;
+        if (p.prune) {
+            srt_c4[i] = float4{0.f, 0.f, 0.f, 0.f};
+            srt_a[i] = INFINITY;
+        }
     }
+    if (p.prune && tid < kPruneBins) pcnt[tid] = 0;
     __syncthreads();
     NMS_STAMP(1);
 
@@ -901,11 +935,31 @@ nms_kernel(NmsArgs p)
                 carea[st] = nms_area_key(cb.area);          // (+inf for area <= 0: see nms_suppresses_fast)
             }
             if (tid < kChunkWords) deadw[tid] = 0ull;
+            if (p.prune && nsel > 0 && (tid >> 6) == 8) {      // one wave: the bins' start offsets from their counts
+                const int cnt = pcnt[lane];
+                int incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += up;
+                }
+                pstart[lane] = incl - cnt;
+                pcur[lane] = incl - cnt;
+                if (lane == 63) pstart[64] = incl;
+            }
             __syncthreads();
 
             if (tid < kChunkWords) {                 // slots past the band end count as dead
                 const int lo = tid * 64;
                 if (T < lo + 64) deadw[tid] = T <= lo ? ~0ull : (~0ull << (T - lo));
+            }
+            if (p.prune) {                           // the selected list, re-ordered by area bin (the order inside a bin is free)
+                for (int i = tid; i < nsel; i += kNmsThreads) {
+                    const float ar = sel_a[i];
+                    const int at = atomicAdd(&pcur[prune_bin(ar)], 1);
+                    srt_c4[at] = sel_c4[i];
+                    srt_a[at] = ar;
+                }
             }
             __syncthreads();
             NMS_STAMP(5);
@@ -938,10 +992,16 @@ nms_kernel(NmsArgs p)
                         // two selected boxes per trip (their LDS reads overlap), a uniform number of trips: the list is
                         // padded to a multiple of 32 with boxes that suppress nothing.  Branch-free: the largest excess
                         // and the smallest margin (nms_excess); the exact tests only if one ratio was close
-                        const float4 *sp = sel_c4 + part;
-                        const float *ap = sel_a + part;
+                        // (area pruning: only the run of area bins whose boxes can reach the threshold with this one)
+                        int run0 = 0, run_n = nsel;
+                        if (p.prune) {
+                            run0 = pstart[prune_bin(ci.area * p.prune_lo)];
+                            run_n = pstart[prune_bin(ci.area * p.prune_hi) + 1] - run0;
+                        }
+                        const float4 *sp = (p.prune ? srt_c4 : sel_c4) + run0 + part;
+                        const float *ap = (p.prune ? srt_a : sel_a) + run0 + part;
                         float ha = -INFINITY, hb = -INFINITY, ma = p.m0, mb = p.m0;
-                        for (int j0 = 0; j0 < nsel; j0 += 32) {
+                        for (int j0 = 0; j0 < run_n; j0 += 32) {
                             const float4 a4 = sp[j0], b4 = sp[j0 + 16];
                             const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j0]}, sb{b4.x, b4.y, b4.z, b4.w, ap[j0 + 16]};
                             ha = vmax_vv(ha, nms_excess(ci, sa, p.iou_thr, p.iou_eps, ma));
@@ -949,10 +1009,10 @@ nms_kernel(NmsArgs p)
                         }
                         hit = vmax_vv(ha, hb) > 0.0f;
                         if (!(vmin_vv(ma, mb) > 1e-30f)) {
-                            hit = false;
-                            for (int j = part; j < nsel; j += 16) {
-                                const float4 a4 = sel_c4[j];
-                                const CBox sa{a4.x, a4.y, a4.z, a4.w, sel_a[j]};
+                            hit = false;                // (the same entries as this lane's loop above, padding included)
+                            for (int j = 0; j < ((run_n + 31) & ~31); j += 16) {
+                                const float4 a4 = sp[j];
+                                const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j]};
                                 hit |= nms_suppresses(ci, sa, p.iou_thr, p.iou_lo, p.iou_hi);
                             }
                         }
@@ -1073,6 +1133,8 @@ nms_kernel(NmsArgs p)
                     // (finer items when there are few of them: 8 or 4 candidates per thread instead of 16)
                     const int tid = fresh_tid();
                     const int c_new = ctl[CTL_NSEL];
+                    if (p.prune && tid >= kNmsThreads - 64 && tid - (kNmsThreads - 64) < c_new - cur)    // the new boxes' area bins
+                        atomicAdd(&pcnt[prune_bin(sel_a[cur + tid - (kNmsThreads - 64)])], 1);
                     const int npl = 4 * (kChunkWords - 1 - gw);
                     const int items16 = c_new < max_sel ? (c_new - cur) * npl : 0;    // (output complete: nothing follows)
                     const int fsh = items16 <= kNmsThreads / 4 ? 2 : (items16 <= kNmsThreads / 2 ? 1 : 0);   // log2(parts per piece)
@@ -1299,8 +1361,15 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     p.cluster = cluster_size(p.B * p.C, p.N);
     if (p.cluster > 1 && (!d_workspace || workspace_bytes < stage_bytes(p.B, p.C, p.max_sel) + cluster_bytes(p.B * p.C, p.cluster, p.N)))
         p.cluster = 1;
-    if (p.linear_select && p.cluster == 1 && p.N <= kScoreCacheMax && lds_layout(p.max_sel, p.N).total <= kLdsLimit) p.cache_n = p.N;
-    const LdsLayout L = lds_layout(p.max_sel, p.cache_n);
+    // area pruning: a threshold in [0.3, 1) (a candidate's run of area bins is then at most 18 of the 64) on the fast test path
+    static const int prune = RPN_KNOB("RPN_NMS_PRUNE", 1);
+    p.prune = prune && fast && p.iou_thr >= 0.3f && p.iou_thr < 1.0f && lds_layout(p.max_sel, 0, 1).total <= kLdsLimit;
+    if (p.prune) {
+        p.prune_lo = p.iou_thr * (1.0f - 0x1p-19f);
+        p.prune_hi = 1.0f / p.prune_lo * (1.0f + 0x1p-22f);        // (the quotient's own rounding is 2^-24)
+    }
+    if (p.linear_select && p.cluster == 1 && p.N <= kScoreCacheMax && lds_layout(p.max_sel, p.N, p.prune).total <= kLdsLimit) p.cache_n = p.N;
+    const LdsLayout L = lds_layout(p.max_sel, p.cache_n, p.prune);
     if (L.total > kLdsLimit)
         return fail(RPN_ERR_UNSUPPORTED, "nms: %zu bytes of LDS needed (max per class=%d) > %zu", L.total, p.max_sel,
                     kLdsLimit);
