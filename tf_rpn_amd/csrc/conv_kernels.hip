@@ -297,11 +297,15 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #endif
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
+            // MFMA step kk multiplies channels (4 q + e, 4 q + 2 + e), q = kk / 2, e = kk % 2: a quad's products enter an
+            // accumulator in the order 0, 2, 1, 3 -- the order of conv_igemm_f32_dma (8-byte fragment reads), so that a layer
+            // gives the same bits whichever of the two kernels and whichever tile width its grid size selects
+            const int krow = GENERIC ? 2 * kk + kh : 4 * (kk >> 1) + 2 * kh + (kk & 1);
             float av[MI], bv[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = As[cur][2 * kk + kh][am + 32 * i];
+            for (int i = 0; i < MI; ++i) av[i] = As[cur][krow][am + 32 * i];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bv[j] = Bs[cur][2 * kk + kh][bn + 32 * j];
+            for (int j = 0; j < NI; ++j) bv[j] = Bs[cur][krow][bn + 32 * j];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -327,67 +331,179 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     return;
 #endif
 
-    // ---- epilogue: bias + residual + activation, NHWC stores (32 lanes = 128 contiguous bytes) --
+#include "conv_f32_epilogue.inc"
+}
+
+// ---- the same GEMM with LDS-DMA staging (`buffer_load ... lds`) --------------------------------------------------------
+// conv_igemm_f32<.., false> stages a slice through registers: 4 global loads, 10 ds_write, a wait and the registers in between
+// per thread and slice, on the issue port the float32 MFMA shares with the vector ALU -- with the gather compiled out
+// (RPN_EXP_F32_NOGATHER) the 128 x 128 tile ran at 0.86-0.88 of the MFMA peak against 0.76 with it.  Here every wave issues
+// FOUR instructions per slice instead: two 1 KB pieces of the A tile and up to two of the B tile go global -> LDS directly
+// (no registers, no ds_write), into the buffer the MFMAs are not reading; one `s_waitcnt vmcnt(0)` + barrier per slice as
+// before, covered by the other workgroups of the CU.
+//   A tile in LDS: pixel-major 16-byte pieces, piece e = 4 m + (q ^ ((m >> 2) & 3)) holds channels 4q .. 4q+3 of pixel m
+//     of the slice.  The LDS side of a DMA is lane-linear, so the permutation is applied on the SOURCE address: instruction
+//     i of a slice covers pixels 16 i .. 16 i + 15, lane l fetches pixel 16 i + (l >> 2), quad (l & 3) ^ ((m >> 2) & 3) --
+//     16 whole 64-byte lines per instruction.  An out-of-image pixel / a quad beyond Cin is an out-of-range offset: zeros.
+//   A fragments: lane (m, kh = lane >> 5) reads channels 2 kh, 2 kh + 1 of quad q as ONE ds_read_b64 (half the fragment
+//     reads of the k-major tile; the XOR keeps the 32 lanes of a half-wave on 16 different piece columns, two lanes each:
+//     the floor for 8-byte reads at a 64-byte pixel pitch) and feeds two MFMAs: k-pairs (4q, 4q + 2) then (4q + 1, 4q + 3).
+//     A quad's four products therefore enter an accumulator in the order 0, 2, 1, 3 -- every non-generic layer runs on
+//     this kernel at every tile width, so an image's bits do not depend on the batch it is in (tests: batch invariance).
+//   B tile: the packed weight rows of the slice, [16][BN] floats, a linear copy (BN / 64 instructions per wave; at BN = 32
+//     two waves issue one each).
+template <int WM, int WN, int MI, int NI>
+__global__ void __launch_bounds__(kConvThreads, 2)
+conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    static_assert(WM * WN == 4 && WM * MI * 32 == BM, "tile shape");
+    constexpr int BN = WN * NI * 32;
+    constexpr int B_INSTR = BK * BN / 256;              // 1 KB instructions per B slice: 8, 4 or 2
+    constexpr int B_ROWS = 256 / BN;                    // weight rows per instruction: 2, 4 or 8
+    constexpr int B_PER_WAVE = B_INSTR >= 4 ? B_INSTR / 4 : 1;
+
+    __shared__ __attribute__((aligned(16))) float4 As4[2][BM * 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = wg % n_tiles;
+    int mt = wg / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
+
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const int cpt = a.ps.cin_pad / BK;                  // slices per tap
+    const int nsteps = a.R * a.S * cpt;
+
+    constexpr unsigned kOobF = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), (short)0, (int)((size_t)a.H * a.W * a.Cin * 4 > 0x7fffffffull ? 0x7fffffff : (size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), (short)0, (int)(a.ps.floats() * 4 > 0x7fffffffull ? 0x7fffffff : a.ps.floats() * 4), 0x00020000);
+
+    // this lane's two pieces of an A slice: instruction 2 wave + j, pixel m_j = 32 wave + 16 j + (lane >> 2)
+    int a_off0[2], a_cq[2];             // byte offset of (pixel, tap (0,0), its channel quad) -- may be negative; the quad's first channel
+    unsigned a_taps[2];                 // bit t: tap t of the pixel lies inside the image
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * NI * 32 + j * 32 + (lane & 31);
-        if (n >= a.Cout) continue;
-        const float bias = a.bias ? a.bias[n] : 0.0f;
-        const bool second = n >= a.split;
-        const int act = second ? a.act2 : a.act;
-        float *__restrict__ obase = second ? a.out2 : a.out;
-        const int ld = second ? a.ld2 : a.ld1;
-        const int ch = second ? n - a.split : n;
-        if (a.out_split) {
-            // SPLIT16 record of (pixel, 16-channel slice) = {hi[0:8], lo[0:8], hi[8:16], lo[8:16]} 16-bit halves
-            // (x ~ hi + lo).  Lanes (2t, 2t+1) hold channels (2t, 2t+1): the even lane stores the pair's hi dword, the
-            // odd lane its lo dword -- one 4-byte store per lane, the 32 lanes cover the pixel's two 64-byte records.
-            unsigned *__restrict__ o32 = reinterpret_cast<unsigned *>(a.out);
-            const int cj = n & 15, odd = lane & 1;
-            const int dw = (n >> 4) * 16 + (cj >> 3) * 8 + odd * 4 + ((cj & 7) >> 1);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = wm * MI * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                    const float v = apply_act(acc[i][j][e] + bias, act);
-                    unsigned hi, lo;
-                    if (a.out_split == 2) {
-                        if (a.status && !(fabsf(v) <= 65504.0f)) atomicOr(a.status, 1u);
-                        const _Float16 h = (_Float16)v;
-                        const _Float16 l = (_Float16)(v - (float)h);
-                        hi = __builtin_bit_cast(unsigned short, h);
-                        lo = __builtin_bit_cast(unsigned short, l);
-                    } else {
-                        const __bf16 h = (__bf16)v;
-                        const __bf16 l = (__bf16)(v - (float)h);
-                        hi = __builtin_bit_cast(unsigned short, h);
-                        lo = __builtin_bit_cast(unsigned short, l);
-                    }
-                    const unsigned got = __shfl_xor(odd ? hi : lo, 1);          // even lane <- partner's hi, odd <- partner's lo
-                    const unsigned word = odd ? (got | (lo << 16)) : (hi | (got << 16));
-                    if (oy < a.OH && ox < a.OW)
-                        o32[(((size_t)img * a.OH + oy) * a.OW + ox) * a.Cout + dw] = word;
-                }
+    for (int j = 0; j < 2; ++j) {
+        const int m = 32 * wave + 16 * j + (lane >> 2);
+        const int q = (lane & 3) ^ ((m >> 2) & 3);
+        const int iy0 = (oy0 + (m >> 4)) * a.stride - a.pad_t, ix0 = (ox0 + (m & 15)) * a.stride - a.pad_l;
+        a_cq[j] = 4 * q;
+        a_off0[j] = ((iy0 * a.W + ix0) * a.Cin + 4 * q) * 4;
+        unsigned msk = 0;
+        int t = 0;
+        for (int r = 0; r < a.R; ++r)
+            for (int s = 0; s < a.S; ++s, ++t) {
+                const int iy = iy0 + r, ix = ix0 + s;
+                if (t < 32 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) msk |= 1u << t;
             }
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = wm * MI * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < a.OH && ox < a.OW) {
-                    const size_t pix = ((size_t)img * a.OH + oy) * a.OW + ox;
-                    float v = acc[i][j][e] + bias;
-                    if (a.residual) v += a.residual[pix * a.Cout + n];
-                    obase[pix * ld + ch] = apply_act(v, act);
-                }
-            }
+        a_taps[j] = msk;
+    }
+    // this lane's pieces of a B slice: instruction ib = B_PER_WAVE * wave + t covers rows ib * B_ROWS ..., 4 columns per lane
+    unsigned b_off0 = kOobF, b_off1 = kOobF;
+    {
+        const int col = n0 + 4 * (lane % (BN / 4));
+        const int row0 = (B_PER_WAVE * wave) * B_ROWS + lane / (BN / 4);
+        if (col < a.ps.cout_pad) {
+            b_off0 = (unsigned)((row0 * a.ps.cout_pad + col) * 4);
+            b_off1 = (unsigned)(((row0 + B_ROWS) * a.ps.cout_pad + col) * 4);
         }
     }
+    const bool b_wave = B_PER_WAVE * wave < B_INSTR;     // (BN = 32: waves 0 and 1 only)
+
+    // walk state of the NEXT slice to fetch: tap index, its (r, s), slice within the tap, byte offsets
+    int w_tap = 0, w_r = 0, w_s = 0, w_cs = 0, w_tapoff = 0, w_brow = 0;
+    const int b_step = 16 * a.ps.cout_pad * 4;          // bytes per slice of the packed weight matrix
+#define RPN_F32_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+    auto fetch = [&](int buf) {
+        const int c0 = w_cs * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool v = c0 + a_cq[j] < a.Cin && ((a_taps[j] >> w_tap) & 1u);
+            const unsigned off = v ? (unsigned)(a_off0[j] + w_tapoff + c0 * 4) : kOobF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, RPN_F32_LDS_PTR(&As4[buf][(2 * wave + j) * 64]), 16, off, 0, 0, 0);
+        }
+        if (b_wave) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, RPN_F32_LDS_PTR(&Bs[buf][0][0] + (B_PER_WAVE * wave) * 256), 16, b_off0,
+                                                     w_brow, 0, 0);
+            if constexpr (B_PER_WAVE == 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, RPN_F32_LDS_PTR(&Bs[buf][0][0] + (2 * wave + 1) * 256), 16, b_off1,
+                                                         w_brow, 0, 0);
+        }
+        w_brow += b_step;
+        if (++w_cs == cpt) {                             // next tap (scalar bookkeeping)
+            w_cs = 0;
+            ++w_tap;
+            if (++w_s == a.S) { w_s = 0; ++w_r; }
+            w_tapoff = (w_r * a.W + w_s) * a.Cin * 4;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int kh = lane >> 5;
+    // fragment addresses: float index of (pixel am + 32 i, quad 0, channel 2 kh); quad q is at (that ^ (q << 2)) -- the XOR term
+    // (m >> 2) & 3 sits in the same two bits
+    int a_idx[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wm * MI * 32 + (lane & 31) + 32 * i;
+        a_idx[i] = 16 * m + 4 * ((m >> 2) & 3);
+    }
+    const int bn = wn * NI * 32 + (lane & 31);
+
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) fetch(cur ^ 1);
+        const float *Af = reinterpret_cast<const float *>(&As4[cur][0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float2 av[MI];
+            float b0[NI], b1[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[i] = *reinterpret_cast<const float2 *>(Af + ((a_idx[i] ^ (q << 2)) + 2 * kh));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                b0[j] = Bs[cur][4 * q + 2 * kh][bn + 32 * j];
+                b1[j] = Bs[cur][4 * q + 2 * kh + 1][bn + 32 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, b1[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next slice has landed; this one's fragment reads are done
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+#undef RPN_F32_LDS_PTR
+
+#include "conv_f32_epilogue.inc"
 }
 
 template <int WM, int WN, int MI, int NI>
@@ -401,9 +517,18 @@ static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
     if (a.ps.generic)
         hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                            stream, a, tiles_x, tiles_y, n_tiles);
-    else
-        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
-                           stream, a, tiles_x, tiles_y, n_tiles);
+    else {
+        // (laboratory builds: RPN_F32_DMA=0: register-staged kernel everywhere, 2: DMA kernel everywhere; same bits)
+        // the DMA kernel on the 128-wide tile (+2.5 ... 3.6 % per layer); the narrower tiles are what small grids get (two
+        // workgroups per CU: nothing covers the DMA's longer latency there -- 31 x 31 x 512 at batch 8: 0.406 against 0.341 ms)
+        static const int dma = RPN_LAB_KNOB("RPN_F32_DMA", 1);
+        if (dma == 2 || (dma == 1 && BN == 128))
+            hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream, a,
+                               tiles_x, tiles_y, n_tiles);
+        else
+            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+                               stream, a, tiles_x, tiles_y, n_tiles);
+    }
     return hipGetLastError();
 }
 
