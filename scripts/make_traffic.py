@@ -15,6 +15,8 @@ def fam(k):
     if m: return "vgg_block1<%s>" % prec(m.group(5))
     m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(, false)?>", k)
     if m: return "conv3x3_split<%s>" % prec(m.group(5))
+    m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)>", k)
+    if m: return "conv_igemm_f32_dma<128x%d>" % (32 * int(m.group(2)) * int(m.group(4)))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
     if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
     return "nms_kernel" if "nms_kernel" in k else "conv_cin3" if "conv_cin3" in k else None

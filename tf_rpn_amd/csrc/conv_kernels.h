@@ -50,6 +50,7 @@ struct ConvArgs {
 // dense convolution as an implicit GEMM on the f32 MFMA; returns hipGetLastError()
 int conv_f32_tile_n(int B, int OH, int OW, int Cout);   // N tile (128 | 64 | 32) launch_conv_f32 picks for a layer
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream);
+bool conv_f32_uses_dma(int tile_n, int generic);       // whether that tile runs on conv_igemm_f32_dma (LDS-DMA staging)
 
 // RPN head (rpn_reg | rpn_cls 1x1 convs on a 512-channel float32 NHWC tensor of P pixels) as one split-K launch:
 // w_packed = pack_head_weights_host(matrix [512][ld] whose columns are reg then cls) -- 512 * 16 * ceil(ncols / 16) floats;

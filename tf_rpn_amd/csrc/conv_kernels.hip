@@ -506,6 +506,8 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 #include "conv_f32_epilogue.inc"
 }
 
+bool conv_f32_uses_dma(int tile_n, int generic);
+
 template <int WM, int WN, int MI, int NI>
 static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
 {
@@ -521,8 +523,7 @@ static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
         // (laboratory builds: RPN_F32_DMA=0: register-staged kernel everywhere, 2: DMA kernel everywhere; same bits)
         // the DMA kernel on the 128-wide tile (+2.5 ... 3.6 % per layer); the narrower tiles are what small grids get (two
         // workgroups per CU: nothing covers the DMA's longer latency there -- 31 x 31 x 512 at batch 8: 0.406 against 0.341 ms)
-        static const int dma = RPN_LAB_KNOB("RPN_F32_DMA", 1);
-        if (dma == 2 || (dma == 1 && BN == 128))
+        if (conv_f32_uses_dma(BN, 0))
             hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream, a,
                                tiles_x, tiles_y, n_tiles);
         else
@@ -552,6 +553,12 @@ int conv_f32_tile_n(int B, int OH, int OW, int Cout)
     int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     while (bn > 32 && m_tiles * ((Cout + bn - 1) / bn) < (long long)occ * n_cus) bn >>= 1;
     return bn;
+}
+
+bool conv_f32_uses_dma(int tile_n, int generic)
+{
+    static const int dma = RPN_LAB_KNOB("RPN_F32_DMA", 1);
+    return !generic && (dma == 2 || (dma == 1 && tile_n == 128));
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream)

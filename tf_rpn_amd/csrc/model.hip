@@ -1058,8 +1058,11 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout) && head_splitk())
             snprintf(kname32, sizeof kname32, "rpn_head_splitk<%d>", (op.Cout + 15) / 16);
         else
-            snprintf(kname32, sizeof kname32, "conv_igemm_f32<128x%d%s>", conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout),
+        {
+            const int bn32 = conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout);
+            snprintf(kname32, sizeof kname32, "conv_igemm_f32%s<128x%d%s>", conv_f32_uses_dma(bn32, op.ps.generic) ? "_dma" : "", bn32,
                      op.ps.generic ? ",generic" : "");
+        }
         k = kname32;
     } else if (op.kind == OP_VGGB1) {
         fl = 2.0 * op.H * op.W * 64 * 9.0 * (3 + 64);
