@@ -24,8 +24,9 @@
  * floats within the documented bound -- they select between implementations:
  *   RPN_KNOB RPN_B1_FUSE     (1)  VGG16 block 1 as one launch under f16x3; 0: two kernels
  *   RPN_KNOB RPN_HEAD_SPLITK (1)  rpn_reg | rpn_cls on the split-K head kernel; 0: generic f32 implicit GEMM
- *   RPN_KNOB RPN_KSPLIT      (0)  1: rpn_conv split along K at small batches (lower latency; a batch-1 result is
- *                                 then no longer bit-identical to the same image inside a larger batch)
+ *   RPN_KNOB RPN_KSPLIT      (1)  rpn_conv (split-precision modes) as a K tree: four fixed leaves of K, value (l0 + l1) +
+ *                                 (l2 + l3) at every batch size, computed by 1, 2 or 4 workgroups per tile as the grid
+ *                                 allows (same bits); 0: one accumulation chain, one workgroup per tile
  *   RPN_KNOB RPN_S16_DYN     (0)  1: dynamic tile queue in the persistent split-precision conv kernel
  *   RPN_KNOB RPN_S16_C64     (0)  1: block1_conv2 on the persistent kernel's 64-wide tiles
  *   RPN_KNOB RPN_NMS_LINEAR  (1)  NMS band selection from the linear score histogram; 0: radix select +

@@ -43,7 +43,7 @@ def bench_name(k):
     """rocprofv3 kernel name -> the kernel name bench.py prints for the op (both POOL instantiations together)."""
     import re
     prec = lambda f16: "f16x3" if f16 == "true" else "bf16x3"
-    m = re.search(r"conv3x3_split16_dma_kernel<(true|false), (true|false), (\d+)>", k)
+    m = re.search(r"conv3x3_split16_dma_kernel<(true|false), (true|false), (\d+)(?:, (?:true|false))?>", k)
     if m: return "conv3x3_split16_dma<%s,%s>" % (prec(m.group(1)), m.group(3))
     m = re.search(r"conv3x3_split16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", k)
     if m: return "conv3x3_split16<%s,%d>" % (prec(m.group(4)), 64 * int(m.group(2)))

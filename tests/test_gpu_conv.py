@@ -2,6 +2,7 @@
 on seeded inputs.  Floating point: tolerance 1e-4 absolute on head outputs (north star); single layers are
 held to a relative bound derived from the f32 MFMA's ordered-fmaf numerics."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -219,6 +220,61 @@ def test_mobilenet_v2_batch_invariance_across_ksplit_factors(img, fm):
     assert torch.isfinite(reg).all() and not model.status()["f16_range"]
     ref = cv.rpn_forward("mobilenet_v2", imgs[:1].cpu().numpy(), synthetic_weights("mobilenet_v2", hp, seed=1), dtype=torch.float64)
     assert np.abs(reg[:1].cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls[:1].cpu().numpy() - ref[1]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("backbone,precision", [("mobilenet_v2", "f16x3"), ("vgg16", "f16x3"), ("vgg16", "bf16x3")])
+def test_rpn_conv_k_tree_same_bits_at_every_split_factor(backbone, precision):
+    """rpn_conv in the split-precision modes is a K TREE: four fixed leaves of K, value (l0 + l1) + (l2 + l3).  One image
+    (64 workgroups of 4 x 32 x 64: four per tile, one leaf each, the head adds four slabs), three images (two per tile: l0 + l1
+    and l2 + l3 as slabs) and eight (the persistent 64-wide kernel walks all of K and folds the leaves in its tile loop) must
+    give BIT-identical outputs for the same image; a model that keeps every activation never splits (tolerance: its
+    upstream layers run on other kernels)."""
+    hp = bo.get_hyper_params(backbone)
+    weights = synthetic_weights(backbone, hp, seed=3)
+    model = RPNModel(backbone, hp, precision=precision, max_batch=8)
+    model.set_weights(weights)
+    imgs = torch.rand((8, 500, 500, 3), generator=torch.Generator().manual_seed(5)).cuda()
+    reg, cls = model.predict_on_batch(imgs)
+    reg, cls = reg.clone(), cls.clone()
+    for nb in (1, 3, 4, 5):
+        r, c = model.predict_on_batch(imgs[:nb].contiguous())
+        assert torch.equal(r, reg[:nb]) and torch.equal(c, cls[:nb]), nb
+    r, c = model.predict_on_batch(imgs[7:8].contiguous())
+    assert torch.equal(r[0], reg[7]) and torch.equal(c[0], cls[7])
+    keep = RPNModel(backbone, hp, precision=precision, max_batch=2, keep_activations=True)   # (layer by layer: other kernels
+    keep.set_weights(weights)                                                                # upstream, so not the same bits)
+    rk, ck = keep.predict_on_batch(imgs[:2].contiguous())
+    assert (rk - reg[:2]).abs().max().item() <= 2e-5 and (ck - cls[:2]).abs().max().item() <= 2e-5
+    ref = cv.rpn_forward(backbone, imgs[:1].cpu().numpy(), weights, dtype=torch.float64)
+    assert np.abs(reg[:1].cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls[:1].cpu().numpy() - ref[1]).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_rpn_conv_one_chain_subprocess():
+    """RPN_KSPLIT=0 (read once per process): rpn_conv as ONE accumulation chain at every batch size, as before the K tree
+    (one workgroup per tile walks all of K at batch 1).  Same tolerance against the oracle, same batch invariance."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from oracle import bbox_oracle as bo
+        from oracle import conv_oracle as cv
+        from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+        hp = bo.get_hyper_params("mobilenet_v2")
+        w = synthetic_weights("mobilenet_v2", hp, seed=3)
+        m = RPNModel("mobilenet_v2", hp, precision="f16x3", max_batch=4); m.set_weights(w)
+        imgs = torch.rand((4, 500, 500, 3), generator=torch.Generator().manual_seed(5)).cuda()
+        reg, cls = m.predict_on_batch(imgs); reg, cls = reg.clone(), cls.clone()
+        r1, c1 = m.predict_on_batch(imgs[:1].contiguous())
+        assert torch.equal(r1[0], reg[0]) and torch.equal(c1[0], cls[0])
+        ref = cv.rpn_forward("mobilenet_v2", imgs[:1].cpu().numpy(), w, dtype=torch.float64)
+        assert np.abs(reg[:1].cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls[:1].cpu().numpy() - ref[1]).max() <= 1e-4
+        print("one chain ok")
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPN_KSPLIT="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "one chain ok" in r.stdout
 
 
 def test_forward_requires_all_weights():

@@ -57,8 +57,8 @@ bool conv_f32_uses_dma(int tile_n, int generic);       // whether that tile runs
 // bias[ncols]; reg (P, n_reg) linear, cls (P, n_cls) sigmoid.  ncols = n_reg + n_cls <= 96.
 bool rpn_head_supported(int Cin, int ncols);
 void pack_head_weights_host(const float *w, int ld, int ncols, float *dst);
-// n_slabs >= 2: x is n_slabs RAW partial-sum slabs of the preceding conv (slab_floats apart); the head adds them in slab
-// order, + conv_bias, ReLU (rpn_conv's epilogue), while it loads its operand.
+// n_slabs = 2 | 4: x is that many RAW partial-sum slabs of the preceding conv (slab_floats apart); the head adds them in TREE
+// order -- s0 + s1, or (s0 + s1) + (s2 + s3) -- then + conv_bias, ReLU (rpn_conv's epilogue), while it loads its operand.
 hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
                            float *reg, float *cls, hipStream_t stream, int n_slabs = 1, long long slab_floats = 0,
                            const float *conv_bias = nullptr);
@@ -125,13 +125,18 @@ void pack_weights_split_host(const float *hwio, const float *scale, int Cin, int
 // 16x16x32-MFMA variant: weights in "split32" packing [Cin/32][9][cout_pad][128 B] (same byte count)
 void pack_weights_split32_host(const float *hwio, const float *scale, int Cin, int Cout, int cout_pad, bool f16,
                                int shift, unsigned short *dst);
+// (ktree: the layer as a K TREE -- conv3x3_split16_ktree_ok -- unsplit: float32 output, no pool, persistent 64-wide kernel)
 hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                   int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                  bool pool, hipStream_t s);
+                                  bool pool, hipStream_t s, bool ktree = false);
 // which 16x16x32 kernel launch_conv3x3_split16 picks for a layer: "dma,128" | "dma,64" (persistent LDS-DMA kernel,
 // tile width in channels) or "reg,128" | "reg,64" (register-staged kernels); nullptr: not launchable
 const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int cout_pad, bool pool);
-// split-K for a layer whose consumer adds partial-sum slabs (rpn_conv -> the RPN head): factor (1 = none) and launch
+// K tree of a layer whose consumer adds partial-sum slabs (rpn_conv -> the RPN head): the layer's value is (l0 + l1) + (l2 +
+// l3) over four fixed leaves of K at every batch size, computed by one workgroup per tile (launch_conv3x3_split16, ktree) or by
+// 2 / 4 (launch_conv3x3_split16_ksplit: slabs l0 + l1 | l2 + l3, or the four leaves; the head adds them in tree order).
+// _ktree_ok: whether the layer can run that way at every batch up to B; _ksplit: the split factor (1 | 2 | 4) at batch B.
+bool conv3x3_split16_ktree_ok(int B, int H, int W, int Cin, int Cout, int cout_pad);
 int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad);
 hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *out, long long slab_floats, int B, int H, int W,
                                          int Cin, int Cout, int cout_pad, float out_scale, bool f16, int ksplit, hipStream_t s);
@@ -140,7 +145,7 @@ hipError_t launch_split_to_f32(const void *x, long long npix, int C, bool f16, f
 hipError_t launch_maxpool_split(const void *x, int B, int H, int W, int C, bool f16, void *out, hipStream_t s);
 hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                bool pool, hipStream_t s);
+                                bool pool, hipStream_t s, bool ktree = false);
 
 // VGG16 block 1 (block1_conv1 + block1_conv2 + block1_pool) in one launch: the 64-channel full-resolution tensor stays
 // on chip.  w1 = pack_weights_cin3_mfma_host records, w2 = pack_weights_split_host records; out: SPLIT16 (B,H/2,W/2,64).

@@ -611,11 +611,15 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
         const f32x4_h *src = reinterpret_cast<const f32x4_h *>(x + px * 512 + 128 * wave + 32 * lk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) av[mb][i] = src[i];
-        if (n_slabs > 1) {              // split-K producer: add the partial sums in slab order, + its bias, ReLU
-            for (int sl = 1; sl < n_slabs; ++sl) {
-                const f32x4_h *ss = reinterpret_cast<const f32x4_h *>(x + (size_t)sl * slab_floats + px * 512 + 128 * wave + 32 * lk);
+        if (n_slabs > 1) {              // K-tree producer: add the partial sums in tree order, + its bias, ReLU
+            const f32x4_h *s1 = reinterpret_cast<const f32x4_h *>(x + (size_t)1 * slab_floats + px * 512 + 128 * wave + 32 * lk);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) av[mb][i] += ss[i];
+            for (int i = 0; i < 8; ++i) av[mb][i] = av[mb][i] + s1[i];                          // s0 + s1
+            if (n_slabs == 4) {
+                const f32x4_h *s2 = reinterpret_cast<const f32x4_h *>(x + (size_t)2 * slab_floats + px * 512 + 128 * wave + 32 * lk);
+                const f32x4_h *s3 = reinterpret_cast<const f32x4_h *>(x + (size_t)3 * slab_floats + px * 512 + 128 * wave + 32 * lk);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) av[mb][i] = av[mb][i] + (s2[i] + s3[i]);            // (s0 + s1) + (s2 + s3)
             }
             const f32x4_h *cb = reinterpret_cast<const f32x4_h *>(conv_bias + 128 * wave + 32 * lk);
 #pragma unroll

@@ -187,6 +187,12 @@ struct SplitConvArgs {
     // slices [y * chunks / gridDim.y, (y + 1) * chunks / gridDim.y) and writes its RAW partial sums (x out_scale; no bias,
     // no activation) as float32 NHWC to slab y of `out` (slab_floats apart); the consumer adds the slabs.
     long long slab_floats;
+    // K TREE (rpn_conv, whose consumer -- the RPN head -- can add partial-sum slabs): the 32-channel slices are cut into FOUR
+    // fixed leaves at slice pairs k * (slices / 2) / 4, k = 0 .. 4, each leaf is one accumulation chain, and the layer's
+    // value is (l0 + l1) + (l2 + l3) -- whoever adds: one workgroup inside its tile loop (conv3x3_split16_dma_kernel<.., 64,
+    // true>, any batch), two workgroups writing l0 + l1 and l2 + l3 as slabs, or four writing one leaf each, the head adding
+    // them in that order.  The same bits at every split factor, so the factor may follow the batch size.
+    int ktree;
 };
 
 // TH: tile height (4 or 8 rows of 32 pixels); WN: waves along N (2 -> BN = 128, 1 -> BN = 64).
@@ -758,8 +764,16 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
                          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));       // XCC_ID, HW_ID
 
     const int all_chunks = a.Cin >> 5;                // 32-channel slices
-    const int c_begin = (int)((long long)blockIdx.y * all_chunks / gridDim.y);        // split-K: this workgroup's slices
-    const int chunks = (int)((long long)(blockIdx.y + 1) * all_chunks / gridDim.y);   // (one past its last slice)
+    int c_begin = (int)((long long)blockIdx.y * all_chunks / gridDim.y);        // split-K: this workgroup's slices
+    int chunks = (int)((long long)(blockIdx.y + 1) * all_chunks / gridDim.y);   // (one past its last slice)
+    int c_fold = -1;                                  // K tree, two leaves per workgroup: the first slice of the second leaf
+    constexpr bool KT = TH == 4 && NW == 4 && !POOL;   // (the instantiation the K-tree launcher uses; the others have no registers for it)
+    if (KT && a.ktree) {                              // (gridDim.y = 2 or 4: the launcher sends an unsplit tree layer elsewhere)
+        const int np = all_chunks >> 1, per = 4 / (int)gridDim.y, l0 = (int)blockIdx.y * per;
+        c_begin = 2 * (l0 * np / 4);
+        chunks = 2 * ((l0 + per) * np / 4);
+        if (per == 2) c_fold = 2 * ((l0 + 1) * np / 4);
+    }
     const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
     const uint4 *__restrict__ xin = a.x + (size_t)img * a.H * a.W * in_pix_stride;
@@ -804,10 +818,15 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_goff[R], (CHUNK) * 128, 0))
 
     f32x4 acc[MT][4];                                 // [M-tile = row i * 2 + half][N-tile j]
+    f32x4 leaf0[KT ? MT : 1][KT ? 4 : 1];            // (K tree: the finished first leaf of this workgroup's pair)
+    (void)leaf0;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (KT) leaf0[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     int a_off[3][2];                                  // [tap column s][16-px half]: lane-constant
 #pragma unroll
@@ -875,6 +894,25 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         }
         abuf ^= 1;
         RPN_STAMP_AT(4 + chunk);
+        if constexpr (KT) {
+            if (chunk + 1 == c_fold) {                // K tree: the first leaf is complete
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        leaf0[m][j] = acc[m][j];
+                        acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
+    }
+    if constexpr (KT) {
+        if (c_fold >= 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] = leaf0[m][j] + acc[m][j];
+        }
     }
 #undef RPN16_LOAD_B
 #undef RPN16_STORE_B
@@ -989,10 +1027,11 @@ __device__ __forceinline__ unsigned halo_source_offset(int j, int wave, int lane
     return in ? (unsigned)((((im * H + iy) * W + ix) * in_pix_stride + q) * 16) : 0x80000000u;
 }
 
-template <bool F16, bool POOL, int BN>
+template <bool F16, bool POOL, int BN, bool KTREE = false>
 __global__ void __launch_bounds__(512, 2)
 conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
+    static_assert(!KTREE || (BN == 64 && !POOL), "K tree: the 64-wide tile has the registers for two more accumulator sets");
     constexpr int TH = 8, NW = 8, WN = 2, RW = 2, MT = 4, PPP = 8;
     constexpr int NJ = BN / (16 * WN);                 // 16-channel MFMA tiles per wave: 4 (BN = 128) or 2 (BN = 64)
     constexpr int B_PER_WAVE = BN * PPP / 64 / NW;     // weight DMA instructions per wave and tap: 2 or 1
@@ -1152,6 +1191,8 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
             nxt = next_tile(cur + slot_stride, nimg, noy0, nox0, nn0);
         }
         f32x4 acc[MT][NJ];
+        f32x4 t01[KTREE ? MT : 1][KTREE ? NJ : 1], t23[KTREE ? MT : 1][KTREE ? NJ : 1];     // K tree (SplitConvArgs::ktree): l0 + l1, l2
+        (void)t01; (void)t23;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1271,6 +1312,27 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
 #endif
                 if (s9 == 8 && tile_no == 1) RPN_STAMP_AT(4 + 2 * pair + c2);   // (second tile: steady state)
             }
+            if constexpr (KTREE) {          // a leaf ends behind slice pair k * np / 4 (np >= 4: every leaf has a pair)
+                const int np = chunks >> 1, done = pair + 1;
+                const bool e0 = done == np / 4, e1 = done == np / 2, e2 = done == 3 * np / 4;
+                if (e0 || e1 || e2) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (e0) t01[m][j] = acc[m][j];
+                            else if (e1) t01[m][j] = t01[m][j] + acc[m][j];
+                            else t23[m][j] = acc[m][j];
+                            acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                }
+            }
+        }
+        if constexpr (KTREE) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[m][j] = t01[m][j] + (t23[m][j] + acc[m][j]);
         }
         // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
         // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
@@ -2325,16 +2387,18 @@ const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int 
 
 hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                   int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                  bool pool, hipStream_t s)
+                                  bool pool, hipStream_t s, bool ktree)
 {
     if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
+    if (ktree && (pool || !conv3x3_split16_ktree_ok(B, H, W, Cin, Cout, cout_pad))) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.status = range_status();
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = act; a.out_f32 = out_f32 ? 1 : 0;
-    const char *variant = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, pool);
+    const char *variant = ktree ? "dma,64" : conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, pool);
     if (!variant) return hipErrorInvalidValue;
+    a.ktree = ktree ? 1 : 0;
     const long long big_blocks = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 127) / 128);
     if (variant[0] == 'd') {
         // Persistent LDS-DMA kernel: 8 x 32 px tiles, 128 channels wide -- or 64 wide where that is all there is
@@ -2375,7 +2439,10 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
             return hipGetLastError();
         }
 #endif
-        if (f16) { if (pool) { RPN_L16D_BN(true, true); } else { RPN_L16D_BN(true, false); } }
+        if (ktree) {                        // the whole K tree inside the tile loop (SplitConvArgs::ktree)
+            if (f16) hipLaunchKernelGGL((conv3x3_split16_dma_kernel<true, false, 64, true>), dim3(pgrid), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles);
+            else hipLaunchKernelGGL((conv3x3_split16_dma_kernel<false, false, 64, true>), dim3(pgrid), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles);
+        } else if (f16) { if (pool) { RPN_L16D_BN(true, true); } else { RPN_L16D_BN(true, false); } }
         else { if (pool) { RPN_L16D_BN(false, true); } else { RPN_L16D_BN(false, false); } }
 #undef RPN_L16D_BN
 #undef RPN_L16D
@@ -2409,19 +2476,27 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
 // Split-K factor for a 3x3 layer whose only consumer can add partial-sum slabs (rpn_conv -> the RPN head): grids of at
 // most a quarter / half of the CUs (batch-1 feature maps) are cut 4 / 2 ways along K so that the layer's time is no longer
 // one workgroup's walk through all of K.  1: no split.
+// Whether a 3x3 layer feeding the slab-adding head runs as a K TREE (SplitConvArgs::ktree) -- at EVERY batch size up to
+// B, so that the split factor may follow the grid size without changing bits: needs the persistent 64-wide kernel for the
+// unsplit case (and its 2 GiB / even-slice limits) and at least one slice pair per leaf.  RPN_KSPLIT=0: one accumulation
+// chain at every batch size (the layer's time at batch 1 is then one workgroup's walk through all of K).
+bool conv3x3_split16_ktree_ok(int B, int H, int W, int Cin, int Cout, int cout_pad)
+{
+    static const int on = RPN_KNOB("RPN_KSPLIT", 1);
+    return on && Cin % 64 == 0 && Cin >= 256 && Cout % 16 == 0 && cout_pad % 128 == 0 && cout_pad >= Cout &&
+           (long long)B * H * W * Cin * 4 < 0x7fffffffll && (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
+}
+
 int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)
 {
-    // Off by default: the partial sums are added in a different order than the one-chain accumulation, so a batch-1 result
-    // would no longer be bit-identical to the same image inside a larger batch (tests/test_gpu_configs.py holds the
-    // path to that).  RPN_KSPLIT=1 is the latency option: MobileNetV2 500 x 500, one image: 0.326 -> 0.292 ms.
-    static const int on = RPN_KNOB("RPN_KSPLIT", 0);
+    // (a K-tree layer only -- the caller checks conv3x3_split16_ktree_ok at its largest batch)  MobileNetV2 500 x 500, one
+    // image: 0.292 -> 0.259 ms per step; 1024 x 1024: 0.395 -> 0.377.
     const char *v = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, false);
-    if (!on || !v || strcmp(v, "reg,64") != 0) return 1;
+    if (!v || strcmp(v, "reg,64") != 0) return 1;
     const long long blocks = (long long)((W + 31) / 32) * ((H + 3) / 4) * B * ((Cout + 63) / 64);
     const int chunks = Cin / 32;
-    int s = blocks <= 128 ? 4 : (blocks <= 256 ? 2 : 1);          // (2 workgroups of this kernel fit a CU: 512 slots)
-    while (s > 1 && chunks / s < 2) s >>= 1;
-    return s;
+    (void)chunks;
+    return blocks <= 128 ? 4 : (blocks <= 256 ? 2 : 1);           // (2 workgroups of this kernel fit a CU: 512 slots)
 }
 
 // The split-K form of launch_conv3x3_split16 (4 x 32 x 64 register-staged tiles): out = ksplit float32 NHWC slabs of
@@ -2429,9 +2504,10 @@ int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)
 hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *out, long long slab_floats, int B, int H, int W,
                                          int Cin, int Cout, int cout_pad, float out_scale, bool f16, int ksplit, hipStream_t s)
 {
-    if (Cin % 32 != 0 || Cout % 16 != 0 || cout_pad % 128 != 0 || ksplit < 2 || ksplit > Cin / 32) return hipErrorInvalidValue;
+    if ((ksplit != 2 && ksplit != 4) || !conv3x3_split16_ktree_ok(B, H, W, Cin, Cout, cout_pad)) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.status = nullptr;
+    a.ktree = 1;
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = nullptr; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = ACT_LINEAR; a.out_f32 = 1; a.slab_floats = slab_floats;
@@ -2451,8 +2527,9 @@ hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *ou
 // x: SPLIT16 (B,H,W,Cin), w: split records, out: SPLIT16 or f32 NHWC of (B,H,W,Cout) or, pooled, (B,H/2,W/2,Cout).
 hipError_t launch_conv3x3_split(const void *x, const void *w, const float *bias, void *out, int B, int H, int W,
                                 int Cin, int Cout, int cout_pad, float out_scale, int act, bool out_f32, bool f16,
-                                bool pool, hipStream_t s)
+                                bool pool, hipStream_t s, bool ktree)
 {
+    if (ktree) return hipErrorInvalidValue;           // (the parameter only keeps the two launchers' signatures equal)
     if (Cin % 16 != 0 || Cout % 16 != 0 || cout_pad % 64 != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
     SplitConvArgs a{};
     a.status = range_status();

@@ -233,7 +233,8 @@ static void add_head(rpn_model *m, int feat)
     const int x = add_conv(m, "rpn_conv", "", feat, 512, 3, 1, 1, 1, tf.H, tf.W, ACT_RELU, -1, true);
     {   // split-K of rpn_conv at small batches (its partial-sum slabs are added by the head): room for the largest S * B
         const Op &cv = m->ops.back();
-        if (cv.split && cv.k16 && cv.out_f32 && !m->keep_all && rpn_head_supported(512, 5 * m->K) && head_splitk()) {
+        if (cv.split && cv.k16 && cv.out_f32 && !m->keep_all && rpn_head_supported(512, 5 * m->K) && head_splitk() &&
+            conv3x3_split16_ktree_ok(m->max_batch, cv.H, cv.W, cv.Cin, cv.Cout, split_cout_pad(cv.Cout))) {
             int cap = m->max_batch;
             for (int b = 1; b <= m->max_batch; ++b) {
                 const int sk = conv3x3_split16_ksplit(b, cv.H, cv.W, cv.Cin, cv.Cout, split_cout_pad(cv.Cout));
@@ -861,11 +862,16 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
     size_t head_conv_bias = 0;
     // split-K factor of op i at this batch size: > 1 only for rpn_conv feeding the slab-adding head, when its output tensor
     // has room for factor * B images (RPN_KSPLIT=1; conv3x3_split16_ksplit says when it pays)
+    // rpn_conv feeding the slab-adding head runs as a K TREE (conv_kernels.h) at every batch size of this model, or at none
+    auto ktree_for = [&](size_t i) -> bool {
+        const Op &o = m->ops[i];
+        return o.kind == OP_CONV && o.split && o.k16 && o.out_f32 && i + 1 < m->ops.size() && m->ops[i + 1].kind == OP_HEAD &&
+               m->ops[i + 1].in == o.out && rpn_head_supported(512, 5 * m->K) && head_splitk() &&
+               conv3x3_split16_ktree_ok(m->max_batch, o.H, o.W, o.Cin, o.Cout, split_cout_pad(o.Cout));
+    };
     auto ksplit_for = [&](size_t i) -> int {
         const Op &o = m->ops[i];
-        if (!(o.kind == OP_CONV && o.split && o.k16 && o.out_f32) || m->keep_all || i + 1 >= m->ops.size() ||
-            m->ops[i + 1].kind != OP_HEAD || m->ops[i + 1].in != o.out || !rpn_head_supported(512, 5 * m->K) || !head_splitk())
-            return 1;
+        if (!ktree_for(i) || m->keep_all) return 1;     // (every activation kept: the tree inside one workgroup's tile loop)
         const int f = conv3x3_split16_ksplit(B, o.H, o.W, o.Cin, o.Cout, split_cout_pad(o.Cout));
         return (size_t)f * B <= (size_t)m->tensors[o.out].slabs * m->max_batch ? f : 1;
     };
@@ -897,11 +903,15 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             e = launch_conv3x3_split16_ksplit(x, m->d_weights + op.w_off, tensor_ptr(m, op.out, d_imgs),
                                               (long long)B * op.H * op.W * op.Cout, B, op.H, op.W, op.Cin, op.Cout,
                                               split_cout_pad(op.Cout), op.out_scale, m->f16, head_slabs, s);
+        } else if (ktree_for(oi)) {
+            e = launch_conv3x3_split16(x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, op.out, d_imgs), B, op.H,
+                                       op.W, op.Cin, op.Cout, split_cout_pad(op.Cout), op.out_scale, op.act, true, m->f16, false,
+                                       s, true);
         } else if (op.kind == OP_CONV && op.split) {
             const int dst = fuse_pool ? m->ops[oi + 1].out : op.out;
             e = (op.k16 ? launch_conv3x3_split16 : launch_conv3x3_split)(
                 x, m->d_weights + op.w_off, m->d_weights + op.b_off, tensor_ptr(m, dst, d_imgs), B, op.H, op.W, op.Cin,
-                op.Cout, split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, fuse_pool, s);
+                op.Cout, split_cout_pad(op.Cout), op.out_scale, op.act, op.out_f32, m->f16, fuse_pool, s, false);
             skip_next = fuse_pool;
         } else if (op.kind == OP_POOL && op.split) {
             e = launch_maxpool_split(x, B, op.H, op.W, op.Cin, m->f16, tensor_ptr(m, op.out, d_imgs), s);
@@ -1045,6 +1055,11 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         if (op.k16) {
             const bool fused_pool = i + 1 < (int)m->ops.size() && m->ops[i + 1].kind == OP_POOL && m->ops[i + 1].split;
             const char *v = conv3x3_split16_variant(m->max_batch, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout), fused_pool);
+            // (rpn_conv as a K tree: the 64-wide persistent kernel whenever one workgroup per tile walks all of K)
+            if (v && v[0] == 'd' && op.out_f32 && i + 1 < (int)m->ops.size() && m->ops[i + 1].kind == OP_HEAD &&
+                rpn_head_supported(512, 5 * m->K) && head_splitk() &&
+                conv3x3_split16_ktree_ok(m->max_batch, op.H, op.W, op.Cin, op.Cout, split_cout_pad(op.Cout)))
+                v = "dma,64";
             if (v && v[0] == 'd') snprintf(kname, sizeof kname, "conv3x3_split16_dma<%s,%s>", prec, v + 4);
             else snprintf(kname, sizeof kname, "conv3x3_split16<%s,%s>", prec, v ? v + 4 : "?");
         } else {
@@ -1199,7 +1214,7 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         if (e == hipSuccess) e = launch_f32_to_split(d_x, (long long)B * H * W, Cin, f16, d_xs, s);
         if (e == hipSuccess)
             e = (k16 ? launch_conv3x3_split16 : launch_conv3x3_split)(d_xs, d_ws, d_bias, d_out, B, H, W, Cin, Cout, cpad,
-                                                                      ldexpf(1.0f, -wshift), act, true, f16, false, s);
+                                                                      ldexpf(1.0f, -wshift), act, true, f16, false, s, false);
         const hipError_t e2 = hipStreamSynchronize(s);
         if (d_ws) (void)hipFree(d_ws);                  // freed on every path
         if (d_xs) (void)hipFree(d_xs);
