@@ -592,20 +592,20 @@ void pack_head_weights_host(const float *w /* [512][ld] */, int ld, int ncols, f
                 }
 }
 
-template <int NB>
+template <int NB, int MB>          // MB: 16-pixel blocks per workgroup (2; 1 on small grids -- twice the workgroups, same bits)
 __global__ void __launch_bounds__(256, 1)
 rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restrict__ wp, const float *__restrict__ bias,
                 int n_reg, int n_cls, float *__restrict__ reg, float *__restrict__ cls, int n_slabs, long long slab_floats,
                 const float *__restrict__ conv_bias)
 {
-    __shared__ __attribute__((aligned(16))) float part[4 * 2 * NB * 64 * 4];        // [wave][tile][lane][4]
+    __shared__ __attribute__((aligned(16))) float part[4 * MB * NB * 64 * 4];        // [wave][tile][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    const long long p0 = (long long)blockIdx.x * 32;
+    const long long p0 = (long long)blockIdx.x * (16 * MB);
     // A: pixel p0 + 16 mb + lr, channels 128 wave + 32 lk .. + 32 (rows beyond P repeat the last pixel; never stored)
-    f32x4_h av[2][8];
+    f32x4_h av[MB][8];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
         long long px = p0 + 16 * mb + lr;
         if (px >= P) px = P - 1;
         const f32x4_h *src = reinterpret_cast<const f32x4_h *>(x + px * 512 + 128 * wave + 32 * lk);
@@ -630,9 +630,9 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
             }
         }
     }
-    f32x4_h acc[2][NB];
+    f32x4_h acc[MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4_h{0.f, 0.f, 0.f, 0.f};
     const f32x4_h *wsrc = reinterpret_cast<const f32x4_h *>(wp) + ((size_t)wave * NB * 64 + lane) * 8;
@@ -651,22 +651,22 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][i][e], bv[nb & 1][i][e], acc[mb][nb], 0, 0, 0);
     }
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            *reinterpret_cast<f32x4_h *>(&part[(((wave * 2 + mb) * NB + nb) * 64 + lane) * 4]) = acc[mb][nb];
+            *reinterpret_cast<f32x4_h *>(&part[(((wave * MB + mb) * NB + nb) * 64 + lane) * 4]) = acc[mb][nb];
     __syncthreads();
     // tile t = mb * NB + nb is finished by wave t % 4: partial sums added in wave order
-    for (int t = wave; t < 2 * NB; t += 4) {
+    for (int t = wave; t < MB * NB; t += 4) {
         const int mb = t / NB, nb = t - mb * NB;
-        f32x4_h sum = *reinterpret_cast<const f32x4_h *>(&part[(((0 * 2 + mb) * NB + nb) * 64 + lane) * 4]);
+        f32x4_h sum = *reinterpret_cast<const f32x4_h *>(&part[(((0 * MB + mb) * NB + nb) * 64 + lane) * 4]);
 #pragma unroll
         for (int wv = 1; wv < 4; ++wv) {
-            const f32x4_h v = *reinterpret_cast<const f32x4_h *>(&part[(((wv * 2 + mb) * NB + nb) * 64 + lane) * 4]);
+            const f32x4_h v = *reinterpret_cast<const f32x4_h *>(&part[(((wv * MB + mb) * NB + nb) * 64 + lane) * 4]);
             sum += v;
         }
         const int n = nb * 16 + lr;
@@ -691,11 +691,18 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
     if (n_slabs < 1 || (n_slabs > 1 && !conv_bias)) return hipErrorInvalidValue;
     const int ncols = n_reg + n_cls;
     if (!rpn_head_supported(512, ncols) || P <= 0 || (P + 31) / 32 > 0x7fffffffll) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((P + 31) / 32));
+    // a grid of fewer than 256 workgroups (one image): 16 pixels per workgroup instead of 32 -- its operand, up to four slabs of
+    // 2 KB per pixel, is read at one CU's bandwidth per workgroup
+    const int MB = (P + 31) / 32 < 256 ? 1 : 2;
+    const dim3 grid((unsigned)((P + 16 * MB - 1) / (16 * MB)));
     const int NB = (ncols + 15) / 16;
 #define RPN_HEAD(NB_)                                                                                                 \
-    hipLaunchKernelGGL(rpn_head_kernel<NB_>, grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls, n_slabs, \
-                       slab_floats, conv_bias)
+    if (MB == 1)                                                                                                      \
+        hipLaunchKernelGGL((rpn_head_kernel<NB_, 1>), grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls,     \
+                           n_slabs, slab_floats, conv_bias);                                                          \
+    else                                                                                                              \
+        hipLaunchKernelGGL((rpn_head_kernel<NB_, 2>), grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls,     \
+                           n_slabs, slab_floats, conv_bias)
     switch (NB) {
         case 1: RPN_HEAD(1); break;
         case 2: RPN_HEAD(2); break;

@@ -188,7 +188,7 @@ struct SplitConvArgs {
     // no activation) as float32 NHWC to slab y of `out` (slab_floats apart); the consumer adds the slabs.
     long long slab_floats;
     // K TREE (rpn_conv, whose consumer -- the RPN head -- can add partial-sum slabs): the 32-channel slices are cut into FOUR
-    // fixed leaves at slice pairs k * (slices / 2) / 4, k = 0 .. 4, each leaf is one accumulation chain, and the layer's
+    // fixed leaves at slices k * slices / 4, k = 0 .. 4 (18 slices: 4 5 4 5), each leaf is one accumulation chain, and the layer's
     // value is (l0 + l1) + (l2 + l3) -- whoever adds: one workgroup inside its tile loop (conv3x3_split16_dma_kernel<.., 64,
     // true>, any batch), two workgroups writing l0 + l1 and l2 + l3 as slabs, or four writing one leaf each, the head adding
     // them in that order.  The same bits at every split factor, so the factor may follow the batch size.
@@ -769,10 +769,10 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     int c_fold = -1;                                  // K tree, two leaves per workgroup: the first slice of the second leaf
     constexpr bool KT = TH == 4 && NW == 4 && !POOL;   // (the instantiation the K-tree launcher uses; the others have no registers for it)
     if (KT && a.ktree) {                              // (gridDim.y = 2 or 4: the launcher sends an unsplit tree layer elsewhere)
-        const int np = all_chunks >> 1, per = 4 / (int)gridDim.y, l0 = (int)blockIdx.y * per;
-        c_begin = 2 * (l0 * np / 4);
-        chunks = 2 * ((l0 + per) * np / 4);
-        if (per == 2) c_fold = 2 * ((l0 + 1) * np / 4);
+        const int per = 4 / (int)gridDim.y, l0 = (int)blockIdx.y * per;
+        c_begin = l0 * all_chunks / 4;
+        chunks = (l0 + per) * all_chunks / 4;
+        if (per == 2) c_fold = (l0 + 1) * all_chunks / 4;
     }
     const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
@@ -1311,20 +1311,22 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 if (s9 == 8 && tile_no == 1) RPN_STAMP_AT(4 + 2 * pair + c2);   // (second tile: steady state)
-            }
-            if constexpr (KTREE) {          // a leaf ends behind slice pair k * np / 4 (np >= 4: every leaf has a pair)
-                const int np = chunks >> 1, done = pair + 1;
-                const bool e0 = done == np / 4, e1 = done == np / 2, e2 = done == 3 * np / 4;
-                if (e0 || e1 || e2) {
+                if constexpr (KTREE) {      // a leaf ends behind slice k * slices / 4 (slices >= 8: every leaf has two or more)
+                    if (s9 == 8) {          // (tap 8's MFMAs are all issued above; tap 9's fragments are in registers already)
+                        const int done = 2 * pair + c2 + 1;
+                        const bool e0 = done == chunks / 4, e1 = done == chunks / 2, e2 = done == 3 * chunks / 4;
+                        if (e0 || e1 || e2) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            if (e0) t01[m][j] = acc[m][j];
-                            else if (e1) t01[m][j] = t01[m][j] + acc[m][j];
-                            else t23[m][j] = acc[m][j];
-                            acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                for (int j = 0; j < NJ; ++j) {
+                                    if (e0) t01[m][j] = acc[m][j];
+                                    else if (e1) t01[m][j] = t01[m][j] + acc[m][j];
+                                    else t23[m][j] = acc[m][j];
+                                    acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                }
                         }
+                    }
                 }
             }
         }
