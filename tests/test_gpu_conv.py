@@ -43,6 +43,11 @@ CONV_CASES = [
     (1, 33, 17, 144, 24, 1, 1, (0, 0, 0, 0), "linear"),       # MNv2 project: Cout = 24
     (3, 9, 9, 96, 576, 1, 1, (0, 0, 0, 0), "relu6"),
     (1, 8, 16, 20, 36, 3, 1, (1, 1, 1, 1), "linear"),         # Cin % 16 != 0 with 9 taps
+    # grids of >= 512 workgroups of 128 x 128: the LDS-DMA staged kernel (conv_igemm_f32_dma)
+    (4, 96, 96, 24, 256, 1, 1, (0, 0, 0, 0), "relu6"),        # 1x1, a partial 16-channel slice (quads beyond Cin are zeros)
+    (4, 90, 100, 20, 136, 3, 1, (1, 1, 1, 1), "relu"),        # ragged tiles, Cin % 16 != 0 with 9 taps, a ragged N tile
+    (4, 191, 191, 32, 256, 3, 2, (0, 1, 0, 1), "linear"),     # stride 2, asymmetric padding
+    (2, 125, 125, 128, 256, 3, 1, (1, 1, 1, 1), "relu"),      # block3_conv1's shape
 ]
 
 
@@ -60,7 +65,10 @@ def test_conv2d_single_layer(case):
     scale = max(1.0, float(np.abs(ref).max()))
     err = np.abs(got - ref).max()
     assert err <= 2e-5 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
-    if R * R * Cin <= 600:                     # cross-check the independent plain-C direct conv on small cases
+    if Cout >= 128 and B >= 2 and H >= 90:      # (these are meant for the DMA-staged kernel: conv_f32_tile_n's rule, restated)
+        n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert -(-OW // 16) * -(-OH // 8) * B * -(-Cout // 128) >= 2 * n_cus
+    if R * R * Cin <= 600 and B * H * W <= 40000:   # cross-check the independent plain-C direct conv on small cases
         cref = co.conv2d(x, w, b, stride=stride, pad_t=pad[0], pad_l=pad[2], out_hw=(OH, OW), act=act)
         assert np.abs(got - cref).max() <= 2e-5 * scale
 
