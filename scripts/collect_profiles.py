@@ -89,7 +89,7 @@ def traffic(prefix, out, note, workload=None, subdirs=None, rename=False):
 
 copy("bench_default.json", "%s_f16x3_bench_default.json" % tag)
 copy("bench_default_layers.txt", "%s_f16x3_bench_layers.txt" % tag)
-for cfg in ("c4", "c5", "mn8", "f32"):
+for cfg in ("c1", "c4", "c5", "mn8", "f32"):
     copy("bench_%s.json" % cfg, "%s_%s_bench.json" % (tag, cfg))
     copy("bench_%s_layers.txt" % cfg, "%s_%s_bench_layers.txt" % (tag, cfg))
 copy("bbox_c3.json", "%s_c3_bbox_kernels.json" % tag)
@@ -103,7 +103,8 @@ import subprocess
 for run, name, wl in (("vgg_f16x3", "f16x3", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f16x3"}),
                       ("vgg_f32", "f32", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f32"}),
                       ("mn8", "mn8", {"backbone": "mobilenet_v2", "img_size": 500, "batch": 8, "precision": "f16x3"}),
-                      ("c5", "c5", {"backbone": "mobilenet_v2", "img_size": 1024, "batch": 1, "precision": "f16x3"})):
+                      ("c5", "c5", {"backbone": "mobilenet_v2", "img_size": 1024, "batch": 1, "precision": "f16x3"}),
+                      ("c1", "c1", {"backbone": "mobilenet_v2", "img_size": 500, "batch": 1, "precision": "f16x3"})):
     d = os.path.join(src, run)
     if not os.path.isdir(d):
         continue
