@@ -51,8 +51,22 @@ extern "C" int rpn_debug_read_ir_stamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ir_stamps), (size_t)n * 8);
 }
+// ... and of ir_block_hrx3_kernel (scripts/hr_stamp_probe.py): per variant v (block 1 / 2 / 3), workgroups 512 .. 767, 40 slots:
+// [0] start, [1] A operand built, per chunk c: [2+3c] E written (after the barrier), [3+3c] D written (after the barrier),
+// [4+3c] P issued, [39] outputs stored
+__device__ unsigned long long g_hr_stamps[3 * 256 * 40];
+#define HR_STAMP(v, k)                                                                                    \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x >= 512 && blockIdx.x < 768 && (k) < 40)                       \
+            g_hr_stamps[((v) * 256 + (blockIdx.x - 512)) * 40 + (k)] = __builtin_readcyclecounter();       \
+    } while (0)
+extern "C" int rpn_debug_read_hr_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hr_stamps), (size_t)n * 8);
+}
 #else
 #define IR_STAMP(w, k) ((void)0)
+#define HR_STAMP(v, k) ((void)0)
 #endif
 
 namespace rpn {
@@ -1249,6 +1263,9 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;              // halo origin on the input grid
     const int pmb = wave & 1, pnb0 = wave >> 1;                          // projection: M-block, first N-block (stride 2)
     const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * CIN;
+    constexpr int HRV = CIN == 16 ? 0 : (S == 1 ? 1 : 2);                // (stamp slot of this variant)
+    (void)HRV;
+    HR_STAMP(HRV, 0);
 
     // the padding channels of the last projection k-step (CE = 16 / 48) are never written by the depthwise: zero once
     if constexpr (CE % 32 != 0)
@@ -1293,6 +1310,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    HR_STAMP(HRV, 1);
 
     for (int c = 0; c < NCHUNK; ++c) {
         // ---- E(c): (halo pixels x 32) * We[:, chunk] -> * 2^-shift + bias, ReLU6, zero outside the image -> Es ------------
@@ -1321,6 +1339,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
             }
         }
         __syncthreads();
+        HR_STAMP(HRV, 2 + 3 * c);
         // ---- D(c): depthwise 3x3 + bias + ReLU6 (float32), hi / lo float16 into the projection's A image ---------------------
         if (dg < DG) {
             float wd_r[10];
@@ -1358,6 +1377,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
             }
         }
         __syncthreads();
+        HR_STAMP(HRV, 3 + 3 * c);
         // ---- P(c): acc (16 px of M-block pmb x COUT) += D (16 x CE) * Wp[chunk] ---------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
@@ -1373,6 +1393,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         }
         // (the next chunk's E writes Es, its D writes DsF behind the barrier after E: P(c) has read DsF by then -- every wave
         // passes that barrier only after its own P(c))
+        HR_STAMP(HRV, 4 + 3 * c);
     }
     // ---- * 2^-shift + bias (+ the block input) -> NHWC ---------------------------------------------------------------------
 #pragma unroll
@@ -1394,6 +1415,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
             }
         }
     }
+    HR_STAMP(HRV, 39);
 }
 
 // chunk size (expanded channels per step) of the high-resolution f16x3 blocks: the f32 form's
