@@ -1273,7 +1273,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
 
     // ---- A operand of the expand GEMM: this wave's halo pixels (M-blocks wave, wave + 4, ...) as hi / lo fragments ----------
     u32x4 xh[MBW], xl[MBW];
-    unsigned vmask = 0;
+    float vmul[MBW * 4];                 // 1 where this lane's expand output (row 4 lk + i of M-block mbi) is a pixel of the image, else 0
 #pragma unroll
     for (int mbi = 0; mbi < MBW; ++mbi) {
         const int m = (wave + 4 * mbi) * 16 + lr;
@@ -1301,7 +1301,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         for (int i = 0; i < 4; ++i) {
             const int mo = (wave + 4 * mbi) * 16 + 4 * lk + i;
             const int oy = mo / IW, ox = mo - oy * IW;
-            if (mo < NH && gy0 + oy >= 0 && gy0 + oy < a.H && gx0 + ox >= 0 && gx0 + ox < a.W) vmask |= 1u << (mbi * 4 + i);
+            vmul[mbi * 4 + i] = (mo < NH && gy0 + oy >= 0 && gy0 + oy < a.H && gx0 + ox >= 0 && gx0 + ox < a.W) ? 1.0f : 0.0f;
         }
     }
     const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
@@ -1332,8 +1332,8 @@ ir_block_hrx3_kernel(IrHrX3Args a)
                         const f32x4 e = mfma_x3(xh[mbi], xl[mbi], wh[nb], wl[nb], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            Es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
-                                ((vmask >> (mbi * 4 + i)) & 1u) ? relu6f(e[i] * a.scale_e + be_r[nb]) : 0.0f;
+                            // (* 1 or * 0: ReLU6's output is finite and >= 0, so the product is the value itself or +0)
+                            Es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] = relu6f(e[i] * a.scale_e + be_r[nb]) * vmul[mbi * 4 + i];
                     }
                 }
             }
