@@ -985,14 +985,14 @@ ir_block_x3_kernel(IrX3Args a)
             *reinterpret_cast<f16x4 *>(xh + (size_t)(blk + 1) * 512 + off) = lo;
         }
     }
-    unsigned vmask = 0;
+    float vmul[4] = {0.f, 0.f, 0.f, 0.f};          // 1 where this lane's expand output (row 4 lk + i) is a pixel of the image, else 0
     if (wave < 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = wave * 16 + 4 * lk + i;
             const int hy = m / IW, hx = m - hy * IW;
             const int gy = gy0 + hy, gx = gx0 + hx;
-            if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) vmask |= 1u << i;
+            vmul[i] = (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.0f : 0.0f;
         }
         we_store(0);
         if (nch > 1) we_fetch(c0 + 1);                       // put in place at the start of step 0
@@ -1069,8 +1069,8 @@ ir_block_x3_kernel(IrX3Args a)
                 for (int nb = 0; nb < NBE; ++nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        es[(wave * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =
-                            ((vmask >> i) & 1u) ? relu6f(eacc[nb][i] * a.scale_e + biasv[nb]) : 0.0f;
+                        es[(wave * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =        // (* 1 or * 0: ReLU6's output is finite and >= 0)
+                            relu6f(eacc[nb][i] * a.scale_e + biasv[nb]) * vmul[i];
             }
             IR_STAMP(0, 2 + 4 * it);
             if (it >= 2) {
