@@ -439,8 +439,14 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d_mai
             key[u] = band[i];
             const int b = seg_of(key[u]);
             const int seg0 = (int)boff[b], cnt = (int)counts[b];
-            int rank = 0;
-            for (int q = 0; q < cnt; ++q) rank += band[seg0 + q] > key[u] ? 1 : 0;
+            // (four reads in flight per trip: a saturated head's segments are hundreds of keys long -- bins next to 1.0 -- and one
+            // dependent LDS read per key made this loop 15 k of configs[0]'s 26 k ordering cycles)
+            int rank = 0, q = 0;
+            for (; q + 4 <= cnt; q += 4) {
+                const unsigned long long k0 = band[seg0 + q], k1 = band[seg0 + q + 1], k2 = band[seg0 + q + 2], k3 = band[seg0 + q + 3];
+                rank += (k0 > key[u] ? 1 : 0) + (k1 > key[u] ? 1 : 0) + (k2 > key[u] ? 1 : 0) + (k3 > key[u] ? 1 : 0);
+            }
+            for (; q < cnt; ++q) rank += band[seg0 + q] > key[u] ? 1 : 0;
             pos[u] = seg0 + rank;
         }
     }
