@@ -201,7 +201,10 @@ int rpn_model_set_layer(rpn_model *m, const char *name, const float *kernel, con
                         const float *bn_var);
 /* d_imgs (B,img,img,3) NHWC float32 in [0,1] (utils/data_utils.py:25-26);
  * d_reg (B,F,F,4K), d_cls (B,F,F,K) -- the reference's output order is [reg, cls]
- * (models/rpn_vgg16.py:21). */
+ * (models/rpn_vgg16.py:21).
+ * A handle owns ONE activation arena and one set of inter-workgroup scratch (K-split partials and tickets): the forwards
+ * of a handle must be ordered on one stream (or by events); for concurrent forwards on several streams create one handle
+ * per stream (the reference's Keras model is not re-entrant either). */
 int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float *d_reg, float *d_cls, void *stream);
 /* Sticky status flags of the forwards run so far (no reference counterpart: TF computes in float32 throughout).
  * RPN_STATUS_F16_RANGE: under RPN_PRECISION_F16X3 some activation did not fit float16 (|x| > 65504 or non-finite) when

@@ -586,6 +586,26 @@ def test_nms_selection_properties_at_full_size():
     assert np.array_equal(again[0], nb) and (again[3] == 300).all()
 
 
+@pytest.mark.parametrize("iou_thr", [0.5, 0.7])
+def test_nms_c3_baseline_size_against_oracle(iou_thr):
+    """BASELINE.json configs[2] at its full size -- B = 64 images, A = 8 649 decoded anchors, top 300 -- against the C
+    oracle (not only through properties): ``rpn_combined_nms`` on the GPU-decoded boxes and the fused ``rpn_decode_nms``
+    on the raw deltas, valid counts and selected indices bit-exact, at TF's default threshold 0.5 (what the reference's
+    bare ``**kwargs`` pass-through gives, utils/bbox_utils.py:66-70) and at 0.7.  Inputs as bench.py's `c3` leg."""
+    anchors = bo.generate_anchors(bo.get_hyper_params("vgg16"))
+    B, A = 64, len(anchors)
+    assert A == 8649
+    deltas = np.random.RandomState(2).standard_normal((B, A, 4)).astype(np.float32)
+    scores = cases.permutation_scores(np.random.RandomState(3), B, A)
+    gpu_boxes = bbox_utils.get_bboxes_from_deltas(anchors, deltas, variances=VAR)
+    got = _check_nms(gpu_boxes[:, :, None, :], scores[:, :, None], max_output_size_per_class=300, max_total_size=300,
+                     iou_threshold=iou_thr)
+    assert (got[3] == 300).all()
+    fb, fs, fi, fv = bbox_utils.decode_and_nms(anchors, deltas, scores, VAR, 300, iou_threshold=iou_thr)
+    assert np.array_equal(fv, got[3]) and np.array_equal(fi, got[4])
+    assert np.array_equal(fs, got[1]) and np.array_equal(fb, got[0])
+
+
 # ---- fused decode + NMS ---------------------------------------------------------------------------
 @pytest.mark.parametrize("backbone,B", [("vgg16", 8), ("mobilenet_v2", 3)])
 def test_decode_nms_fused_equals_two_step(backbone, B):

@@ -293,3 +293,123 @@ def test_f16x3_on_trained_like_statistics_through_the_h5_path(tmp_path):
                                                                                  e_reg, e_cls))
     assert e_reg <= 1e-4 and e_cls <= 1e-4
     assert not flagged or feat_max > 6e4                # the flag may only rise when something really left the range
+
+
+def _trained_like_mobilenet_v2(hp, seed=7):
+    """MobileNetV2 + RPN weights with the BatchNorm STATISTICS of a trained checkpoint instead of the near-identity ones of
+    ``synthetic_weights`` (gamma, var in [0.8, 1.2]): every conv output channel c carries its own scale s_c, log-uniform in
+    [0.01, 100] (kernel column x s_c), and its BatchNorm has co-adapted statistics, moving_variance = s_c^2 v0 and
+    moving_mean = s_c m0 (v0 in [0.5, 2], m0 in [-0.3, 0.3]), with gamma in [0.4, 1.2] and beta in [-0.5, 0.5] -- so the
+    fold scale gamma / sqrt(var + eps) spans ~3e-3 ... 38 (its top is capped by eps = 1e-3: channels with var << eps are
+    where the eps term matters), while the folded network stays as well conditioned as a trained one is (float32 torch-CPU
+    agrees with float64 to ~2e-7 on it).  rpn_conv x 0.3: an unsaturated head, so the 1e-4 bound is meaningful."""
+    rng = np.random.RandomState(seed)
+    w = {}
+    ratios = []
+
+    def conv_bn(name, bn_name, shape, fan, ch, depthwise=False):
+        s = np.exp(rng.uniform(np.log(0.01), np.log(100.0), size=ch)).astype(np.float32)
+        k = (rng.standard_normal(shape) * np.sqrt(2.0 / fan)).astype(np.float32)
+        w[name] = {"kernel": (k * (s.reshape(1, 1, ch, 1) if depthwise else s.reshape(1, 1, 1, ch))).astype(np.float32)}
+        v0 = rng.uniform(0.5, 2.0, size=ch).astype(np.float32)
+        gamma = rng.uniform(0.4, 1.2, size=ch).astype(np.float32)
+        w[bn_name] = {"gamma": gamma, "beta": rng.uniform(-0.5, 0.5, size=ch).astype(np.float32),
+                      "mean": (s * rng.uniform(-0.3, 0.3, size=ch)).astype(np.float32), "var": (s * s * v0).astype(np.float32)}
+        ratios.append(gamma / np.sqrt(w[bn_name]["var"] + np.float32(cv.BN_EPS)))
+
+    conv_bn("Conv1", "bn_Conv1", (3, 3, 3, 32), 27, 32)
+    for (bid, cin, t, cout, _stride) in cv.MNV2_BLOCKS:
+        p = "expanded_conv_" if bid == 0 else "block_%d_" % bid
+        ce = cin * t
+        if bid != 0:
+            conv_bn(p + "expand", p + "expand_BN", (1, 1, cin, ce), cin, ce)
+        conv_bn(p + "depthwise", p + "depthwise_BN", (3, 3, ce, 1), 9, ce, depthwise=True)
+        conv_bn(p + "project", p + "project_BN", (1, 1, ce, cout), ce, cout)
+    conv_bn("block_13_expand", "block_13_expand_BN", (1, 1, 96, 576), 96, 576)
+    K = int(hp["anchor_count"])
+    he = lambda shape, fan: (rng.standard_normal(shape) * np.sqrt(2.0 / fan)).astype(np.float32)
+    w["rpn_conv"] = {"kernel": he((3, 3, 576, 512), 9 * 576) * np.float32(0.3), "bias": rng.uniform(-0.05, 0.05, 512).astype(np.float32)}
+    w["rpn_cls"] = {"kernel": he((1, 1, 512, K), 512), "bias": rng.uniform(-0.05, 0.05, K).astype(np.float32)}
+    w["rpn_reg"] = {"kernel": he((1, 1, 512, 4 * K), 512) * np.float32(0.1),
+                    "bias": rng.uniform(-0.05, 0.05, 4 * K).astype(np.float32)}
+    r = np.concatenate(ratios)
+    return w, (float(r.min()), float(r.max()))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_mobilenet_v2_trained_like_batchnorm_through_the_h5_path(tmp_path, precision):
+    """The BatchNorm-folded backbone on trained-like statistics (fold scales over four decades, beta != 0, variances below
+    eps), loaded the way the reference loads a checkpoint (``load_weights(path, by_name=True)``, predictor.py:43-44; Keras
+    .h5 written by the real h5py when an interpreter with it exists): head outputs within 1e-4 of the float64 oracle with
+    the float16 range flag clear -- or, when the flag is raised, the documented bf16x3 fallback within the bound."""
+    import os
+    import subprocess
+    hp = bo.get_hyper_params("mobilenet_v2")
+    weights, (r_lo, r_hi) = _trained_like_mobilenet_v2(hp)
+    assert r_lo < 1e-2 and r_hi > 20.0                   # the fold scales really span the decades
+    imgs = np.random.RandomState(3).uniform(0, 1, size=(2, 500, 500, 3)).astype(np.float32)
+    ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64, return_features=True)
+    print("fold scale gamma/sqrt(var+eps) in [%.2e, %.1f]; block_13_expand_relu: max %.2f mean %.3f; |deltas| max %.3f; "
+          "objectness in [%.3f, %.3f]" % (r_lo, r_hi, float(ref[2].max()), float(ref[2].mean()), float(np.abs(ref[0]).max()),
+                                          float(ref[1].min()), float(ref[1].max())))
+    assert 0.01 < float(ref[1].min()) and float(ref[1].max()) < 0.99      # an unsaturated head
+    assert float((ref[2] > 0).mean()) > 0.2                                # a live feature map, not a dead one
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        have_h5py = subprocess.run([H5PY_PYTHON, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except OSError:
+        have_h5py = False
+    model = RPNModel("mobilenet_v2", hp, precision=precision, max_batch=2)
+    if have_h5py:
+        npz, h5 = str(tmp_path / "w.npz"), str(tmp_path / "w.h5")
+        RPNModel.save_weights(weights, npz)
+        r = subprocess.run([H5PY_PYTHON, os.path.join(here, "golden", "npz_to_keras_h5.py"), npz, h5, "fixed"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        done = model.load_weights(h5, by_name=True)
+        assert sorted(done) == sorted(l["name"] for l in model.layers)
+    else:
+        model.set_weights(weights)                      # (no interpreter with h5py here: same arrays, set directly)
+    x = torch.from_numpy(imgs).cuda()
+    reg, cls = [t.cpu().numpy() for t in model.predict_on_batch(x)]
+    flagged = precision == "f16x3" and model.status(reset=True)["f16_range"]
+    if flagged:                                         # the documented fallback: bfloat16 halves, float32 range
+        model = RPNModel("mobilenet_v2", hp, precision="bf16x3", max_batch=2)
+        model.set_weights(weights)
+        reg, cls = model.predict_on_batch(imgs)
+    e_reg = float(np.abs(reg.reshape(ref[0].shape) - ref[0]).max())
+    e_cls = float(np.abs(cls.reshape(ref[1].shape) - ref[1]).max())
+    print("%s%s: max|err| vs float64 oracle: deltas %.3e, objectness %.3e" % (precision, " -> bf16x3 (range flag)" if flagged else "",
+                                                                              e_reg, e_cls))
+    assert e_reg <= 1e-4 and e_cls <= 1e-4
+    assert not flagged                                   # nothing here leaves the float16 range (ReLU6-bounded activations)
+
+
+def test_proposer_wait_raises_on_f16_range_error():
+    """CUDA-tensor callers of the Proposer: the hot launches never synchronise, but the points where results are collected
+    -- ``wait()`` (hence ``propose()`` in pipelined mode) and ``flush_distributed()`` -- read the float16 range word under
+    f16x3 and raise FloatingPointError instead of handing out invalid proposals; ``check_range=False`` keeps the old
+    poll-it-yourself behaviour; clean weights never raise."""
+    hp = bo.get_hyper_params("vgg16", img_size=96, feature_map_shape=6)
+    base = synthetic_weights("vgg16", hp, seed=1)
+    bad = _scaled_pair(base, "block2_conv1", "block2_conv2", 2.0 ** 20)
+    x = torch.from_numpy(np.random.RandomState(0).uniform(0, 1, size=(2, 96, 96, 3)).astype(np.float32)).cuda()
+    prop = Proposer("vgg16", hyper_params=dict(hp), weights=bad, precision="f16x3", max_batch=2, overlap_nms=True)
+    prop.propose_async(x)                               # the launch itself does not raise (no host read-back)
+    with pytest.raises(FloatingPointError, match="float16 range"):
+        prop.wait()
+    with pytest.raises(FloatingPointError, match="float16 range"):
+        prop.propose(x)
+    gather = [torch.empty((2, prop.topn * 5 + 1), device="cuda") for _ in range(2)]
+    prop.propose_distributed_pipelined(x, gather)
+    with pytest.raises(FloatingPointError, match="float16 range"):
+        prop.flush_distributed(gather)
+    quiet = Proposer("vgg16", hyper_params=dict(hp), weights=bad, precision="f16x3", max_batch=2, overlap_nms=True,
+                     check_range=False)
+    quiet.propose(x)
+    assert quiet.rpn_model.status(reset=True)["f16_range"]
+    for precision in ("f16x3", "bf16x3"):
+        good = Proposer("vgg16", hyper_params=dict(hp), weights=base if precision == "f16x3" else bad, precision=precision,
+                        max_batch=2, overlap_nms=True)
+        boxes, scores, valid, idx = good.propose(x)
+        assert int(valid.min()) > 0

@@ -688,7 +688,7 @@ bool rpn_head_supported(int Cin, int ncols) { return Cin == 512 && ncols >= 1 &&
 hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, const float *bias, int n_reg, int n_cls,
                            float *reg, float *cls, hipStream_t stream, int n_slabs, long long slab_floats, const float *conv_bias)
 {
-    if (n_slabs < 1 || (n_slabs > 1 && !conv_bias)) return hipErrorInvalidValue;
+    if ((n_slabs != 1 && n_slabs != 2 && n_slabs != 4) || (n_slabs > 1 && !conv_bias)) return hipErrorInvalidValue;   // the kernel adds 1, 2 or 4 slabs, nothing else
     const int ncols = n_reg + n_cls;
     if (!rpn_head_supported(512, ncols) || P <= 0 || (P + 31) / 32 > 0x7fffffffll) return hipErrorInvalidValue;
     // a grid of fewer than 256 workgroups (one image): 16 pixels per workgroup instead of 32 -- its operand, up to four slabs of

@@ -88,7 +88,11 @@ struct rpn_model {
     size_t weight_floats = 0, arena_floats = 0;   // arena: per-image floats
     float *d_weights = nullptr, *d_arena = nullptr;
     unsigned *d_status = nullptr;          // RPN_STATUS_* flags raised by the kernels (sticky until rpn_model_status resets)
-    float *d_ksplit = nullptr;             // MobileNetV2 f16x3 blocks on small grids: partial projections + tickets (launch_ir_block_x3)
+    // MobileNetV2 f16x3 blocks on small grids: partial projections + tickets (launch_ir_block_x3).  ONE buffer per handle,
+    // shared by every such launch of a forward: the tickets are left at zero by the last arriver of each tile, which holds
+    // only while the forwards of a handle run in stream order.  Two concurrent rpn_model_forward calls on the SAME handle
+    // from different streams are not supported (rpn_hip.h says so); use one handle per stream.
+    float *d_ksplit = nullptr;
     const float *last_input = nullptr;
     double flops = 0.0;
     // optional per-op timing: one hipEvent before the first op and one after every op

@@ -496,8 +496,10 @@ extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
 // barrier -> every workgroup reads the 8 KB sum back and takes the same decision the single workgroup would have taken;
 // the band's keys are compacted per slice into the rank's region of the workspace, and after the last barrier the LEADER
 // (rank 0) orders the band and runs the greedy selection (and any later band) alone; the other ranks have left.
-// Deadlock-free: a waiting workgroup holds its CU, the ones it waits for are already dispatched or are dispatched as
-// soon as ANY CU frees up (other kernels' workgroups always finish), and the host keeps pairs * G <= 128 workgroups.
+// No hang by construction of the WAIT, not of the dispatch: a waiting workgroup holds its CU and nothing guarantees that the
+// ranks it waits for are resident (persistent kernels of another stream can hold every other CU for their whole run), so
+// every wait is bounded in wall-clock time (kClusterWaitTicks) and a rank that does not show up in time is given up -- the
+// leader recomputes alone.  The host keeps pairs * G <= 128 workgroups so that, on an idle device, all of them fit at once.
 constexpr int kClusterMax = 16;
 constexpr int kClCtlWords = 64 + 3 * 2048;      // [0..2] barrier counters, [16 + g] keys of rank g, [64..) three histograms
 
@@ -516,9 +518,11 @@ struct ClusterCtx {
 // with relaxed device-scope loads.  (First version: __threadfence() by all 1024 threads on both sides and an acquire load per
 // poll: ~25 k cycles per barrier; one release / acquire fence pair by thread 0: ~4-6 k -- an L2 write-back and invalidate
 // each, which also evict what the kernels of the other stream are working from.)
-// The wait is BOUNDED (~0.1 s of polling: far beyond any kernel another stream could be holding the CUs with): returns
-// false when a rank never arrived, and the caller then gives the cluster up -- the leader recomputes the band alone, so a
-// lost rank costs time, never a hang or a wrong result.  `flag`: one int of LDS.
+// The wait is BOUNDED in wall-clock time (s_memrealtime, the constant 100 MHz counter: 2 ms -- several times the longest
+// conv kernel another stream could be holding the CUs with, and independent of the shader clock and of load latency):
+// returns false when a rank did not arrive in time, and the caller then gives the cluster up -- the leader recomputes the
+// band alone, so a late rank costs at most the budget, never a hang or a wrong result.  `flag`: one int of LDS.
+constexpr unsigned long long kClusterWaitTicks = 200000ull;
 __device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool wait, int *flag)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -527,9 +531,9 @@ __device__ __forceinline__ bool cluster_arrive(const ClusterCtx &cl, int k, bool
         __hip_atomic_fetch_add(cl.ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
         if (wait) {
-            int spins = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(cl.ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl.G) {
-                if (++spins > (1 << 17)) { ok = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kClusterWaitTicks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }

@@ -22,7 +22,8 @@ class Proposer(object):
     """anchors once (predictor.py:46), then ``propose(imgs)`` per batch."""
 
     def __init__(self, backbone="vgg16", hyper_params=None, weights="synthetic", precision="f32",
-                 max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1, overlap_nms=False):
+                 max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1, overlap_nms=False,
+                 check_range=True):
         if backbone == "mobilenet_v2":
             from .models.rpn_mobilenet_v2 import get_model
         else:
@@ -41,6 +42,10 @@ class Proposer(object):
         self.iou_threshold = float(iou_threshold)
         self.score_threshold = float(score_threshold)
         self.max_batch = int(max_batch)
+        # precision "f16x3" only: ``wait()`` / ``flush_distributed()`` -- the points where a caller collects results --
+        # read the device's float16 range word and raise FloatingPointError instead of handing out invalid proposals.
+        # The launches themselves (``propose_async``, ``propose_distributed_pipelined``) never synchronise.
+        self.check_range = bool(check_range)
         F, K = self.rpn_model.feature_map_shape, self.rpn_model.anchor_count
         self.total_anchors = F * F * K
         dev = "cuda"
@@ -56,7 +61,10 @@ class Proposer(object):
         self._vkeep = _keep
         # NMS scratch (rpn_nms_workspace_bytes): non-zero for few images with many anchors, where several workgroups per
         # image share the passes over the scores.  One buffer: a Proposer's NMS launches are ordered on one stream.
-        self._nms_ws_bytes = int(L.lib().rpn_nms_workspace_bytes(self.max_batch, self.total_anchors, 1, M, M))
+        # The size depends on the RUNTIME batch (the cluster scratch exists for few images with many anchors only), so it is
+        # the maximum over every batch size this object accepts, not the value at max_batch.
+        self._nms_ws_bytes = max(int(L.lib().rpn_nms_workspace_bytes(b, self.total_anchors, 1, M, M))
+                                 for b in range(1, self.max_batch + 1))
         self._nms_ws = torch.empty((max(self._nms_ws_bytes, 16),), dtype=torch.uint8, device=dev)
         # optional 2-stage pipeline across batches: the NMS of batch k (one workgroup per image: 8 of 256 CUs)
         # runs on a side stream while the conv stack of batch k+1 runs on the main stream.  Head outputs and
@@ -161,9 +169,17 @@ class Proposer(object):
         return ob, osc, ov, oi
 
     def wait(self):
-        """Make the current stream wait for the proposals returned by the last ``propose`` (pipelined mode)."""
+        """Make the current stream wait for the proposals returned by the last ``propose`` (pipelined mode).  Under
+        precision "f16x3" (and ``check_range``) this is also where the float16 range word of the forwards so far is read
+        back (one 4-byte copy, synchronising the current stream): FloatingPointError when an activation left the range --
+        the proposals are invalid then; use "bf16x3" or "f32" for such weights."""
         if self.overlap_nms and getattr(self, "_last", None) is not None:
             torch.cuda.current_stream().wait_event(self._last["nms_done"])
+        self._poll_range()
+
+    def _poll_range(self):
+        if self.check_range and self.rpn_model.precision in ("f16x3", "fp16x3"):
+            self.rpn_model.raise_on_range_error()
 
     def propose_unfused(self, imgs):
         """Same result through the reference's separate calls (decode, then NMS)."""
@@ -263,6 +279,7 @@ class Proposer(object):
         if prev is None:
             return None
         torch.cuda.current_stream().wait_event(prev[1])
+        self._poll_range()                             # (f16x3: FloatingPointError instead of invalid records, see wait())
         return prev[0]
 
     def propose_distributed(self, local_imgs, gather_out=None, total=None):
