@@ -47,9 +47,20 @@ __device__ unsigned long long g_ir_stamps[512 * 128];
         if (threadIdx.x == 64 * (w) && blockIdx.x < 512 && (k) < 128 && a.stamp)                          \
             g_ir_stamps[blockIdx.x * 128 + (k)] = __builtin_readcyclecounter();                            \
     } while (0)
+#define IR_STAMP_RT(w, k)                                                                                 \
+    do {                                                                                                  \
+        if (threadIdx.x == 64 * (w) && blockIdx.x < 512 && (k) < 128 && a.stamp)                          \
+            g_ir_stamps[blockIdx.x * 128 + (k)] = __builtin_amdgcn_s_memrealtime();                        \
+    } while (0)
 extern "C" int rpn_debug_read_ir_stamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ir_stamps), (size_t)n * 8);
+}
+extern "C" int rpn_debug_clear_ir_stamps(void)
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ir_stamps)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(g_ir_stamps));
 }
 // ... and of ir_block_hrx3_kernel (scripts/hr_stamp_probe.py): per variant v (block 1 / 2 / 3), workgroups 512 .. 767, 40 slots:
 // [0] start, [1] A operand built, per chunk c: [2+3c] E written (after the barrier), [3+3c] D written (after the barrier),
@@ -66,6 +77,7 @@ extern "C" int rpn_debug_read_hr_stamps(unsigned long long *out, int n)
 }
 #else
 #define IR_STAMP(w, k) ((void)0)
+#define IR_STAMP_RT(w, k) ((void)0)
 #define HR_STAMP(v, k) ((void)0)
 #endif
 
@@ -928,6 +940,7 @@ ir_block_x3_kernel(IrX3Args a)
     const int oy0 = ty * IR_TH, ox0 = tx * IR_TW;
     const int gy0 = oy0 - 1, gx0 = ox0 - 1;
     IR_STAMP(0, 0);
+    IR_STAMP_RT(0, 104);
     if (wave >= 4) __builtin_amdgcn_s_setprio(2);            // (see ir_block_kernel)
 
     u32x4 we_st[NWE], wp_st[NWP];
@@ -1141,6 +1154,24 @@ ir_block_x3_kernel(IrX3Args a)
         IR_STAMP(0, 5 + 4 * it);
     }
 
+    // the output epilogue's operands (projection bias, the residual = this tile's own input pixels) are requested here, in
+    // front of the seam: their L2 round trip runs under the hand-off instead of behind it
+    float obias[NJ], ores[NJ][4];
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co = (nbp + 2 * j) * 16 + lr;
+            obias[j] = a.bp[co];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = mbp * 16 + 4 * lk + i;
+                const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
+                ores[j][i] = 0.0f;
+                if constexpr (RES)
+                    if (oy < a.H && ox < a.W) ores[j][i] = a.x[(((size_t)img * a.H + oy) * a.W + ox) * KP + co];
+            }
+        }
+    }
     if (ksplit > 1) {
         // ---- K-split: this workgroup's pair (ksplit = 3) or leaf (6) -> `part`; the last arriver adds them in tree order -------
         // Visibility WITHOUT cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility, second form): every handed-off
@@ -1148,15 +1179,21 @@ ir_block_x3_kernel(IrX3Args a)
         // drains its stores (vmcnt(0)) in front of the workgroup barrier that precedes the ticket.  (First version: an
         // agent-scope release in front of the ticket and an acquire behind it -- an L2 write-back and an L2 invalidate per
         // workgroup, with hundreds of workgroups of the same kernel still computing out of that L2: configs[4] 0.384 -> 0.455 ms.)
-        float *mine = a.part + ((size_t)tile * ksplit + part_h) * (32 * COUT);
+        // The slab layout is the accumulator layout: lane l of matrix wave w keeps its f32x4 of N-block pair j at
+        // [(j * 4 + w) * 64 + l] -- ONE 16-byte sc1 store per accumulator (1 KB contiguous per wave instruction) and one
+        // 16-byte sc1 load per partial for the last arriver, all of them in flight together.  (First version: 4-byte
+        // device-scope atomics, 8 stores + 48 dependent-free but scalar loads per lane: the seam cost 11.5 k cycles of a
+        // 26 k-cycle workgroup at one image -- scalar sc1 accesses are one fabric transaction each.)
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            a.part + (size_t)tile * ksplit * (32 * COUT), (short)0, ksplit * 32 * COUT * 4, 0x00020000);
+        constexpr int kSc1 = 16;                                         // cache-policy bit 4 = sc1 (device scope)
+        IR_STAMP(0, 100);
         if (wave < 4) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int co = (nbp + 2 * j) * 16 + lr;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __hip_atomic_store(mine + (mbp * 16 + 4 * lk + i) * COUT + co, (ksplit == 2 && part_h == 0) ? ptot[j][i] : ppair[j][i],
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const f32x4 v = (ksplit == 2 && part_h == 0) ? ptot[j] : ppair[j];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs,
+                                                       (part_h * 32 * COUT + ((j * 4 + wave) * 64 + lane) * 4) * 4, 0, kSc1);
             }
         }
         __shared__ unsigned last_flag;
@@ -1169,43 +1206,46 @@ ir_block_x3_kernel(IrX3Args a)
             last_flag = last;
         }
         __syncthreads();
+        IR_STAMP(0, 101);
+        IR_STAMP_RT(0, 105);
         if (last_flag == 0u) return;
         if (wave < 4) {
-            const float *base = a.part + (size_t)tile * ksplit * (32 * COUT);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int co = (nbp + 2 * j) * 16 + lr;
+                f32x4 q[6];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = (mbp * 16 + 4 * lk + i) * COUT + co;
-                    float q[6];
-#pragma unroll
-                    for (int h = 0; h < 6; ++h)
-                        q[h] = h < ksplit ? __hip_atomic_load(base + (size_t)h * (32 * COUT) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-                    ptot[j][i] = ksplit == 2 ? q[0] + q[1]
-                                             : (ksplit == 3 ? (q[0] + q[1]) + q[2] : ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
-                }
+                for (int h = 0; h < 6; ++h)
+                    q[h] = h < ksplit ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            prs, (h * 32 * COUT + ((j * 4 + wave) * 64 + lane) * 4) * 4, 0, kSc1))
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                ptot[j] = ksplit == 2 ? q[0] + q[1]
+                                      : (ksplit == 3 ? (q[0] + q[1]) + q[2] : ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
             }
         }
     }
+    IR_STAMP(0, 102);
     if (wave < 4) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int co = (nbp + 2 * j) * 16 + lr;
-            const float bias = a.bp[co];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = mbp * 16 + 4 * lk + i;
                 const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
                 if (oy < a.H && ox < a.W) {
                     const size_t pix = ((size_t)img * a.H + oy) * a.W + ox;
-                    float v = ptot[j][i] * a.scale_p + bias;
-                    if constexpr (RES) v += a.x[pix * KP + co];           // the block input (L2-hot: this tile just read it)
+                    float v = ptot[j][i] * a.scale_p + obias[j];
+                    if constexpr (RES) v += ores[j][i];
                     a.out[pix * COUT + co] = v;
                 }
             }
         }
     }
+#ifdef RPN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IR_STAMP(0, 103);
+    IR_STAMP_RT(0, 105);
+#endif
 }
 
 // ---- f16x3 variant of the high-resolution blocks (blocks 1-3: Cin = 16 / 24) -------------------------------------------
@@ -1577,6 +1617,11 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
         const char *sel = getenv("RPN_IR_STAMP_OP");
         int sc = -1, ss = -1;
         a.stamp = sel && sscanf(sel, "%d,%d", &sc, &ss) == 2 && sc == cin && ss == 1 && (cin != 64 || cout == 64);
+        // RPN_IR_STAMP_NTH=n,k: of the matching launches, only every k-th one starting with the n-th (one block of a forward)
+        static long long matches = 0;
+        const char *nth = getenv("RPN_IR_STAMP_NTH");
+        int sn = 0, sk = 1;
+        if (a.stamp && nth && sscanf(nth, "%d,%d", &sn, &sk) == 2 && sk > 0) a.stamp = (matches++ % sk) == sn;
     }
 #endif
     if (cin == 32) hipLaunchKernelGGL((ir_block_x3_kernel<32, 192, 32, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
