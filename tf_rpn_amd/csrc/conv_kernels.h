@@ -95,6 +95,12 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
                               const float *bp, float scale_e, float scale_p, float *out, unsigned *status, float *scratch,
                               hipStream_t s);
 
+// pointwise conv (1 x 1) + bias + ReLU6 on the 16-bit MFMA (f16x3), float32 NHWC (P, cin) in -> SPLIT16 (P, cout) out:
+// MobileNetV2's block_13_expand in front of rpn_conv.  w = pack_ir_x3_expand image, scale = 2^-shift.
+bool pw_x3_supported(int cin, int cout);
+hipError_t launch_pw_x3(const float *x, long long P, int cin, int cout, const void *w, const float *bias, float scale,
+                        void *out, unsigned *status, hipStream_t s);
+
 // f16x3 variant of the high-resolution blocks 1-3 (Cin = 16 / 24; mnv2_block_kernels.hip: ir_block_hrx3_kernel): the
 // expand GEMM's K is zero-padded to one 32-deep step, so the fragment images are LARGER than the float32 matrices --
 // ir_hrx3_*_floats give their sizes in floats.

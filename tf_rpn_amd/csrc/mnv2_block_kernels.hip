@@ -1248,6 +1248,150 @@ ir_block_x3_kernel(IrX3Args a)
 #endif
 }
 
+// ---- pointwise conv (1 x 1, stride 1) + bias + ReLU6 on the 16-bit MFMA, float32 NHWC in -> SPLIT16 out ------------------
+// block_13_expand (96 -> 576, models/rpn_mobilenet_v2.py:17: the tap layer that feeds rpn_conv) under f16x3: the expand
+// GEMM of ir_block_x3_kernel on its own (hi + lo float16 operands, lo*hi + hi*lo + hi*hi per product, float32 accumulation),
+// weights in pack_ir_x3_expand's fragment-major image.  It replaces the float32-MFMA implicit GEMM there (1/16 of the rate:
+// 27 us at batch 8, 11 us at one image).  A wave owns 16 pixels: its A fragments (a lane = (pixel, 8 channels): two 16-byte
+// loads per k-step) are built straight from global memory and stay in registers; the workgroup's NT output channels' weight
+// fragments are staged once in LDS (one linear copy) and read with linear, conflict-free ds_read_b128.  Epilogue: the wave's
+// 16 x NT outputs go to LDS as SPLIT16 records ({hi[0:8], lo[0:8], hi[8:16], lo[8:16]} per 16 channels: even lane = the hi
+// dword of a channel pair, odd lane = its lo dword, DPP pair exchange) over the weight tile, and leave as 16-byte stores of
+// NT * 4 contiguous bytes per pixel.
+struct PwX3Args {
+    const float *x;       // (P, KP) float32
+    const u32x4 *w;       // pack_ir_x3_expand(w [KP][COUT] * 2^shift)
+    const float *bias;    // (COUT)
+    unsigned *out;        // (P, COUT / 16) SPLIT16 records of 64 bytes
+    float scale;          // 2^-shift
+    long long P;
+    int COUT;
+    unsigned *status;     // float16 range flag, or null
+};
+
+template <int KP, int NT, int MW>
+__global__ void __launch_bounds__(64 * MW)
+pw_x3_kernel(PwX3Args a)
+{
+    constexpr int KS = KP / 32, NB = NT / 16;
+    constexpr int WPIECES = NB * KS * 2 * 64;                              // 16-byte pieces of the weight tile
+    constexpr int OUT_DW = 16 * NT;                                         // dwords of one wave's output records (16 px x NT ch x 4 B)
+    static_assert(KP % 32 == 0 && NT % 32 == 0, "shape");
+    static_assert(MW * OUT_DW * 4 <= WPIECES * 16 || true, "");
+    constexpr int LDS_PIECES = WPIECES > MW * OUT_DW / 4 ? WPIECES : MW * OUT_DW / 4;
+    __shared__ u32x4 Ws[LDS_PIECES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ntiles = a.COUT / NT;
+    const int nt = (int)blockIdx.x % ntiles;
+    const long long mt = (long long)blockIdx.x / ntiles;
+    const long long p0 = (mt * MW + wave) * 16;                            // this wave's first pixel
+
+    // weight tile: chunks [nt * NT / 32, (nt + 1) * NT / 32) of the packed image are one contiguous run
+    {
+        const u32x4 *src = a.w + (size_t)nt * WPIECES;
+        u32x4 st[(WPIECES + 64 * MW - 1) / (64 * MW)];
+#pragma unroll
+        for (int i = 0; i < (WPIECES + 64 * MW - 1) / (64 * MW); ++i)
+            if (WPIECES % (64 * MW) == 0 || tid + 64 * MW * i < WPIECES) st[i] = src[tid + 64 * MW * i];
+        // A operand: lane (row lr, k-quarter lk) <- 8 consecutive channels of pixel p0 + lr per k-step (requested behind the
+        // weight loads, in flight with them)
+        float4 xa[KS][2];
+        const long long px = p0 + lr;
+        const bool live = px < a.P;
+        const float *xr = a.x + (size_t)(live ? px : 0) * KP + lk * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xa[ks][0] = live ? *reinterpret_cast<const float4 *>(xr + ks * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[ks][1] = live ? *reinterpret_cast<const float4 *>(xr + ks * 32 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < (WPIECES + 64 * MW - 1) / (64 * MW); ++i)
+            if (WPIECES % (64 * MW) == 0 || tid + 64 * MW * i < WPIECES) Ws[tid + 64 * MW * i] = st[i];
+        __syncthreads();
+
+        u32x4 ahi[KS], alo[KS];
+        bool bad = false;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float v[8] = {xa[ks][0].x, xa[ks][0].y, xa[ks][0].z, xa[ks][0].w, xa[ks][1].x, xa[ks][1].y, xa[ks][1].z, xa[ks][1].w};
+            f16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bad = bad || !(fabsf(v[j]) <= 65504.0f);
+                h[j] = (_Float16)v[j];
+                l[j] = (_Float16)(v[j] - (float)h[j]);
+            }
+            ahi[ks] = __builtin_bit_cast(u32x4, h);
+            alo[ks] = __builtin_bit_cast(u32x4, l);
+        }
+        if (a.status && bad) atomicOr(a.status, 1u);
+
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int c = nb >> 1, h2 = nb & 1;                                // packed image: [chunk][nb 2][ks][hi|lo][lane]
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 bhi = Ws[(((c * 2 + h2) * KS + ks) * 2 + 0) * 64 + lane];
+                const u32x4 blo = Ws[(((c * 2 + h2) * KS + ks) * 2 + 1) * 64 + lane];
+                acc[nb] = mfma_x3(ahi[ks], alo[ks], bhi, blo, acc[nb]);
+            }
+        }
+        __syncthreads();                                                       // the weight tile is dead: records go over it
+
+        unsigned *rec = reinterpret_cast<unsigned *>(Ws) + wave * OUT_DW;      // [16 px][NT / 16 records][16 dwords]
+        const int odd = lr & 1;
+        const int dw = (lr >> 3) * 8 + odd * 4 + ((lr & 7) >> 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float bias = a.bias[nt * NT + nb * 16 + lr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = relu6f(acc[nb][i] * a.scale + bias);
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);
+                const unsigned hu = __builtin_bit_cast(unsigned short, h), lu = __builtin_bit_cast(unsigned short, l);
+                const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
+                const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
+                rec[((4 * lk + i) * NB + nb) * 16 + dw] = word;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (the wave reads back only what it wrote itself)
+        constexpr int ROWP = NT / 4;                                           // 16-byte pieces per pixel
+        const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(rec);
+#pragma unroll
+        for (int t = 0; t < (16 * ROWP) / 64; ++t) {
+            const int piece = lane + 64 * t;
+            const int row = piece / ROWP, col = piece - row * ROWP;
+            if (p0 + row < a.P)
+                *reinterpret_cast<u32x4 *>(a.out + (size_t)(p0 + row) * a.COUT + nt * NT + col * 4) = rec4[piece];
+        }
+    }
+}
+
+bool pw_x3_supported(int cin, int cout) { return cin == 96 && cout % 96 == 0; }
+
+hipError_t launch_pw_x3(const float *x, long long P, int cin, int cout, const void *w, const float *bias, float scale,
+                        void *out, unsigned *status, hipStream_t s)
+{
+    if (!pw_x3_supported(cin, cout) || P <= 0) return hipErrorInvalidValue;
+    PwX3Args a{};
+    a.x = x; a.w = reinterpret_cast<const u32x4 *>(w); a.bias = bias; a.out = reinterpret_cast<unsigned *>(out);
+    a.scale = scale; a.P = P; a.COUT = cout; a.status = status;
+    // small grids (one image): 64-pixel x 32-channel tiles, hundreds of short workgroups; else 128 x 96
+    if (P <= 4096) {
+        const long long blocks = (P + 63) / 64 * (cout / 32);
+        hipLaunchKernelGGL((pw_x3_kernel<96, 32, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+        const long long blocks = (P + 127) / 128 * (cout / 96);
+        hipLaunchKernelGGL((pw_x3_kernel<96, 96, 8>), dim3((unsigned)blocks), dim3(512), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 // ---- f16x3 variant of the high-resolution blocks (blocks 1-3: Cin = 16 / 24) -------------------------------------------
 // ir_block_hr_kernel with both GEMMs on v_mfma_f32_16x16x32_f16 (hi + lo float16 operands, three MFMAs per product, float32
 // accumulation: the arithmetic of ir_block_x3_kernel).  rocprofv3 on the float32 form (profiles/r03_mn8_pmc.txt): the waves

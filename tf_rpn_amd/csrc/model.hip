@@ -152,6 +152,16 @@ static int add_param(rpn_model *m, int op, const std::string &name, const std::s
     return (int)m->params.size() - 1;
 }
 
+// F16X3 only: a pointwise conv + ReLU6 whose output goes to a split conv as SPLIT16 (MobileNetV2: block_13_expand in front
+// of rpn_conv) runs on the 16-bit MFMA (pw_x3_kernel) instead of the float32 implicit GEMM.  Decided where it is used: the
+// producer only learns that its output is SPLIT16 when its consumer is added.
+static bool is_pw_x3(const rpn_model *m, const Op &op)
+{
+    return op.kind == OP_CONV && op.f32_out_split && m->f16 && op.R == 1 && op.S == 1 && op.stride == 1 && op.act == ACT_RELU6 &&
+           op.residual < 0 && !op.ps.generic && pw_x3_supported(op.Cin, op.Cout) && op.ps.floats() == (size_t)op.Cin * op.Cout &&
+           (RPN_KNOB("RPN_MN_X3", 1) != 0);
+}
+
 // dense conv op; returns the output tensor id
 static int add_conv(rpn_model *m, const std::string &name, const std::string &bn, int in, int Cout, int R,
                     int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1,
@@ -803,6 +813,17 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                 hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+    } else if (is_pw_x3(m, op)) {
+        // [Cin][Cout] with BatchNorm folded, then the power-of-two pre-scale and the fragment-major hi / lo float16 image
+        std::vector<float> w((size_t)p.Cin * p.Cout);
+        for (int k = 0; k < p.Cin; ++k)
+            for (int n = 0; n < p.Cout; ++n) w[(size_t)k * p.Cout + n] = kernel[(size_t)k * p.Cout + n] * (has_bn ? scale[n] : 1.0f);
+        const int sh = split_weight_shift(w.data(), w.size(), true);
+        std::vector<float> packed(w.size());
+        pack_ir_x3_expand(w.data(), p.Cin, p.Cout, sh, reinterpret_cast<unsigned short *>(packed.data()));
+        op.out_scale = ldexpf(1.0f, -sh);
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float), hipMemcpyHostToDevice));
     } else {
         std::vector<float> packed(op.ps.floats());
         pack_weights_host(op.ps, kernel, has_bn ? scale.data() : nullptr, packed.data());
@@ -924,6 +945,9 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                                 m->K, d_reg, d_cls, s, head_slabs, (long long)B * op.H * op.W * 512,
                                 head_slabs > 1 ? m->d_weights + head_conv_bias : nullptr);
             head_slabs = 1;
+        } else if (is_pw_x3(m, op)) {
+            e = launch_pw_x3(x, (long long)B * op.H * op.W, op.Cin, op.Cout, m->d_weights + op.w_off, m->d_weights + op.b_off,
+                             op.out_scale, tensor_ptr(m, op.out, d_imgs), m->d_status, s);
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
             a.x = x;
@@ -1076,6 +1100,8 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         static thread_local char kname32[64];
         if (op.kind == OP_HEAD && rpn_head_supported(op.Cin, op.Cout) && head_splitk())
             snprintf(kname32, sizeof kname32, "rpn_head_splitk<%d>", (op.Cout + 15) / 16);
+        else if (is_pw_x3(m, op))
+            snprintf(kname32, sizeof kname32, "pw_f16x3<%d,%d>", op.Cin, op.Cout);
         else
         {
             const int bn32 = conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout);
@@ -1118,7 +1144,8 @@ extern "C" int rpn_model_op_arith(const rpn_model *m, int i)
 {
     if (!m || i < 0 || i >= (int)m->ops.size()) return -1;
     const Op &op = m->ops[i];
-    const bool x3 = (op.kind == OP_CONV && (op.split || op.cin3_mfma)) || op.kind == OP_VGGB1 || (op.kind == OP_IRBLOCK && op.ir_x3);
+    const bool x3 = (op.kind == OP_CONV && (op.split || op.cin3_mfma)) || op.kind == OP_VGGB1 || (op.kind == OP_IRBLOCK && op.ir_x3) ||
+                    is_pw_x3(m, op);
     return x3 ? (m->f16 ? RPN_PRECISION_F16X3 : RPN_PRECISION_BF16X3) : RPN_PRECISION_F32;
 }
 
