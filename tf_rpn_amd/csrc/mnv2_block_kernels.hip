@@ -895,6 +895,18 @@ __device__ __forceinline__ f32x4 mfma_x3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ahi), __builtin_bit_cast(f16x8, bhi), c, 0, 0, 0);
 }
 
+// Slot swizzle of the fragment-major A images the kernels BUILD in LDS (input tile, depthwise output).  A 1 KB block holds
+// 64 slots of 16 bytes, slot = 16 * kq + row for the lane (row, kq) that reads it.  The builders scatter: for one pixel (row)
+// the 32 channels of a chunk land in the four kq slots of the hi block and of the lo block -- slots 16 apart = the same
+// four LDS banks: an 8-way conflict on every store (rocprofv3, round 3: 25-49 % of the LDS cycles of these kernels).  With
+// slot = 16 * kq + (row ^ (kq | sel << 2)) -- sel = hi / lo for the depthwise image, the parity of the k-step for the input
+// image -- the eight stores of a pixel fall into eight different bank groups, and the reading side stays conflict-free: a
+// ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), the XOR only permutes rows inside
+// the aligned sets {0-3}, {4-7}, {8-11}, {12-15} (kq < 4) or swaps such sets pairwise (sel), so every group still covers
+// 16 different slots mod 16.
+__device__ __forceinline__ int frag_slot(int kq, int row, int sel) { return kq * 16 + (row ^ (kq | (sel << 2))); }
+__device__ __forceinline__ int frag_lane(int lane, int sel) { return lane ^ ((lane >> 4) | (sel << 2)); }
+
 template <int KP, int CEXP, int COUT, bool RES>
 __global__ void __launch_bounds__(IR_THREADS)
 ir_block_x3_kernel(IrX3Args a)
@@ -993,7 +1005,7 @@ ir_block_x3_kernel(IrX3Args a)
                               (_Float16)(v.w - (float)hi[3])};
             const int c0 = 4 * cq, ks = c0 >> 5, kq = (c0 >> 3) & 3, j0 = c0 & 7;
             const int blk = ((m >> 4) * KS + ks) * 2;                     // hi block; lo block = blk + 1
-            const int off = ((kq * 16 + (m & 15)) * 8 + j0);             // halves inside the 1 KB block
+            const int off = (frag_slot(kq, m & 15, ks & 1) * 8 + j0);    // halves inside the 1 KB block (swizzled slot)
             *reinterpret_cast<f16x4 *>(xh + (size_t)blk * 512 + off) = hi;
             *reinterpret_cast<f16x4 *>(xh + (size_t)(blk + 1) * 512 + off) = lo;
         }
@@ -1046,8 +1058,8 @@ ir_block_x3_kernel(IrX3Args a)
             if (it >= 2) {
                 const u32x4 *dsf = DsF[it & 1];
                 const u32x4 *wps = WpS[it & 1];
-                dhi = dsf[(mbp * 2 + 0) * 64 + lane];
-                dlo = dsf[(mbp * 2 + 1) * 64 + lane];
+                dhi = dsf[(mbp * 2 + 0) * 64 + frag_lane(lane, 0)];
+                dlo = dsf[(mbp * 2 + 1) * 64 + frag_lane(lane, 1)];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int nb = nbp + 2 * j;
@@ -1061,8 +1073,8 @@ ir_block_x3_kernel(IrX3Args a)
                 u32x4 xa[KS][2], wb[KS][NBE][2];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    xa[ks][0] = XsF[((wave * KS + ks) * 2 + 0) * 64 + lane];
-                    xa[ks][1] = XsF[((wave * KS + ks) * 2 + 1) * 64 + lane];
+                    xa[ks][0] = XsF[((wave * KS + ks) * 2 + 0) * 64 + frag_lane(lane, ks & 1)];
+                    xa[ks][1] = XsF[((wave * KS + ks) * 2 + 1) * 64 + frag_lane(lane, ks & 1)];
 #pragma unroll
                     for (int nb = 0; nb < NBE; ++nb) {
                         wb[ks][nb][0] = wes[((nb * KS + ks) * 2 + 0) * 64 + lane];
@@ -1145,7 +1157,7 @@ ir_block_x3_kernel(IrX3Args a)
                     const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
                     const int p = py * IR_TW + dg * PXG + px;
                     const int blk = (p >> 4) * 2 + odd;                  // [mb][hi|lo]
-                    dw32[blk * 256 + (kq * 16 + (p & 15)) * 4 + jp] = word;
+                    dw32[blk * 256 + frag_slot(kq, p & 15, odd) * 4 + jp] = word;
                 }
             }
             IR_STAMP(4, 4 + 4 * it);
@@ -1556,7 +1568,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
                     const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
                     const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
                     const int p = py * HR_T + dx0 + px;
-                    dw32[(((p >> 4) * KSP + ks) * 2 + odd) * 256 + (kq * 16 + (p & 15)) * 4 + jp] = word;
+                    dw32[(((p >> 4) * KSP + ks) * 2 + odd) * 256 + frag_slot(kq, p & 15, odd) * 4 + jp] = word;
                 }
             }
         }
@@ -1565,7 +1577,8 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         // ---- P(c): acc (16 px of M-block pmb x COUT) += D (16 x CE) * Wp[chunk] ---------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
-            const u32x4 dhi = DsF[((pmb * KSP + ks) * 2 + 0) * 64 + lane], dlo = DsF[((pmb * KSP + ks) * 2 + 1) * 64 + lane];
+            const u32x4 dhi = DsF[((pmb * KSP + ks) * 2 + 0) * 64 + frag_lane(lane, 0)],
+                        dlo = DsF[((pmb * KSP + ks) * 2 + 1) * 64 + frag_lane(lane, 1)];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int nb = pnb0 + 2 * j;
@@ -1603,13 +1616,20 @@ ir_block_hrx3_kernel(IrHrX3Args a)
 }
 
 // chunk size (expanded channels per step) of the high-resolution f16x3 blocks: the f32 form's
-static int ir_hrx3_ce(int cin, int stride) { return (cin == 24 && stride == 1) ? 48 : 16; }
+// block 6 (32 -> 192 -> 64, stride 2) on this kernel: RPN_MN_B6 = its chunk size (16 | 48), 0 = the float32 two-group kernel
+static int ir_hrx3_b6()
+{
+    static const int v = RPN_LAB_KNOB("RPN_MN_B6", 48);
+    return v;
+}
+static int ir_hrx3_ce(int cin, int stride) { return cin == 32 ? ir_hrx3_b6() : ((cin == 24 && stride == 1) ? 48 : 16); }
 
 bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
     return (cin == 16 && cexp == 96 && cout == 24 && stride == 2 && !residual) ||
            (cin == 24 && cexp == 144 && cout == 24 && stride == 1 && residual) ||
-           (cin == 24 && cexp == 144 && cout == 32 && stride == 2 && !residual);
+           (cin == 24 && cexp == 144 && cout == 32 && stride == 2 && !residual) ||
+           (cin == 32 && cexp == 192 && cout == 64 && stride == 2 && !residual && ir_hrx3_b6() != 0);
 }
 
 size_t ir_hrx3_expand_floats(int cexp) { return (size_t)32 * cexp; }                      // K padded to 32: CEXP x 128 bytes
@@ -1670,7 +1690,9 @@ hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, in
     a.tiles_y = (OH + 3) / 4;
     const long long nb = (long long)a.tiles_x * a.tiles_y * B;
     if (nb <= 0 || nb > 0x7fffffffll) return hipErrorInvalidValue;
-    if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    if (cin == 32 && ir_hrx3_b6() == 48) hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 48, 64, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (cin == 32) hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 16, 64, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 48, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 16, 32, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     return hipGetLastError();
