@@ -291,25 +291,34 @@ __device__ __forceinline__ f32x2_t div2_in_range(f32x2_t a, f32x2_t b)
 // flight, where wave-uniform scalar loads made the wave wait out the scalar-cache latency on every trip
 // (rocprofv3: waves parked 35 % of their 15 k cycles in s_waitcnt, 12 waves per CU -- the kernel was bound by
 // per-wave latency x occupancy, not by its stores).
-__host__ __device__ inline int iou_rows_wave_floats(int G) { return ((64 * G + 4 + 3) & ~3) + 5 * ((G + 3) & ~3); }
+__host__ __device__ inline int iou_rows_wave_floats(int G, int rows = 64) { return ((rows * G + 4 + 3) & ~3) + 5 * ((G + 3) & ~3); }
 
 // RPN_IOU_PERSIST=1 (off by default: measured slower, 28.2 vs 26.6 us at C3) makes the waves walk several tiles.
-template <bool NT, int WAVES, bool FAST>
+// ROWS = 64: a lane owns one anchor and walks all G gt boxes.  ROWS = 32 (round 4): a wave's tile is 32 anchors, lane
+// = (anchor lane & 31, half lane >> 5) and each half walks its own run of the gt boxes ([0, Gh) | [Gh, G), Gh = G / 2 rounded
+// down to a multiple of 4; the two halves read their operands at two LDS addresses per wave, still a broadcast per 16-lane
+// read group).  Half the wave-private LDS tile (6.3 KB at G = 42: 24 instead of 12 resident waves per CU by LDS) and half the
+// per-wave latency: the kernel was bound by per-wave latency x occupancy (rocprofv3, round 2), not by its stores.
+template <bool NT, int WAVES, bool FAST, int ROWS = 64>
 __global__ void __launch_bounds__(64 * WAVES)
 iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt, int G,
                     float *__restrict__ out, int tiles_per_img, int n_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) float iou_tile[];       // WAVES x iou_rows_wave_floats(G)
+    static_assert(ROWS == 64 || ROWS == 32, "tile");
+    extern __shared__ __attribute__((aligned(16))) float iou_tile[];       // WAVES x iou_rows_wave_floats(G, ROWS)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int GP = (G + 3) & ~3;
-    float *wt = iou_tile + wave * iou_rows_wave_floats(G);
-    f32x4_t *gbox_t = reinterpret_cast<f32x4_t *>(wt + ((64 * G + 4 + 3) & ~3));       // [GP]
+    float *wt = iou_tile + wave * iou_rows_wave_floats(G, ROWS);
+    f32x4_t *gbox_t = reinterpret_cast<f32x4_t *>(wt + ((ROWS * G + 4 + 3) & ~3));     // [GP]
     float *garea_t = reinterpret_cast<float *>(gbox_t + GP);                            // [GP]
+    const int al = ROWS == 64 ? lane : (lane & 31);           // this lane's anchor inside the tile
+    const int Gh = ROWS == 64 ? G : ((G >> 1) & ~3);          // the gt run of this lane: [g_lo, g_hi)
+    const int g_lo = (ROWS == 64 || lane < 32) ? 0 : Gh, g_hi = (ROWS == 64 || lane >= 32) ? G : Gh;
     for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
     const int b = tile / tiles_per_img;
-    const int a_base = (tile - b * tiles_per_img) * 64;
-    const int rows = min(64, A - a_base);
-    const int a = min(a_base + lane, A - 1);                  // idle lanes recompute the last anchor, results unused
+    const int a_base = (tile - b * tiles_per_img) * ROWS;
+    const int rows = min(ROWS, A - a_base);
+    const int a = min(a_base + al, A - 1);                    // idle lanes recompute the last anchor, results unused
     const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
     const Box bb = load_box(bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a);
     if constexpr (FAST) {                                     // lane g stages gt box g and its area (G <= 64)
@@ -322,7 +331,7 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
     const float barea = box_area_plain(bb);                   // :139
     const long long s = ((long long)b * A + a_base) * G;      // first float of this wave's run
     const int q = (int)(s & 3);
-    float *row = wt + q + lane * G;
+    float *row = wt + q + al * G;
     bool exact_needed = !FAST;
     if constexpr (FAST) {
         constexpr unsigned kLo = 0x21800000u, kHi = 0x5D800000u;            // bits of 2^-60, 2^60
@@ -333,10 +342,10 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
         const f32x2_t barea2 = {barea, barea};
         // 4 gt boxes (two packed pairs = two independent dependency chains) per trip; the next trip's operands are
         // requested before this trip's arithmetic
-        const int G4 = G & ~3;
-        f32x4_t c0 = gbox_t[0], c1 = gbox_t[1], c2 = gbox_t[2], c3 = gbox_t[3];
-        f32x4_t ca = *reinterpret_cast<const f32x4_t *>(garea_t);
-        for (int g = 0; g < G4; g += 4) {
+        const int G4 = g_lo + ((g_hi - g_lo) & ~3);           // whole trips of this lane's run ([g_lo, g_hi), g_lo a multiple of 4)
+        f32x4_t c0 = gbox_t[g_lo], c1 = gbox_t[g_lo + 1], c2 = gbox_t[g_lo + 2], c3 = gbox_t[g_lo + 3];
+        f32x4_t ca = *reinterpret_cast<const f32x4_t *>(garea_t + g_lo);
+        for (int g = g_lo; g < G4; g += 4) {
             const int gn = g + 4 < GP ? g + 4 : g;            // (GP is a multiple of 4: in bounds; clamped on the last trip)
             const f32x4_t n0 = gbox_t[gn], n1 = gbox_t[gn + 1], n2 = gbox_t[gn + 2], n3 = gbox_t[gn + 3];
             const f32x4_t na = *reinterpret_cast<const f32x4_t *>(garea_t + gn);
@@ -349,18 +358,18 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
             row[g + 3] = r23.y;
             c0 = n0; c1 = n1; c2 = n2; c3 = n3; ca = na;
         }
-        if (G4 + 2 <= G) {                                     // c0.. hold gt G4 .. G4+3 (staged rows beyond G repeat G-1)
+        if (G4 + 2 <= g_hi) {                                  // c0.. hold gt G4 .. G4+3 (staged rows beyond G repeat G-1)
             f32x2_t r01;
             RPN_IOU_PAIR(c0, c1, ca[0], ca[1], r01, mn2, mx2);
             row[G4] = r01.x;
             row[G4 + 1] = r01.y;
-            if (G4 + 3 == G) {                                 // odd G: the last gt box alone, plain divide
-                const Box gg = load_box(gtb + 4 * (G - 1));
-                row[G - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+            if (G4 + 3 == g_hi) {                              // odd run: the last gt box alone, plain divide
+                const Box gg = load_box(gtb + 4 * (g_hi - 1));
+                row[g_hi - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
             }
-        } else if (G4 < G) {
-            const Box gg = load_box(gtb + 4 * (G - 1));
-            row[G - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
+        } else if (G4 < g_hi) {
+            const Box gg = load_box(gtb + 4 * (g_hi - 1));
+            row[g_hi - 1] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
         }
         const unsigned mn = min(min(mn2.x, mn2.y), min(mn2b.x, mn2b.y)), mx = max(max(mx2.x, mx2.y), max(mx2b.x, mx2b.y));
         exact_needed = __any(mn < kLo - 1u || mx > kHi) != 0;
@@ -368,18 +377,18 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
     if (exact_needed) {
         // 4 independent pairs per trip: one pair is a ~20-deep dependent chain (max/min, products, an IEEE divide) and a
         // wave alone issues a dependent instruction only every 4-8 cycles
-        int g = 0;
-        for (; g + 4 <= G; g += 4) {
+        int g = g_lo;
+        for (; g + 4 <= g_hi; g += 4) {
             float r4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const Box gg = load_box(gtb + 4 * (g + j));       // wave-uniform address
+                const Box gg = load_box(gtb + 4 * (g + j));       // wave-uniform address (per half)
                 r4[j] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) row[g + j] = r4[j];
         }
-        for (; g < G; ++g) {
+        for (; g < g_hi; ++g) {
             const Box gg = load_box(gtb + 4 * g);
             row[g] = iou_map_pair(bb, barea, gg, box_area_plain(gg));
         }
@@ -576,11 +585,14 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
     static const int nt = RPN_LAB_KNOB("RPN_IOU_NT", 1);
     static const int rowsk = RPN_LAB_KNOB("RPN_IOU_ROWS", 1);
     const int g32 = (G % 4 == 0) ? 4 : (G % 2 == 0 ? 2 : 1);          // >= gcd(G, 32) capped at 4
-    const size_t wave_lds = (size_t)iou_rows_wave_floats(G) * sizeof(float);
-    if (rowsk && G >= 1 && g32 <= 2 && wave_lds <= 12 * 1024 && A >= 64) {
+    static const int half_rows = RPN_LAB_KNOB("RPN_IOU_HALF", 0);   // 32-anchor tiles, the gt run split over the wave's halves
+    const bool half = half_rows && G >= 16;
+    const int tile_rows = half ? 32 : 64;
+    const size_t wave_lds = (size_t)iou_rows_wave_floats(G, tile_rows) * sizeof(float);
+    if (rowsk && G >= 1 && g32 <= 2 && (size_t)iou_rows_wave_floats(G) * sizeof(float) <= 12 * 1024 && A >= 64) {
         // one tile (64 anchors x G) per wave, 4 waves per workgroup (single-wave workgroups measured 30.4 vs 26.5 us at C3).
         // RPN_IOU_PERSIST=1: as many workgroups as stay resident, every wave walking the same number of tiles
-        const int tiles_per_img = (A + 63) / 64;
+        const int tiles_per_img = (A + tile_rows - 1) / tile_rows;
         const long long n_tiles = (long long)tiles_per_img * B;
         RPN_REQUIRE(n_tiles <= 0x7fffffffll, "rpn_iou_map: too many tiles");
         static const int persist = RPN_LAB_KNOB("RPN_IOU_PERSIST", 0);
@@ -597,10 +609,12 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
         }
         const dim3 grid((unsigned)wgs);
         const int nt_i = (int)n_tiles;
-#define RPN_IOU_ROWS(NT_, W_, FAST_)                                                                                  \
-    hipLaunchKernelGGL((iou_map_rows_kernel<NT_, W_, FAST_>), grid, dim3(64 * W_), W_ * wave_lds, as_stream(stream), d_bboxes, \
+#define RPN_IOU_ROWS(NT_, W_, FAST_, ...)                                                                             \
+    hipLaunchKernelGGL((iou_map_rows_kernel<NT_, W_, FAST_, ##__VA_ARGS__>), grid, dim3(64 * W_), W_ * wave_lds, as_stream(stream), d_bboxes, \
                        bboxes_batched, A, d_gt, G, d_iou, tiles_per_img, nt_i)
-        if (!nt_rows()) RPN_IOU_ROWS(false, 4, true);
+        if (half && nt_rows() && fast && W == 4) RPN_IOU_ROWS(true, 4, true, 32);
+        else if (half) return rpn::fail(RPN_ERR_INVALID, "rpn_iou_map: RPN_IOU_HALF needs the default row-kernel settings");
+        else if (!nt_rows()) RPN_IOU_ROWS(false, 4, true);
         else if (!fast) RPN_IOU_ROWS(true, 4, false);
         else if (W == 2) RPN_IOU_ROWS(true, 2, true);
         else RPN_IOU_ROWS(true, 4, true);

@@ -45,6 +45,8 @@ struct ConvArgs {
     int out_split;          // 0: float32 NHWC; 1 / 2: `out` is SPLIT16 with bfloat16 / float16 halves (needs Cout % 32 == 0,
                             // a single output, no residual): the consumer is a split-precision 3x3 conv
     unsigned *status;       // float16 range flag (out_split == 2), or null
+    int pool;               // 1: `out` is the layer's output after MaxPooling2D(2, 2) 'valid', (B, OH/2, OW/2, ld1), pooled in the
+                            // epilogue (needs a single float32 output, no residual, a monotone activation)
 };
 
 // dense convolution as an implicit GEMM on the f32 MFMA; returns hipGetLastError()

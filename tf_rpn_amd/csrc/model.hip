@@ -162,6 +162,17 @@ static bool is_pw_x3(const rpn_model *m, const Op &op)
            (RPN_KNOB("RPN_MN_X3", 1) != 0);
 }
 
+// Float32 graph: a float32 implicit-GEMM conv directly followed by its 2 x 2 max-pool (VGG16 block*_pool) runs as ONE kernel,
+// the pool inside the conv's epilogue (ConvArgs::pool; same bits as the separate pool kernel), unless every activation must be
+// kept.  True for op i = the conv; op i + 1 is then the pool that does not launch.
+static bool f32_pool_fused(const rpn_model *m, size_t i)
+{
+    if (m->keep_all || i + 1 >= m->ops.size()) return false;
+    const Op &op = m->ops[i], &nx = m->ops[i + 1];
+    return op.kind == OP_CONV && !op.split && !op.cin3 && !op.f32_out_split && op.residual < 0 && op.act != ACT_SIGMOID &&
+           nx.kind == OP_POOL && !nx.split && nx.in == op.out && (RPN_LAB_KNOB("RPN_F32_POOLFUSE", 1) != 0);
+}
+
 // dense conv op; returns the output tensor id
 static int add_conv(rpn_model *m, const std::string &name, const std::string &bn, int in, int Cout, int R,
                     int stride, int pad_t, int pad_l, int OH, int OW, int act, int residual = -1,
@@ -446,6 +457,7 @@ static void plan_arena(rpn_model *m)
             const Op &op = m->ops[i], &nx = m->ops[i + 1];
             if (op.kind == OP_CONV && op.split && !op.out_f32 && nx.kind == OP_POOL && nx.split && nx.in == op.out)
                 m->tensors[nx.out].def = (int)i;
+            if (f32_pool_fused(m, i)) m->tensors[nx.out].def = (int)i;      // (the float32 graph's fused pools likewise)
         }
     size_t top = 0;
     std::vector<int> placed;
@@ -961,10 +973,13 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 a.out = d_reg; a.ld1 = 4 * m->K; a.act = ACT_LINEAR; a.split = 4 * m->K;
                 a.out2 = d_cls; a.ld2 = m->K; a.act2 = ACT_SIGMOID;
             } else {
-                a.out = tensor_ptr(m, op.out, d_imgs); a.ld1 = op.Cout; a.act = op.act; a.split = op.Cout;
+                const bool pool = f32_pool_fused(m, oi);                // + block*_pool in the epilogue: writes the pool's tensor
+                a.out = tensor_ptr(m, pool ? m->ops[oi + 1].out : op.out, d_imgs); a.ld1 = op.Cout; a.act = op.act; a.split = op.Cout;
                 a.out2 = nullptr; a.ld2 = 0; a.act2 = ACT_LINEAR;
                 a.out_split = op.f32_out_split ? (m->f16 ? 2 : 1) : 0;
                 a.status = op.f32_out_split && m->f16 ? m->d_status : nullptr;
+                a.pool = pool ? 1 : 0;
+                skip_next = pool;
             }
             e = launch_conv_f32(a, s);
         } else if (op.kind == OP_VGGB1) {
@@ -1067,6 +1082,8 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         k = "f32_to_split";
     } else if (pool_fused_away) {
         k = "fused:maxpool_split";
+    } else if (op.kind == OP_POOL && i > 0 && f32_pool_fused(m, (size_t)i - 1)) {
+        k = "fused:maxpool_f32";                   // runs inside the previous float32 conv's epilogue: no launch, no bytes of its own
     } else if (op.kind == OP_POOL && op.split) {
         by = in_b + out_b;
         k = "maxpool_split";
