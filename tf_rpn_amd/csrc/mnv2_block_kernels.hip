@@ -1260,6 +1260,340 @@ ir_block_x3_kernel(IrX3Args a)
 #endif
 }
 
+// (LABORATORY BUILD ONLY, -DRPN_LAB, RPN_MN_X3W=1: measured NOT faster -- blocks 7-9 17.5 -> 17.8 us at batch 8, 12.4 -> 11.5 us
+// at one image; the 96-channel variants spill at the 128-register budget of 1024 threads and run 2x slower; blocks 4-5 lose
+// residency (two workgroups per CU instead of four).  The step is not per-wave latency after all: ~820 of its ~1.9 k cycles
+// are LDS-pipe occupancy (weight staging writes + every matrix wave re-reading the chunk's We) and ~420 VMEM issue, both
+// per CU and unchanged by the wave count.  See NOTES.md.)
+#ifdef RPN_LAB
+// ---- the same block on SIXTEEN waves (round 4) ----------------------------------------------------------------------------
+// The idea: ir_block_x3_kernel's steps are latency, not throughput: in-kernel stamps at batch 8 (scripts/ir_stamp_probe.py) show
+// ~1.9 k cycles per chunk with the matrix pipe 6-10 % busy -- E is one M-block x 2 N-blocks per wave (12-18 dependent MFMAs,
+// 8 epilogue stores), D four output pixels per lane (18 window reads, 36 FMAs, 4 conversions and stores), each a chain of
+// LDS / vector round trips on ONE wave per SIMD and group.  Here the same tile, the same LDS images and the same products in
+// the same order (bit-identical results) run on eight matrix + eight service waves: E = one (M-block, N-block) per wave, P =
+// one (M-block, N-block quarter) per wave, D = two output pixels per lane; weight staging spread over 512 threads.
+template <int KP, int CEXP, int COUT, bool RES>
+__global__ void __launch_bounds__(2 * IR_THREADS)
+ir_block_x3w_kernel(IrX3Args a)
+{
+    constexpr int S = 1, CE = 32, G = 8, THREADS = 2 * IR_THREADS;        // matrix waves 0 .. G-1, service waves G .. 2G-1
+    constexpr int IH = IR_TH + 2, IW = IR_TW + 2, NH = IH * IW;           // 6 x 10 halo pixels
+    constexpr int MB = 4, MH = 64;
+    constexpr int KS = KP / 32;
+    constexpr int NBE = CE / 16, NCHUNK = CEXP / CE;
+    constexpr int SEP = CE + 4;
+    constexpr int NBO = COUT / 16, NJ = (NBO + 3) / 4;                    // projection N-blocks; per wave (nb = nbq + 4 j)
+    constexpr int WE_P = NBE * KS * 2 * 64, WP_P = NBO * 2 * 64;
+    constexpr int SW = 64 * G;                                            // staging threads (the matrix waves)
+    constexpr int NWE = (WE_P + SW - 1) / SW, NWP = (WP_P + SW - 1) / SW;
+    static_assert(KP % 32 == 0 && CEXP % CE == 0 && COUT % 32 == 0 && (!RES || KP == COUT) && NBE == 2, "shape");
+
+    __shared__ u32x4 XsF[MB * KS * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float Es[2][MH * SEP];
+    __shared__ u32x4 DsF[2][2 * 2 * 64];
+    __shared__ u32x4 WeS[2][WE_P];
+    __shared__ u32x4 WpS[2][WP_P];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int stid = tid;
+    constexpr int LEAF = NCHUNK / 6;                                      // (the projection tree: see ir_block_x3_kernel)
+    static_assert(NCHUNK % 6 == 0, "the projection tree has six leaves");
+    const int ksplit = a.ksplit;
+    const int tile = (int)blockIdx.x / ksplit, part_h = (int)blockIdx.x - tile * ksplit;
+    const int nch = ksplit == 2 ? (part_h == 0 ? 4 * LEAF : 2 * LEAF) : NCHUNK / ksplit;
+    const int c0 = ksplit == 2 ? part_h * 4 * LEAF : part_h * nch;
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int img = t / a.tiles_y;
+    const int oy0 = ty * IR_TH, ox0 = tx * IR_TW;
+    const int gy0 = oy0 - 1, gx0 = ox0 - 1;
+    IR_STAMP(0, 0);
+    IR_STAMP_RT(0, 104);
+    if (wave >= G) __builtin_amdgcn_s_setprio(2);
+
+    u32x4 we_st[NWE], wp_st[NWP];
+    auto we_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i)
+            if (WE_P % SW == 0 || stid + SW * i < WE_P) we_st[i] = a.we[(size_t)c * WE_P + stid + SW * i];
+    };
+    auto we_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWE; ++i)
+            if (WE_P % SW == 0 || stid + SW * i < WE_P) WeS[slot][stid + SW * i] = we_st[i];
+    };
+    auto wp_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            if (WP_P % SW == 0 || stid + SW * i < WP_P) wp_st[i] = a.wp[(size_t)c * WP_P + stid + SW * i];
+    };
+    auto wp_store = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            if (WP_P % SW == 0 || stid + SW * i < WP_P) WpS[slot][stid + SW * i] = wp_st[i];
+    };
+    // depthwise: lane = (channel dn, pixel pair): service wave sw -> output row sw / 2, pixels 2 * ((sw & 1) * 2 + lane / 32) + {0, 1}
+    constexpr int PXG = 2;
+    const int dn = lane & 31;
+    const int dpy = (wave - G) >> 1, dx0 = ((((wave - G) & 1) << 1) | (lane >> 5)) * PXG;
+    float wd_cur[10], wd_nxt[10];
+    auto wd_fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
+        wd_nxt[9] = a.bd[c * CE + dn];
+    };
+    if (wave < G) we_fetch(c0);
+
+    // ---- 1. input tile: float32 NHWC -> hi / lo float16, fragment-major (swizzled slots: frag_slot) ------------------------
+    {
+        constexpr int CQ = KP / 4;
+        const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * KP;
+        _Float16 *xh = reinterpret_cast<_Float16 *>(XsF);
+        for (int idx = tid; idx < MH * CQ; idx += THREADS) {
+            const int m = idx / CQ, cq = idx - m * CQ;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const float4 *>(xin + ((size_t)gy * a.W + gx) * KP + 4 * cq);
+            if (a.status && !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65504.0f))
+                atomicOr(a.status, 1u);
+            const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const f16x4 lo = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                              (_Float16)(v.w - (float)hi[3])};
+            const int ch0 = 4 * cq, ks = ch0 >> 5, kq = (ch0 >> 3) & 3, j0 = ch0 & 7;
+            const int blk = ((m >> 4) * KS + ks) * 2;
+            const int off = (frag_slot(kq, m & 15, ks & 1) * 8 + j0);
+            *reinterpret_cast<f16x4 *>(xh + (size_t)blk * 512 + off) = hi;
+            *reinterpret_cast<f16x4 *>(xh + (size_t)(blk + 1) * 512 + off) = lo;
+        }
+    }
+    // matrix wave w: E on (M-block emb, N-block enb); P on M-block mbp, N-blocks nbq + 4 j
+    const int emb = wave & 3, enb = (wave >> 2) & 1;
+    const int mbp = wave & 1, nbq = (wave >> 1) & 3;
+    float vmul[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave < G) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = emb * 16 + 4 * lk + i;
+            const int hy = m / IW, hx = m - hy * IW;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            vmul[i] = (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.0f : 0.0f;
+        }
+        we_store(0);
+        if (nch > 1) we_fetch(c0 + 1);
+    }
+    __syncthreads();
+    IR_STAMP(0, 1);
+
+    f32x4 pacc[NJ], ppair[NJ], ptot[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) pacc[j] = ppair[j] = ptot[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias_nxt = a.be[c0 * CE + enb * 16 + lr];
+
+    for (int it = 0; it < nch + 2; ++it) {
+        if (wave < G) {
+            if (it + 1 < nch) we_store((it + 1) & 1);
+            if (it >= 1 && it <= nch) wp_store((it - 1) & 1);
+            const float biasv = bias_nxt;
+            if (it + 1 < nch) bias_nxt = a.be[(c0 + it + 1) * CE + enb * 16 + lr];
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < nch) we_fetch(c0 + it + 2);
+            if (it < nch) wp_fetch(c0 + it);
+            u32x4 dhi, dlo, pb[NJ][2];
+            if (it >= 2) {
+                const u32x4 *dsf = DsF[it & 1];
+                const u32x4 *wps = WpS[it & 1];
+                dhi = dsf[(mbp * 2 + 0) * 64 + frag_lane(lane, 0)];
+                dlo = dsf[(mbp * 2 + 1) * 64 + frag_lane(lane, 1)];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int nb = nbq + 4 * j;
+                    if (NBO % 4 == 0 || nb < NBO) {
+                        pb[j][0] = wps[(nb * 2 + 0) * 64 + lane];
+                        pb[j][1] = wps[(nb * 2 + 1) * 64 + lane];
+                    }
+                }
+            }
+            if (it < nch) {
+                // ---- E(it): (M-block emb) x (N-block enb) x KS k-steps x 3 MFMAs ----------------------------------------
+                const u32x4 *wes = WeS[it & 1];
+                u32x4 xa[KS][2], wb[KS][2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    xa[ks][0] = XsF[((emb * KS + ks) * 2 + 0) * 64 + frag_lane(lane, ks & 1)];
+                    xa[ks][1] = XsF[((emb * KS + ks) * 2 + 1) * 64 + frag_lane(lane, ks & 1)];
+                    wb[ks][0] = wes[((enb * KS + ks) * 2 + 0) * 64 + lane];
+                    wb[ks][1] = wes[((enb * KS + ks) * 2 + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 eacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) eacc = mfma_x3(xa[ks][0], xa[ks][1], wb[ks][0], wb[ks][1], eacc);
+                float *es = Es[it & 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    es[(emb * 16 + 4 * lk + i) * SEP + enb * 16 + lr] = relu6f(eacc[i] * a.scale_e + biasv) * vmul[i];
+            }
+            IR_STAMP(0, 2 + 4 * it);
+            if (it >= 2) {
+                // ---- P(it-2) ----------------------------------------------------------------------------------------------
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (NBO % 4 == 0 || nbq + 4 * j < NBO) pacc[j] = mfma_x3(dhi, dlo, pb[j][0], pb[j][1], pacc[j]);
+                const int cg = c0 + it - 2;
+                if ((cg + 1) % LEAF == 0) {
+                    const int leaf = cg / LEAF;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        ppair[j] = ((leaf & 1) && ksplit != 6) ? ppair[j] + pacc[j] : pacc[j];
+                        if (leaf & 1) ptot[j] = leaf == 1 ? ppair[j] : ptot[j] + ppair[j];
+                        pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            IR_STAMP(0, 3 + 4 * it);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < nch) wd_fetch(c0 + it);
+            if (it >= 1 && it <= nch) {
+                // ---- D(it-1): two output pixels per lane --------------------------------------------------------------------
+                const int c = it - 1;
+                const float *es = Es[c & 1] + dn;
+                constexpr int WW = (PXG - 1) * S + 3;
+                float win[3][WW];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < WW; ++x) win[r][x] = es[((dpy * S + r) * IW + dx0 * S + x) * SEP];
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned *dw32 = reinterpret_cast<unsigned *>(DsF[c & 1]);
+                const int kq = dn >> 3, jp = (dn & 7) >> 1, odd = dn & 1;
+#pragma unroll
+                for (int px = 0; px < PXG; ++px) {
+                    float acc = wd_cur[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc = fmaf(win[r][px * S + q], wd_cur[r * 3 + q], acc);
+                    const float v = relu6f(acc);
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const unsigned hu = __builtin_bit_cast(unsigned short, h), lu = __builtin_bit_cast(unsigned short, l);
+                    const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
+                    const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
+                    const int p = dpy * IR_TW + dx0 + px;
+                    const int blk = (p >> 4) * 2 + odd;
+                    dw32[blk * 256 + frag_slot(kq, p & 15, odd) * 4 + jp] = word;
+                }
+            }
+            IR_STAMP(G, 4 + 4 * it);
+        }
+        __syncthreads();
+        IR_STAMP(0, 5 + 4 * it);
+    }
+
+    // epilogue operands in front of the seam (see ir_block_x3_kernel)
+    float obias[NJ], ores[NJ][4];
+    if (wave < G) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nb = nbq + 4 * j;
+            const int co = (nb < NBO ? nb : 0) * 16 + lr;
+            obias[j] = a.bp[co];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = mbp * 16 + 4 * lk + i;
+                const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
+                ores[j][i] = 0.0f;
+                if constexpr (RES)
+                    if (oy < a.H && ox < a.W) ores[j][i] = a.x[(((size_t)img * a.H + oy) * a.W + ox) * KP + co];
+            }
+        }
+    }
+    if (ksplit > 1) {
+        // K-split seam: 16-byte sc1 slab stores / loads in accumulator layout (see ir_block_x3_kernel); slab slot of the
+        // accumulator of (N-block nb, M-block mbp) = nb * 2 + mbp
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            a.part + (size_t)tile * ksplit * (32 * COUT), (short)0, ksplit * 32 * COUT * 4, 0x00020000);
+        constexpr int kSc1 = 16;
+        IR_STAMP(0, 100);
+        if (wave < G) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = nbq + 4 * j;
+                if (NBO % 4 == 0 || nb < NBO) {
+                    const f32x4 v = (ksplit == 2 && part_h == 0) ? ptot[j] : ppair[j];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs,
+                                                           (part_h * 32 * COUT + ((nb * 2 + mbp) * 64 + lane) * 4) * 4, 0, kSc1);
+                }
+            }
+        }
+        __shared__ unsigned last_flag;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)ksplit - 1u ? 1u : 0u;
+            if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = last;
+        }
+        __syncthreads();
+        IR_STAMP(0, 101);
+        IR_STAMP_RT(0, 105);
+        if (last_flag == 0u) return;
+        if (wave < G) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = nbq + 4 * j;
+                if (NBO % 4 == 0 || nb < NBO) {
+                    f32x4 q[6];
+#pragma unroll
+                    for (int h = 0; h < 6; ++h)
+                        q[h] = h < ksplit ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                prs, (h * 32 * COUT + ((nb * 2 + mbp) * 64 + lane) * 4) * 4, 0, kSc1))
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+                    ptot[j] = ksplit == 2 ? q[0] + q[1]
+                                          : (ksplit == 3 ? (q[0] + q[1]) + q[2] : ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]));
+                }
+            }
+        }
+    }
+    IR_STAMP(0, 102);
+    if (wave < G) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nb = nbq + 4 * j;
+            if (!(NBO % 4 == 0 || nb < NBO)) continue;
+            const int co = nb * 16 + lr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = mbp * 16 + 4 * lk + i;
+                const int oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
+                if (oy < a.H && ox < a.W) {
+                    const size_t pix = ((size_t)img * a.H + oy) * a.W + ox;
+                    float v = ptot[j][i] * a.scale_p + obias[j];
+                    if constexpr (RES) v += ores[j][i];
+                    a.out[pix * COUT + co] = v;
+                }
+            }
+        }
+    }
+#ifdef RPN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IR_STAMP(0, 103);
+    IR_STAMP_RT(0, 105);
+#endif
+}
+
+#endif   // RPN_LAB
+
 // ---- pointwise conv (1 x 1, stride 1) + bias + ReLU6 on the 16-bit MFMA, float32 NHWC in -> SPLIT16 out ------------------
 // block_13_expand (96 -> 576, models/rpn_mobilenet_v2.py:17: the tap layer that feeds rpn_conv) under f16x3: the expand
 // GEMM of ir_block_x3_kernel on its own (hi + lo float16 operands, lo*hi + hi*lo + hi*hi per product, float32 accumulation),
@@ -1788,6 +2122,16 @@ hipError_t launch_ir_block_x3(const float *x, int B, int H, int W, int cin, int 
         const char *nth = getenv("RPN_IR_STAMP_NTH");
         int sn = 0, sk = 1;
         if (a.stamp && nth && sscanf(nth, "%d,%d", &sn, &sk) == 2 && sk > 0) a.stamp = (matches++ % sk) == sn;
+    }
+#endif
+#ifdef RPN_LAB
+    static const int wide = RPN_LAB_KNOB("RPN_MN_X3W", 0);        // 1: the sixteen-wave form (same bits, measured not faster)
+    if (wide) {
+        if (cin == 32) hipLaunchKernelGGL((ir_block_x3w_kernel<32, 192, 32, true>), dim3((unsigned)nblocks), dim3(2 * IR_THREADS), 0, s, a);
+        else if (cin == 64 && cout == 64) hipLaunchKernelGGL((ir_block_x3w_kernel<64, 384, 64, true>), dim3((unsigned)nblocks), dim3(2 * IR_THREADS), 0, s, a);
+        else if (cin == 64) hipLaunchKernelGGL((ir_block_x3w_kernel<64, 384, 96, false>), dim3((unsigned)nblocks), dim3(2 * IR_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((ir_block_x3w_kernel<96, 576, 96, true>), dim3((unsigned)nblocks), dim3(2 * IR_THREADS), 0, s, a);
+        return hipGetLastError();
     }
 #endif
     if (cin == 32) hipLaunchKernelGGL((ir_block_x3_kernel<32, 192, 32, true>), dim3((unsigned)nblocks), dim3(IR_THREADS), 0, s, a);
