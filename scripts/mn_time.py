@@ -19,7 +19,7 @@ out = []
 for tag, hp, B in (("c1", hp_mn, 1), ("c5", hp_c5, 1), ("b8", hp_mn, 8)):
     if only and tag not in only: continue
     w = synthetic_weights("mobilenet_v2", hp, seed=1)
-    prop = Proposer("mobilenet_v2", hyper_params=hp, weights=w, precision="f16x3", max_batch=B, iou_threshold=0.7, overlap_nms=True)
+    prop = Proposer("mobilenet_v2", hyper_params=hp, weights=w, precision="f16x3", max_batch=B, iou_threshold=0.7, overlap_nms=True, check_range="--no-check" not in sys.argv)
     x = torch.rand((B, hp["img_size"], hp["img_size"], 3), device="cuda")
     best = None
     for rep in range(3):

@@ -88,6 +88,9 @@ hipError_t launch_ir_block(const float *x, int B, int H, int W, int cin, int cex
 bool ir_block_x3_supported(int cin, int cexp, int cout, int stride, bool residual);
 void pack_ir_x3_expand(const float *w, int K, int CEXP, int shift, unsigned short *dst);
 void pack_ir_x3_project(const float *w, int CEXP, int COUT, int shift, unsigned short *dst);
+// depthwise weights [9][cexp] + bias [cexp] -> one 48-byte record per channel (what `wd` of launch_ir_block_x3 points to; `bd` unused)
+size_t ir_x3_dw_floats(int cexp);
+void pack_ir_x3_dw(const float *wd, const float *bd, int cexp, float *dst);
 // scratch: ir_block_x3_scratch_floats() zero-initialised floats (partials + tickets of the K-split used on small grids), or
 // null = never split.  The kernel leaves the tickets at zero.
 size_t ir_block_x3_scratch_floats();

@@ -979,10 +979,15 @@ ir_block_x3_kernel(IrX3Args a)
     constexpr int PG = 2, PXG = IR_TW / PG;                              // depthwise: lane = (channel dn, pixel group dg)
     const int dn = lane & 31, dg = lane >> 5;
     float wd_cur[10], wd_nxt[10];
+    // depthwise weights of a chunk: ONE 48-byte record per channel -- 9 taps, the bias, 2 floats of padding (pack_ir_x3_dw) --
+    // = three 16-byte loads per lane and step (ten 4-byte loads from the [9][CEXP] matrix + bias cost 13 % of blocks 4, 5, 7-9:
+    // their ISSUE, ~660 cycles at the head of every step beside the matrix waves' weight requests)
     auto wd_fetch = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
-        wd_nxt[9] = a.bd[c * CE + dn];
+        const float4 *rec = reinterpret_cast<const float4 *>(a.wd) + ((size_t)c * CE + dn) * 3;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        wd_nxt[0] = q0.x; wd_nxt[1] = q0.y; wd_nxt[2] = q0.z; wd_nxt[3] = q0.w;
+        wd_nxt[4] = q1.x; wd_nxt[5] = q1.y; wd_nxt[6] = q1.z; wd_nxt[7] = q1.w;
+        wd_nxt[8] = q2.x; wd_nxt[9] = q2.y;
     };
     if (wave < 4) we_fetch(c0);
 
@@ -1010,27 +1015,42 @@ ir_block_x3_kernel(IrX3Args a)
             *reinterpret_cast<f16x4 *>(xh + (size_t)(blk + 1) * 512 + off) = lo;
         }
     }
-    float vmul[4] = {0.f, 0.f, 0.f, 0.f};          // 1 where this lane's expand output (row 4 lk + i) is a pixel of the image, else 0
+    // E mapping: matrix wave w owns the M-block PAIR emp = w & 1 (halo rows 32 emp .. 32 emp + 31) and the N-block enb = w >> 1 of
+    // every chunk.  Its A fragments (the input tile: constant over the chunks) are read from LDS ONCE, below, and stay in
+    // registers; per step it reads only its N-block's weight fragments (2 KS ds_read_b128 instead of 6 KS when a wave owned one
+    // M-block and both N-blocks: the LDS pipe, shared by the CU's eight waves, is what a step waits for -- NOTES.md, round 4).
+    const int emp = wave & 1, enb = (wave >> 1) & 1;
+    float vmul[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 1 where this lane's expand output (M-block 2 emp + h, row 4 lk + i) is a pixel of the image
     if (wave < 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = wave * 16 + 4 * lk + i;
-            const int hy = m / IW, hx = m - hy * IW;
-            const int gy = gy0 + hy, gx = gx0 + hx;
-            vmul[i] = (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.0f : 0.0f;
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (2 * emp + h) * 16 + 4 * lk + i;
+                const int hy = m / IW, hx = m - hy * IW;
+                const int gy = gy0 + hy, gx = gx0 + hx;
+                vmul[4 * h + i] = (m < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.0f : 0.0f;
+            }
         we_store(0);
         if (nch > 1) we_fetch(c0 + 1);                       // put in place at the start of step 0
     }
     __syncthreads();
     IR_STAMP(0, 1);
+    u32x4 xa[2][KS][2];                                      // [M-block of the pair][k-step][hi | lo]
+    if (wave < 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xa[h][ks][0] = XsF[(((2 * emp + h) * KS + ks) * 2 + 0) * 64 + frag_lane(lane, ks & 1)];
+                xa[h][ks][1] = XsF[(((2 * emp + h) * KS + ks) * 2 + 1) * 64 + frag_lane(lane, ks & 1)];
+            }
+    }
 
     f32x4 pacc[NJ], ppair[NJ], ptot[NJ];                     // the current leaf; the current pair of leaves; the tree so far
 #pragma unroll
     for (int j = 0; j < NJ; ++j) pacc[j] = ppair[j] = ptot[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bias_nxt[NBE];
-#pragma unroll
-    for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[c0 * CE + nb * 16 + lr];
+    float bias_nxt = a.be[c0 * CE + enb * 16 + lr];
     const int mbp = wave & 1, nbp = (wave >> 1) & 1;
 
     for (int it = 0; it < nch + 2; ++it) {
@@ -1038,21 +1058,20 @@ ir_block_x3_kernel(IrX3Args a)
             // Weight staging, one step ahead of its use and one step behind its loads: what was requested at the start of
             // the previous step (We(it+1), Wp(it-1)) has had a whole step to arrive and is put in place now, then the next
             // requests go out.  Done by the matrix waves: on the 16-bit MFMA their step is shorter than the service waves'.
+#ifndef RPN_EXP_X3_NOFETCH       /* timing experiment only (results are wrong): no weight traffic inside the chunk loop */
             if (it + 1 < nch) we_store((it + 1) & 1);
             if (it >= 1 && it <= nch) wp_store((it - 1) & 1);
+#endif
             // the expand bias of the NEXT chunk is requested BEFORE the weight fragments: vmcnt retires loads in order, and
             // the register copy that hands it to the next step sits at the end of E -- behind the weight requests it would
             // wait for all of them (measured: +1.1 k cycles per step)
-            float biasv[NBE];
-#pragma unroll
-            for (int nb = 0; nb < NBE; ++nb) biasv[nb] = bias_nxt[nb];
-            if (it + 1 < nch) {
-#pragma unroll
-                for (int nb = 0; nb < NBE; ++nb) bias_nxt[nb] = a.be[(c0 + it + 1) * CE + nb * 16 + lr];
-            }
+            const float biasv = bias_nxt;
+            if (it + 1 < nch) bias_nxt = a.be[(c0 + it + 1) * CE + enb * 16 + lr];
             __builtin_amdgcn_sched_barrier(0);
+#ifndef RPN_EXP_X3_NOFETCH
             if (it + 2 < nch) we_fetch(c0 + it + 2);
             if (it < nch) wp_fetch(c0 + it);
+#endif
             // operands of P(it-2) first: they are ready when the step starts, and their LDS latency then hides behind E
             u32x4 dhi, dlo, pb[NJ][2];
             if (it >= 2) {
@@ -1068,34 +1087,29 @@ ir_block_x3_kernel(IrX3Args a)
                 }
             }
             if (it < nch) {
-                // ---- E(it): one M-block (16 halo pixels) x 2 N-blocks x KS k-steps x 3 MFMAs ---------------------------
+                // ---- E(it): two M-blocks (32 halo pixels) x one N-block x KS k-steps x 3 MFMAs ------------------------
                 const u32x4 *wes = WeS[it & 1];
-                u32x4 xa[KS][2], wb[KS][NBE][2];
+                u32x4 wb[KS][2];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    xa[ks][0] = XsF[((wave * KS + ks) * 2 + 0) * 64 + frag_lane(lane, ks & 1)];
-                    xa[ks][1] = XsF[((wave * KS + ks) * 2 + 1) * 64 + frag_lane(lane, ks & 1)];
-#pragma unroll
-                    for (int nb = 0; nb < NBE; ++nb) {
-                        wb[ks][nb][0] = wes[((nb * KS + ks) * 2 + 0) * 64 + lane];
-                        wb[ks][nb][1] = wes[((nb * KS + ks) * 2 + 1) * 64 + lane];
-                    }
+                    wb[ks][0] = wes[((enb * KS + ks) * 2 + 0) * 64 + lane];
+                    wb[ks][1] = wes[((enb * KS + ks) * 2 + 1) * 64 + lane];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 eacc[NBE];
+                f32x4 eacc[2];
 #pragma unroll
-                for (int nb = 0; nb < NBE; ++nb) eacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int h = 0; h < 2; ++h) eacc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int nb = 0; nb < NBE; ++nb) eacc[nb] = mfma_x3(xa[ks][0], xa[ks][1], wb[ks][nb][0], wb[ks][nb][1], eacc[nb]);
+                    for (int h = 0; h < 2; ++h) eacc[h] = mfma_x3(xa[h][ks][0], xa[h][ks][1], wb[ks][0], wb[ks][1], eacc[h]);
                 float *es = Es[it & 1];
 #pragma unroll
-                for (int nb = 0; nb < NBE; ++nb)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        es[(wave * 16 + 4 * lk + i) * SEP + nb * 16 + lr] =        // (* 1 or * 0: ReLU6's output is finite and >= 0)
-                            relu6f(eacc[nb][i] * a.scale_e + biasv[nb]) * vmul[i];
+                        es[((2 * emp + h) * 16 + 4 * lk + i) * SEP + enb * 16 + lr] =   // (* 1 or * 0: ReLU6's output is finite and >= 0)
+                            relu6f(eacc[h][i] * a.scale_e + biasv) * vmul[4 * h + i];
             }
             IR_STAMP(0, 2 + 4 * it);
             if (it >= 2) {
@@ -1122,7 +1136,9 @@ ir_block_x3_kernel(IrX3Args a)
             for (int k = 0; k < 10; ++k) wd_cur[k] = wd_nxt[k];
             IR_STAMP(4, 66 + 4 * it);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef RPN_EXP_X3_NOWD
             if (it < nch) wd_fetch(c0 + it);
+#endif
             IR_STAMP(4, 65 + 4 * it);
             if (it >= 1 && it <= nch) {
                 // ---- D(it-1): depthwise 3x3 + bias + ReLU6, then hi / lo float16 into P's A-operand image ----------------
@@ -1341,10 +1357,15 @@ ir_block_x3w_kernel(IrX3Args a)
     const int dn = lane & 31;
     const int dpy = (wave - G) >> 1, dx0 = ((((wave - G) & 1) << 1) | (lane >> 5)) * PXG;
     float wd_cur[10], wd_nxt[10];
+    // depthwise weights of a chunk: ONE 48-byte record per channel -- 9 taps, the bias, 2 floats of padding (pack_ir_x3_dw) --
+    // = three 16-byte loads per lane and step (ten 4-byte loads from the [9][CEXP] matrix + bias cost 13 % of blocks 4, 5, 7-9:
+    // their ISSUE, ~660 cycles at the head of every step beside the matrix waves' weight requests)
     auto wd_fetch = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wd_nxt[k] = a.wd[(size_t)k * CEXP + c * CE + dn];
-        wd_nxt[9] = a.bd[c * CE + dn];
+        const float4 *rec = reinterpret_cast<const float4 *>(a.wd) + ((size_t)c * CE + dn) * 3;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        wd_nxt[0] = q0.x; wd_nxt[1] = q0.y; wd_nxt[2] = q0.z; wd_nxt[3] = q0.w;
+        wd_nxt[4] = q1.x; wd_nxt[5] = q1.y; wd_nxt[6] = q1.z; wd_nxt[7] = q1.w;
+        wd_nxt[8] = q2.x; wd_nxt[9] = q2.y;
     };
     if (wave < G) we_fetch(c0);
 
@@ -2060,6 +2081,17 @@ void pack_ir_x3_expand(const float *w /* [K][CEXP] */, int K, int CEXP, int shif
                         memcpy(dst + (blk * 64 + ln) * 8 + j, &h, 2);
                         memcpy(dst + ((blk + 1) * 64 + ln) * 8 + j, &l, 2);
                     }
+}
+
+// depthwise weights + bias of the f16x3 blocks (ir_block_x3_kernel): [CEXP][12] = 9 taps, bias, 0, 0 per channel
+size_t ir_x3_dw_floats(int cexp) { return (size_t)12 * cexp; }
+void pack_ir_x3_dw(const float *wd /* [9][CEXP] */, const float *bd /* [CEXP] */, int CEXP, float *dst)
+{
+    for (int c = 0; c < CEXP; ++c) {
+        for (int k = 0; k < 9; ++k) dst[(size_t)c * 12 + k] = wd[(size_t)k * CEXP + c];
+        dst[(size_t)c * 12 + 9] = bd[c];
+        dst[(size_t)c * 12 + 10] = dst[(size_t)c * 12 + 11] = 0.0f;
+    }
 }
 
 void pack_ir_x3_project(const float *w /* [CEXP][COUT] */, int CEXP, int COUT, int shift, unsigned short *dst)
