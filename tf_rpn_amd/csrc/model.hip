@@ -533,9 +533,8 @@ static void plan_weights(rpn_model *m)
             if (op.ir_hrx3) {                                             // zero-padded fragment images: larger than the matrices
                 sizes[0] = ir_hrx3_expand_floats(op.cexp);
                 sizes[4] = ir_hrx3_project_floats(op.Cin, op.cexp, op.Cout, op.stride);
-            } else if (op.ir_x3) {
-                sizes[2] = ir_x3_dw_floats(op.cexp);                      // depthwise taps + bias as one record per channel
             }
+            if (op.ir_x3) sizes[2] = ir_x3_dw_floats(op.cexp);           // depthwise taps + bias as one record per channel
             op.w_off = off;
             for (int i = 0; i < 6; ++i) {
                 op.ir_off[i] = off;
@@ -743,7 +742,7 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             w.resize((size_t)9 * p.Cin);
             for (int t = 0; t < 9; ++t)
                 for (int c = 0; c < p.Cin; ++c) w[(size_t)t * p.Cin + c] = kernel[(size_t)t * p.Cin + c] * scale[c];
-            if (op.ir_x3 && !op.ir_hrx3) {                 // [channel][9 taps, bias, 0, 0]
+            if (op.ir_x3) {                                // [channel][9 taps, bias, 0, 0] (both f16x3 block kernels)
                 std::vector<float> packed(ir_x3_dw_floats(p.Cin));
                 pack_ir_x3_dw(w.data(), shift.data(), p.Cin, packed.data());
                 w.swap(packed);
