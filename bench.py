@@ -783,11 +783,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    if overlap and use_dist:
-        prop.flush_distributed(gather_bufs)
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
     model = prop.rpn_model
     ops = model.ops()
 
@@ -797,8 +792,10 @@ def main():
             tot[op["kernel"]] = tot.get(op["kernel"], 0.0) + ms
         return max(tot, key=tot.get)
 
-    # untimed pre-pass: every op timed, to find the dominant kernel.  The timed region then carries HIP events only
-    # around ITS launches (2 events per launch on the launch stream; events around all 20 ops cost ~2.5 % of a step).
+    # untimed pre-pass, BEFORE the warm-up: every op timed, to find the dominant kernel.  The timed region then carries HIP
+    # events only around ITS launches (2 events per launch on the launch stream; events around all 20 ops cost ~2.5 % of a
+    # step).  (Until round 3 this pass -- with its host-side read-back -- sat between the warm-up and the timed region: the
+    # device idled for milliseconds right in front of the K timed steps.)
     model.set_profiling(2)
     for _ in range(2):
         step()
@@ -812,7 +809,12 @@ def main():
     # otherwise all of them in every step
     rotate = args.steps >= 2 * sum(dom_mask)
     model.set_profiling_rotate(rotate)
-    model.set_profiling(args.steps)
+    model.set_profiling(args.steps)               # (a ring of the last K forwards: the warm-up's fall out of it)
+    # ---- W untimed warm-up steps, then the timed region: exactly K steps, barrier + synchronize on both sides ----------
+    for _ in range(args.warmup):
+        step()
+    if overlap and use_dist:
+        prop.flush_distributed(gather_bufs)
     nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()

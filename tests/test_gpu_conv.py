@@ -189,6 +189,26 @@ def test_model_forward_full_size_one_image(backbone):
     assert 0.0 < cls.min() and cls.max() < 1.0
 
 
+@pytest.mark.parametrize("img,B", [(96, 2), (150, 1), (203, 3)])
+def test_f32_fused_pool_equals_layerwise(img, B):
+    """Exact-float32 VGG16 graph: block*_pool runs inside the preceding conv's epilogue (the 2 x 2 window sits in one lane's
+    accumulators; ConvArgs::pool) unless every activation is kept.  Same bits as conv -> HBM -> pool kernel, odd edges
+    included (150 -> 75 -> 37 -> 18 -> 9: every pool floors), and within 1e-4 of the float64 oracle."""
+    hp = bo.get_hyper_params("vgg16", img_size=img, feature_map_shape=None)
+    weights = synthetic_weights("vgg16", hp, seed=4)
+    imgs = np.random.RandomState(5).uniform(0, 1, size=(B, img, img, 3)).astype(np.float32)
+    outs = []
+    for keep in (False, True):
+        model = RPNModel("vgg16", hp, precision="f32", max_batch=B, keep_activations=keep)
+        model.set_weights(weights)
+        kernels = [op["kernel"] for op in model.ops()]
+        assert ("fused:maxpool_f32" in kernels) == (not keep)
+        outs.append(model.predict_on_batch(imgs))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ref = cv.rpn_forward("vgg16", imgs, weights, dtype=torch.float64)
+    assert np.abs(outs[0][0] - ref[0]).max() <= 1e-4 and np.abs(outs[0][1] - ref[1]).max() <= 1e-4
+
+
 def test_model_batch_invariance_full_size():
     """BASELINE config C2 (B=8, VGG16, 500x500): image i alone gives bit-identical outputs to image i in
     the batch (no cross-image term anywhere on the path)."""
