@@ -904,8 +904,11 @@ __device__ __forceinline__ f32x4 mfma_x3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 
 // ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), the XOR only permutes rows inside
 // the aligned sets {0-3}, {4-7}, {8-11}, {12-15} (kq < 4) or swaps such sets pairwise (sel), so every group still covers
 // 16 different slots mod 16.
-__device__ __forceinline__ int frag_slot(int kq, int row, int sel) { return kq * 16 + (row ^ (kq | (sel << 2))); }
-__device__ __forceinline__ int frag_lane(int lane, int sel) { return lane ^ ((lane >> 4) | (sel << 2)); }
+// `rot` (0 | 2): a second k-step of the same image XORs kq with 2 first -- ir_block_hrx3_kernel at CE = 48 stores a pixel's
+// channels 32 .. 47 (k-step 1) and, from the same 32-lane group, channels 0 .. 15 of the pixel 8 further on (k-step 0, same low
+// row bits): without it those two fall into the same bank groups (2-way; measured 15 % of that kernel's LDS cycles).
+__device__ __forceinline__ int frag_slot(int kq, int row, int sel, int rot = 0) { return kq * 16 + (row ^ ((kq ^ rot) | (sel << 2))); }
+__device__ __forceinline__ int frag_lane(int lane, int sel, int rot = 0) { return lane ^ (((lane >> 4) ^ rot) | (sel << 2)); }
 
 template <int KP, int CEXP, int COUT, bool RES>
 __global__ void __launch_bounds__(IR_THREADS)
@@ -1642,7 +1645,8 @@ pw_x3_kernel(PwX3Args a)
 {
     constexpr int KS = KP / 32, NB = NT / 16;
     constexpr int WPIECES = NB * KS * 2 * 64;                              // 16-byte pieces of the weight tile
-    constexpr int OUT_DW = 16 * NT;                                         // dwords of one wave's output records (16 px x NT ch x 4 B)
+    constexpr int ROW_DW = NT + 4;                                          // a pixel's records + 16 bytes of padding: rows 4 apart fall into different banks
+    constexpr int OUT_DW = 16 * ROW_DW;                                     // dwords of one wave's output records (16 px x NT ch x 4 B, padded)
     static_assert(KP % 32 == 0 && NT % 32 == 0, "shape");
     static_assert(MW * OUT_DW * 4 <= WPIECES * 16 || true, "");
     constexpr int LDS_PIECES = WPIECES > MW * OUT_DW / 4 ? WPIECES : MW * OUT_DW / 4;
@@ -1723,7 +1727,7 @@ pw_x3_kernel(PwX3Args a)
                 const unsigned hu = __builtin_bit_cast(unsigned short, h), lu = __builtin_bit_cast(unsigned short, l);
                 const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
                 const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
-                rec[((4 * lk + i) * NB + nb) * 16 + dw] = word;
+                rec[(4 * lk + i) * ROW_DW + nb * 16 + dw] = word;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (the wave reads back only what it wrote itself)
@@ -1734,7 +1738,7 @@ pw_x3_kernel(PwX3Args a)
             const int piece = lane + 64 * t;
             const int row = piece / ROWP, col = piece - row * ROWP;
             if (p0 + row < a.P)
-                *reinterpret_cast<u32x4 *>(a.out + (size_t)(p0 + row) * a.COUT + nt * NT + col * 4) = rec4[piece];
+                *reinterpret_cast<u32x4 *>(a.out + (size_t)(p0 + row) * a.COUT + nt * NT + col * 4) = rec4[row * (ROW_DW / 4) + col];
         }
     }
 }
@@ -1927,7 +1931,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
                     const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hu : lu), 0xB1, 0xF, 0xF, false);
                     const unsigned word = odd ? (got | (lu << 16)) : (hu | (got << 16));
                     const int p = py * HR_T + dx0 + px;
-                    dw32[(((p >> 4) * KSP + ks) * 2 + odd) * 256 + frag_slot(kq, p & 15, odd) * 4 + jp] = word;
+                    dw32[(((p >> 4) * KSP + ks) * 2 + odd) * 256 + frag_slot(kq, p & 15, odd, (ks & 1) << 1) * 4 + jp] = word;
                 }
             }
         }
@@ -1936,8 +1940,8 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         // ---- P(c): acc (16 px of M-block pmb x COUT) += D (16 x CE) * Wp[chunk] ---------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
-            const u32x4 dhi = DsF[((pmb * KSP + ks) * 2 + 0) * 64 + frag_lane(lane, 0)],
-                        dlo = DsF[((pmb * KSP + ks) * 2 + 1) * 64 + frag_lane(lane, 1)];
+            const u32x4 dhi = DsF[((pmb * KSP + ks) * 2 + 0) * 64 + frag_lane(lane, 0, (ks & 1) << 1)],
+                        dlo = DsF[((pmb * KSP + ks) * 2 + 1) * 64 + frag_lane(lane, 1, (ks & 1) << 1)];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int nb = pnb0 + 2 * j;
