@@ -2128,8 +2128,10 @@ int ir_block_x3_ksplit(long long tiles)
     if (forced == 1 || forced == 2 || forced == 3 || forced == 6) return forced;
     // ... as long as tiles x factor workgroups still fit the 256 CUs in one round (beyond that the parts queue up behind one
     // another and the split only adds its fixed costs: configs[4] at 3 x 128 workgroups 0.385 -> 0.41 ms)
-    // (the uneven 2-way form -- 256 workgroups for configs[4]'s 128 tiles -- measured no gain there: laboratory knob only)
-    return tiles <= 42 ? 6 : (tiles <= 85 ? 3 : 1);
+    // The uneven 2-way form (leaves 0..3 | 4..5: 256 workgroups for configs[4]'s 128 tiles) pays since round 4's 16-byte seam:
+    // configs[4] 0.323 -> 0.316 ms (blocks 11-12 22.8 -> 20.8 us); with the 4-byte seam of round 3 it measured no gain.
+    static const int two = RPN_LAB_KNOB("RPN_MN_KS2", 1);             // 0: one workgroup per tile above 85 tiles
+    return tiles <= 42 ? 6 : (tiles <= 85 ? 3 : ((two && tiles <= 128) ? 2 : 1));
 }
 size_t ir_block_x3_scratch_floats() { return (size_t)128 * 6 * 32 * 96 + 1024; }    // partials of <= 128 tiles x 6 parts x 32 px x 96 ch, then 1024 tickets
 
