@@ -51,6 +51,8 @@ def bench_name(k):
     if m: return "vgg_block1<%s>" % prec(m.group(5))
     m = re.search(r"conv3x3_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(, false)?>", k)
     if m: return "conv3x3_split<%s>" % prec(m.group(5))
+    m = re.search(r"pw_x3_kernel<(\d+), (\d+), (\d+)>", k)
+    if m: return "pw_f16x3<%s,576>" % m.group(1)
     m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)>", k)
     if m: return "conv_igemm_f32_dma<128x%d>" % (32 * int(m.group(2)) * int(m.group(4)))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
