@@ -556,7 +556,9 @@ stem_block_kernel(IrArgs a)
             const int pr = idx / PC, pc = idx - pr * PC;
             const int iy = iy0 + pr, ixc = ixc0 + pc;                      // ixc = column * 3 + channel
             float v = 0.0f;
+#ifndef RPN_EXP_STEM_NOLOAD      /* timing experiments only (results are wrong) */
             if (iy >= 0 && iy < a.H && ixc >= 0 && ixc < a.W * 3) v = xin[(size_t)iy * a.W * 3 + ixc];
+#endif
             XD[pr * PSTR + pc] = v;
         }
     }
@@ -602,8 +604,12 @@ stem_block_kernel(IrArgs a)
             for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
+#ifndef RPN_EXP_STEM_NOE
                     if (MB % 4 == 0 || wave + 4 * mbi < MB)
                         eacc[mbi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][mbi], we_r[kk][nb], eacc[mbi][nb], 0, 0, 0);
+#else
+                    eacc[mbi][nb][0] += av[kk][mbi] * we_r[kk][nb];
+#endif
 #pragma unroll
         for (int mbi = 0; mbi < MBW; ++mbi)
 #pragma unroll
@@ -618,6 +624,7 @@ stem_block_kernel(IrArgs a)
     __syncthreads();                                                      // Es complete; the patch is dead
 
     // ---- D: depthwise 3x3 + bias + ReLU6: thread = (channel dc, output row dg), 16 outputs ----------------------------
+#ifndef RPN_EXP_STEM_NOD
     {
         const float *es = Es + (drow * IW + dcol0) * SEP + dc;
         float *ds = XD + (drow * ST_TW + dcol0) * SD + dc;
@@ -636,6 +643,7 @@ stem_block_kernel(IrArgs a)
             ds[px * SD] = relu6f(acc);
         }
     }
+#endif
     __syncthreads();
 
     // ---- P: projection 32 -> 16 + bias -> NHWC -----------------------------------------------------------------------
@@ -652,7 +660,11 @@ stem_block_kernel(IrArgs a)
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int mbi = 0; mbi < PMW; ++mbi)
+#ifndef RPN_EXP_STEM_NOP
                 pacc[mbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk][mbi], wp_r[kk], pacc[mbi], 0, 0, 0);
+#else
+                pacc[mbi][0] += pa[kk][mbi] * wp_r[kk];
+#endif
 #pragma unroll
         for (int mbi = 0; mbi < PMW; ++mbi)
 #pragma unroll
