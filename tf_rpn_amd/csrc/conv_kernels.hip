@@ -592,7 +592,11 @@ void pack_head_weights_host(const float *w /* [512][ld] */, int ld, int ncols, f
                 }
 }
 
-template <int NB, int MB>          // MB: 16-pixel blocks per workgroup (2; 1 on small grids -- twice the workgroups, same bits)
+// PXV (16 | 4): pixels of its one M-block that a workgroup owns.  4 (one image at 500 x 500: 1024 pixels, four slabs of 2 KB
+// each) makes 256 workgroups of 32 KB instead of 64 of 128 KB: a workgroup reads its operand at ONE CU's bandwidth (~10 B / clk),
+// so the 64-workgroup form spent 5 us on loads alone; rows 4 .. 15 of the M-block are zeros, neither loaded nor stored (same bits:
+// an output's sum order does not depend on the other rows).
+template <int NB, int MB, int PXV = 16>          // MB: 16-pixel blocks per workgroup (2; 1 on small grids -- twice the workgroups, same bits)
 __global__ void __launch_bounds__(256, 1)
 rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restrict__ wp, const float *__restrict__ bias,
                 int n_reg, int n_cls, float *__restrict__ reg, float *__restrict__ cls, int n_slabs, long long slab_floats,
@@ -601,13 +605,19 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
     __shared__ __attribute__((aligned(16))) float part[4 * MB * NB * 64 * 4];        // [wave][tile][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    const long long p0 = (long long)blockIdx.x * (16 * MB);
+    static_assert(PXV == 16 || (PXV == 4 && MB == 1), "PXV");
+    const long long p0 = (long long)blockIdx.x * (PXV * MB);
     // A: pixel p0 + 16 mb + lr, channels 128 wave + 32 lk .. + 32 (rows beyond P repeat the last pixel; never stored)
     f32x4_h av[MB][8];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         long long px = p0 + 16 * mb + lr;
         if (px >= P) px = P - 1;
+        if (PXV < 16 && lr >= PXV) {            // rows this workgroup does not own: zero operand, no loads
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[mb][i] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         const f32x4_h *src = reinterpret_cast<const f32x4_h *>(x + px * 512 + 128 * wave + 32 * lk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) av[mb][i] = src[i];
@@ -675,7 +685,7 @@ rpn_head_kernel(const float *__restrict__ x, long long P, const float *__restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long long px = p0 + 16 * mb + 4 * lk + i;
-            if (px >= P) continue;
+            if (px >= P || 4 * lk + i >= PXV) continue;
             const float v = sum[i] + b;
             if (n < n_reg) reg[px * n_reg + n] = v;
             else cls[px * n_cls + (n - n_reg)] = 1.0f / (1.0f + expf(-v));
@@ -694,10 +704,14 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
     // a grid of fewer than 256 workgroups (one image): 16 pixels per workgroup instead of 32 -- its operand, up to four slabs of
     // 2 KB per pixel, is read at one CU's bandwidth per workgroup
     const int MB = (P + 31) / 32 < 256 ? 1 : 2;
-    const dim3 grid((unsigned)((P + 16 * MB - 1) / (16 * MB)));
+    const bool px4 = MB == 1 && (P + 15) / 16 <= 64 && n_slabs > 1;     // <= 64 workgroups of up to four slabs: 4 pixels each instead
+    const dim3 grid((unsigned)(px4 ? (P + 3) / 4 : (P + 16 * MB - 1) / (16 * MB)));
     const int NB = (ncols + 15) / 16;
 #define RPN_HEAD(NB_)                                                                                                 \
-    if (MB == 1)                                                                                                      \
+    if (px4)                                                                                                          \
+        hipLaunchKernelGGL((rpn_head_kernel<NB_, 1, 4>), grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls,  \
+                           n_slabs, slab_floats, conv_bias);                                                          \
+    else if (MB == 1)                                                                                                 \
         hipLaunchKernelGGL((rpn_head_kernel<NB_, 1>), grid, dim3(256), 0, stream, x, P, w_packed, bias, n_reg, n_cls, reg, cls,     \
                            n_slabs, slab_floats, conv_bias);                                                          \
     else                                                                                                              \
