@@ -117,7 +117,7 @@ void pack_ir_hrx3_project(const float *w, int cin, int cexp, int cout, int strid
 hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
                                 int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
                                 const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
-                                hipStream_t s);
+                                float *scratch, hipStream_t s);   // scratch: ir_block_x3_scratch_floats() (K tree of blocks 3 / 6), or null
 
 // Device word into which the split-format writers launched from THIS host thread flag float16 range violations
 // (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.

@@ -1797,9 +1797,16 @@ struct IrHrX3Args {
     float scale_e, scale_p;
     int B, H, W, OH, OW, pad, tiles_x, tiles_y;
     unsigned *status;
+    // K tree (NLEAF > 1 instantiations: the stride-2 blocks 3 and 6, whose one-image grids are 128 / 32 tiles walking 9 / 4 chunks):
+    // the projection is summed over NLEAF fixed runs of chunks -- (l0 + l1) + l2, or (l0 + l1) + (l2 + l3) -- at EVERY batch size;
+    // `ksplit` (1 | 2 | NLEAF) workgroups per tile share the leaves, partial sums go to `part` ([tile][ksplit][32 px x COUTP]) and
+    // the last arriver (tickets[tile], left at zero) finishes the same tree: same bits at every factor (as in ir_block_x3_kernel).
+    int ksplit;
+    float *part;
+    unsigned *tickets;
 };
 
-template <int CIN, int CEXP, int CE, int COUT, int S, bool RES>
+template <int CIN, int CEXP, int CE, int COUT, int S, bool RES, int NLEAF = 1, int KSPLIT = 1>
 __global__ void __launch_bounds__(HR_THREADS)
 ir_block_hrx3_kernel(IrHrX3Args a)
 {
@@ -1816,12 +1823,19 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     static_assert(CIN % 8 == 0 && CIN <= 32 && SEP % 8 == 4 && CEXP % CE == 0 && CE % 16 == 0 && CE <= 48 && DG * CE <= HR_THREADS,
                   "layout");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
+    static_assert((NLEAF == 1 || NLEAF == 3 || NLEAF == 4) && NCHUNK % NLEAF == 0, "projection tree");
+    constexpr int LEAFC = NCHUNK / NLEAF;                                 // chunks per leaf
     __shared__ __attribute__((aligned(16))) float Es[MH * SEP];
     __shared__ u32x4 DsF[2 * KSP * 2 * 64];                               // [mb 2][ks][hi|lo][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    int t = blockIdx.x;
+    // (the split factor is a template parameter: with run-time chunk bounds the unsplit batch-8 form lost 6 % -- 21.3 -> 22.6 us)
+    static_assert(KSPLIT == 1 || (NLEAF > 1 && (KSPLIT == NLEAF || (NLEAF == 4 && KSPLIT == 2))), "split factor");
+    constexpr int ksplit = KSPLIT;
+    const int tile = (int)blockIdx.x / ksplit, part_h = (int)blockIdx.x - tile * ksplit;
+    const int c_begin = part_h * (NCHUNK / ksplit), c_end = c_begin + NCHUNK / ksplit;
+    int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -1874,12 +1888,14 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
     const int dy0 = (dg * PXG) / HR_T, dx0 = (dg * PXG) % HR_T;
     f32x4 pacc[NJ];
+    f32x4 tsum[NLEAF > 1 ? NJ : 1], usum[NLEAF == 4 ? NJ : 1];          // the tree so far; leaf 2 of a four-leaf tree
+    (void)tsum; (void)usum;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     HR_STAMP(HRV, 1);
 
-    for (int c = 0; c < NCHUNK; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         // ---- E(c): (halo pixels x 32) * We[:, chunk] -> * 2^-shift + bias, ReLU6, zero outside the image -> Es ------------
         {
             u32x4 wh[NBE], wl[NBE];
@@ -1966,6 +1982,61 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         // (the next chunk's E writes Es, its D writes DsF behind the barrier after E: P(c) has read DsF by then -- every wave
         // passes that barrier only after its own P(c))
         HR_STAMP(HRV, 4 + 3 * c);
+        if constexpr (NLEAF > 1) {
+            if ((c + 1) % LEAFC == 0) {          // a leaf ends: fold it into the tree in the fixed order
+                const int leaf = c / LEAFC;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (ksplit == NLEAF || leaf == 0) tsum[j] = pacc[j];                          // (one leaf per workgroup: as it is)
+                    else if (NLEAF == 4 && leaf == 2) { if (ksplit == 2) tsum[j] = pacc[j]; else usum[j] = pacc[j]; }
+                    else if (NLEAF == 4 && leaf == 3) tsum[j] = ksplit == 2 ? tsum[j] + pacc[j] : tsum[j] + (usum[j] + pacc[j]);
+                    else tsum[j] = tsum[j] + pacc[j];                                             // leaf 1; leaf 2 of three
+                    pacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+    if constexpr (NLEAF > 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pacc[j] = tsum[j];
+        if (ksplit > 1) {
+            // K-split seam: 16-byte sc1 slab stores / loads in accumulator layout (ir_block_x3_kernel); slab slot of the accumulator
+            // of (N-block nb, M-block pmb) = nb * 2 + pmb
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                a.part + (size_t)tile * ksplit * (32 * COUTP), (short)0, ksplit * 32 * COUTP * 4, 0x00020000);
+            constexpr int kSc1 = 16;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = pnb0 + 2 * j;
+                if (NBO % 2 == 0 || nb < NBO)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pacc[j]), prs,
+                                                           (part_h * 32 * COUTP + ((nb * 2 + pmb) * 64 + lane) * 4) * 4, 0, kSc1);
+            }
+            __shared__ unsigned last_flag;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned last = ticket == (unsigned)ksplit - 1u ? 1u : 0u;
+                if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                last_flag = last;
+            }
+            __syncthreads();
+            if (last_flag == 0u) return;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = pnb0 + 2 * j;
+                if (NBO % 2 == 0 || nb < NBO) {
+                    f32x4 q[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        q[h] = h < ksplit ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                prs, (h * 32 * COUTP + ((nb * 2 + pmb) * 64 + lane) * 4) * 4, 0, kSc1))
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+                    pacc[j] = ksplit == 2 ? q[0] + q[1] : (ksplit == 3 ? (q[0] + q[1]) + q[2] : (q[0] + q[1]) + (q[2] + q[3]));
+                }
+            }
+        }
     }
     // ---- * 2^-shift + bias (+ the block input) -> NHWC ---------------------------------------------------------------------
 #pragma unroll
@@ -2051,10 +2122,21 @@ void pack_ir_hrx3_project(const float *w /* [cexp][coutp] */, int cin, int cexp,
                     }
 }
 
+// K-split factor of the stride-2 tree blocks (3: 24 -> 144 -> 32, three leaves; 6: 32 -> 192 -> 64, four) on a grid of `tiles`
+// 4 x 8 tiles: one leaf per workgroup while tiles x leaves still fits the chip at its residency (256-thread workgroups, 4-5 per CU).
+int ir_block_hrx3_ksplit(int cin, long long tiles, bool have_scratch)
+{
+    static const int forced = RPN_LAB_KNOB("RPN_MN_HRKS", -1);        // 1: never split (A/B timing)
+    if (!have_scratch || forced == 1) return 1;
+    if (cin == 32) return tiles <= 64 ? 4 : (tiles <= 160 ? 2 : 1);
+    if (cin == 24) return tiles <= 160 ? 3 : 1;
+    return 1;
+}
+
 hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
                                 int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
                                 const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
-                                hipStream_t s)
+                                float *scratch, hipStream_t s)
 {
     if (!ir_block_hrx3_supported(cin, cexp, cout, stride, residual)) return hipErrorInvalidValue;
     IrHrX3Args a{};
@@ -2063,13 +2145,30 @@ hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, in
     a.B = B; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.pad = pad; a.status = status;
     a.tiles_x = (OW + HR_T - 1) / HR_T;
     a.tiles_y = (OH + 3) / 4;
-    const long long nb = (long long)a.tiles_x * a.tiles_y * B;
-    if (nb <= 0 || nb > 0x7fffffffll) return hipErrorInvalidValue;
-    if (cin == 32 && ir_hrx3_b6() == 48) hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 48, 64, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
-    else if (cin == 32) hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 16, 64, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * B;
+    if (tiles <= 0 || tiles > 0x7fffffffll) return hipErrorInvalidValue;
+    // blocks 3 and 6 are K TREES (IrHrX3Args::ksplit); the scratch is the fused x3 blocks' (partials, then 1024 tickets)
+    const bool tree = stride == 2 && (cin == 32 || cin == 24);
+    a.ksplit = tree ? ir_block_hrx3_ksplit(cin, tiles, scratch != nullptr) : 1;
+    const int coutp = (cout + 15) / 16 * 16;
+    if (a.ksplit > 1 && (tiles > 1024 || (size_t)tiles * a.ksplit * 32 * coutp > (size_t)128 * 6 * 32 * 96)) a.ksplit = 1;
+    a.part = scratch;
+    a.tickets = scratch ? reinterpret_cast<unsigned *>(scratch + (size_t)128 * 6 * 32 * 96) : nullptr;
+    const long long nb = tiles * a.ksplit;
+#define RPN_HRX3(KS_, ...) hipLaunchKernelGGL((ir_block_hrx3_kernel<__VA_ARGS__, KS_>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a)
+    if (cin == 32 && ir_hrx3_b6() == 48) {
+        if (a.ksplit == 4) RPN_HRX3(4, 32, 192, 48, 64, 2, false, 4);
+        else if (a.ksplit == 2) RPN_HRX3(2, 32, 192, 48, 64, 2, false, 4);
+        else RPN_HRX3(1, 32, 192, 48, 64, 2, false, 4);
+    } else if (cin == 32) {
+        a.ksplit = 1;
+        hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 16, 64, 2, false, 4>), dim3((unsigned)tiles), dim3(HR_THREADS), 0, s, a);
+    }
     else if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 48, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 16, 32, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (a.ksplit == 3) RPN_HRX3(3, 24, 144, 16, 32, 2, false, 3);
+    else RPN_HRX3(1, 24, 144, 16, 32, 2, false, 3);
+#undef RPN_HRX3
     return hipGetLastError();
 }
 

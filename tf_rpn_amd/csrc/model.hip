@@ -561,7 +561,7 @@ static int ensure_device(rpn_model *m)
     }
     if (!m->d_ksplit) {
         bool any = false;
-        for (const Op &op : m->ops) any = any || (op.kind == OP_IRBLOCK && op.ir_x3 && !op.ir_hrx3);
+        for (const Op &op : m->ops) any = any || (op.kind == OP_IRBLOCK && op.ir_x3);
         if (any) {
             RPN_HIP_CHECK(hipMalloc(&m->d_ksplit, ir_block_x3_scratch_floats() * sizeof(float)));
             RPN_HIP_CHECK(hipMemset(m->d_ksplit, 0, ir_block_x3_scratch_floats() * sizeof(float)));
@@ -998,7 +998,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 e = launch_ir_block_hrx3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_pad, op.OH, op.OW,
                                          wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
                                          wb + op.ir_off[4], wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1],
-                                         tensor_ptr(m, op.out, d_imgs), m->d_status, s);
+                                         tensor_ptr(m, op.out, d_imgs), m->d_status, m->d_ksplit, s);
             else if (op.ir_x3)
                 e = launch_ir_block_x3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.ir_res, wb + op.ir_off[0],
                                        wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3], wb + op.ir_off[4],
