@@ -2129,7 +2129,7 @@ int ir_block_hrx3_ksplit(int cin, long long tiles, bool have_scratch)
     static const int forced = RPN_LAB_KNOB("RPN_MN_HRKS", -1);        // 1: never split (A/B timing)
     if (!have_scratch || forced == 1) return 1;
     if (cin == 32) return tiles <= 64 ? 4 : (tiles <= 160 ? 2 : 1);
-    if (cin == 24) return tiles <= 160 ? 3 : 1;
+    if (cin == 24) return tiles <= 160 ? 3 : 1;       // (512 tiles -- configs[4] -- x 3 no longer fit one round: 19.2 -> 23.3 us)
     return 1;
 }
 
