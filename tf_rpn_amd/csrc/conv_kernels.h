@@ -147,7 +147,17 @@ const char *conv3x3_split16_variant(int B, int H, int W, int Cin, int Cout, int 
 // l3) over four fixed leaves of K at every batch size, computed by one workgroup per tile (launch_conv3x3_split16, ktree) or by
 // 2 / 4 (launch_conv3x3_split16_ksplit: slabs l0 + l1 | l2 + l3, or the four leaves; the head adds them in tree order).
 // _ktree_ok: whether the layer can run that way at every batch up to B; _ksplit: the split factor (1 | 2 | 4) at batch B.
+// Leaf boundaries of the K tree over `chunks` 32-channel slices: leaf k = slices [ktree_cut(k), ktree_cut(k + 1)).  The middle cut
+// is EVEN, so that the two halves of a 2-way split are whole slice PAIRS (what the persistent LDS-DMA kernel walks): 18 slices
+// (MobileNetV2's 576 channels) -> 4 4 5 5 (round 3: 4 5 4 5); 16 slices (VGG16) -> 4 4 4 4, unchanged.
+__host__ __device__ inline int ktree_cut(int chunks, int k)
+{
+    return k <= 0 ? 0 : (k == 1 ? chunks / 4 : (k == 2 ? ((chunks / 2) & ~1) : (k == 3 ? 3 * chunks / 4 : chunks)));
+}
 bool conv3x3_split16_ktree_ok(int B, int H, int W, int Cin, int Cout, int cout_pad);
+// whether the 2-way split of such a layer at batch B runs on the persistent LDS-DMA kernel (8 x 32 x 64 tiles, two workgroups
+// per tile: grids of 65 .. 128 tiles -- configs[4]'s 64 x 64 feature map) instead of the register-staged 4 x 32 x 64 kernel
+bool conv3x3_split16_ksplit_dma(int B, int H, int W, int Cin, int Cout, int cout_pad);
 int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad);
 hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *out, long long slab_floats, int B, int H, int W,
                                          int Cin, int Cout, int cout_pad, float out_scale, bool f16, int ksplit, hipStream_t s);

@@ -770,9 +770,9 @@ conv3x3_split16_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     constexpr bool KT = TH == 4 && NW == 4 && !POOL;   // (the instantiation the K-tree launcher uses; the others have no registers for it)
     if (KT && a.ktree) {                              // (gridDim.y = 2 or 4: the launcher sends an unsplit tree layer elsewhere)
         const int per = 4 / (int)gridDim.y, l0 = (int)blockIdx.y * per;
-        c_begin = l0 * all_chunks / 4;
-        chunks = (l0 + per) * all_chunks / 4;
-        if (per == 2) c_fold = (l0 + 1) * all_chunks / 4;
+        c_begin = ktree_cut(all_chunks, l0);
+        chunks = ktree_cut(all_chunks, l0 + per);
+        if (per == 2) c_fold = ktree_cut(all_chunks, l0 + 1);
     }
     const int steps = chunks * 3;
     const size_t in_pix_stride = (size_t)(a.Cin >> 4) * 4;
@@ -1068,13 +1068,25 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
     const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride, BN};
 #define next_tile(SLOT, IMG, OY0, OX0, N0) walk.next((SLOT), (IMG), (OY0), (OX0), (N0))
 
-    const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
-    const int total_taps = chunks * 9;
+    const int all_chunks = a.Cin >> 5;                // 32-channel slices (even)
+    // K tree split two ways (gridDim.y == 2; launch_conv3x3_split16_ksplit on grids of 65 .. 128 tiles): workgroup y walks the
+    // slices [cb, cb + chunks) = leaves 2y, 2y + 1 (ktree_cut's middle cut is even: whole slice pairs) and writes the RAW sum of
+    // its two leaves to slab y (the host passes no bias, a linear activation, float32 output); the RPN head adds the slabs
+    int cb = 0, chunks = all_chunks;
+    if constexpr (KTREE) {
+        if (gridDim.y == 2) {
+            const int mid = ktree_cut(all_chunks, 2);
+            cb = blockIdx.y ? mid : 0;
+            chunks = blockIdx.y ? all_chunks - mid : mid;
+            a.out = reinterpret_cast<float *>(a.out) + (size_t)blockIdx.y * a.slab_floats;
+        }
+    }
+    const int total_taps = chunks * 9, tap0 = cb * 9;
     const int in_pix_stride = (a.Cin >> 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(a.x), (short)0, (int)((size_t)a.B * a.H * a.W * in_pix_stride * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
+        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)all_chunks * 9 * a.cout_pad * 128), 0x00020000);
     const int w_tap_bytes = a.cout_pad * 128;
 
     // halo DMA: wave-instruction k = j * 8 + wave fills LDS pieces [64k, 64k + 64); piece e = pixel * 8 + physical slot.
@@ -1167,9 +1179,9 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) a_goff[j] = halo_goff(j, img, oy0, ox0);
 #pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) RPN_DMA_A(j, a_goff[j], 0, 0);
+    for (int j = 0; j < A_PER_WAVE; ++j) RPN_DMA_A(j, a_goff[j], cb * 128, 0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) RPN_DMA_B(t * w_tap_bytes + n0 * (PPP * 16), t);
+    for (int t = 0; t < 3; ++t) RPN_DMA_B((tap0 + t) * w_tap_bytes + n0 * (PPP * 16), t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1212,7 +1224,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                         else tap = total_taps - 1;
                     }
 #ifndef RPN_EXP_NO_DMA
-                    RPN_DMA_B(tap * w_tap_bytes + nb * (PPP * 16), s9 % 3);
+                    RPN_DMA_B((tap0 + tap) * w_tap_bytes + nb * (PPP * 16), s9 % 3);
 #endif
                     ++gt;
                 }
@@ -1230,7 +1242,7 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 if (s9 < A_PER_WAVE) {      // halo piece s9 of the next slice: this tile's, or slice 0 of the next tile
                     const int nc = 2 * pair + c2 + 1;
 #ifndef RPN_EXP_NO_DMA
-                    RPN_DMA_A(s9, a_goff[s9], nc < chunks ? nc * 128 : (nxt >= 0 ? 0 : (chunks - 1) * 128), (c2 + 1) & 1);
+                    RPN_DMA_A(s9, a_goff[s9], (cb + (nc < chunks ? nc : (nxt >= 0 ? 0 : chunks - 1))) * 128, (c2 + 1) & 1);
 #endif
                 }
                 // ---- half 0: row 0.  Program order = intended issue order: a fragment read behind each of the first MFMAs
@@ -1313,8 +1325,9 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
                 if (s9 == 8 && tile_no == 1) RPN_STAMP_AT(4 + 2 * pair + c2);   // (second tile: steady state)
                 if constexpr (KTREE) {      // a leaf ends behind slice k * slices / 4 (slices >= 8: every leaf has two or more)
                     if (s9 == 8) {          // (tap 8's MFMAs are all issued above; tap 9's fragments are in registers already)
-                        const int done = 2 * pair + c2 + 1;
-                        const bool e0 = done == chunks / 4, e1 = done == chunks / 2, e2 = done == 3 * chunks / 4;
+                        const int done = cb + 2 * pair + c2 + 1;     // slices of the LAYER finished
+                        const bool e0 = done == ktree_cut(all_chunks, 1), e1 = done == ktree_cut(all_chunks, 2),
+                                   e2 = done == ktree_cut(all_chunks, 3);
                         if (e0 || e1 || e2) {
 #pragma unroll
                             for (int m = 0; m < MT; ++m)
@@ -1334,7 +1347,10 @@ conv3x3_split16_dma_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tile
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[m][j] = t01[m][j] + (t23[m][j] + acc[m][j]);
+                for (int j = 0; j < NJ; ++j) {
+                    if (gridDim.y == 2) acc[m][j] = blockIdx.y == 0 ? t01[m][j] : t23[m][j] + acc[m][j];   // l0 + l1 | l2 + l3
+                    else acc[m][j] = t01[m][j] + (t23[m][j] + acc[m][j]);
+                }
         }
         // The first fragments of the next tile's tap 0 are already in registers and its DMAs are in flight (halo buffer 0,
         // the weight ring): the epilogue stages through halo buffer 1 + the spare LDS, both dead until the next tile's
@@ -1431,13 +1447,25 @@ conv3x3_split16_dma4_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_til
     const int slot_stride = gridDim.x >> 3;
     const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride, BN};
 
-    const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
-    const int total_taps = chunks * 9;
+    const int all_chunks = a.Cin >> 5;                // 32-channel slices (even)
+    // K tree split two ways (gridDim.y == 2; launch_conv3x3_split16_ksplit on grids of 65 .. 128 tiles): workgroup y walks the
+    // slices [cb, cb + chunks) = leaves 2y, 2y + 1 (ktree_cut's middle cut is even: whole slice pairs) and writes the RAW sum of
+    // its two leaves to slab y (the host passes no bias, a linear activation, float32 output); the RPN head adds the slabs
+    int cb = 0, chunks = all_chunks;
+    if constexpr (KTREE) {
+        if (gridDim.y == 2) {
+            const int mid = ktree_cut(all_chunks, 2);
+            cb = blockIdx.y ? mid : 0;
+            chunks = blockIdx.y ? all_chunks - mid : mid;
+            a.out = reinterpret_cast<float *>(a.out) + (size_t)blockIdx.y * a.slab_floats;
+        }
+    }
+    const int total_taps = chunks * 9, tap0 = cb * 9;
     const int in_pix_stride = (a.Cin >> 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(a.x), (short)0, (int)((size_t)a.B * a.H * a.W * in_pix_stride * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
+        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)all_chunks * 9 * a.cout_pad * 128), 0x00020000);
     const int w_tap_bytes = a.cout_pad * 128;
 
 #define halo_goff4(J, IM, Y0, X0) halo_source_offset<NW, A_INSTR, HP * PPP>((J), wave, lane, (IM), (Y0), (X0), a.H, a.W, in_pix_stride)
@@ -2489,8 +2517,19 @@ bool conv3x3_split16_ktree_ok(int B, int H, int W, int Cin, int Cout, int cout_p
            (long long)B * H * W * Cin * 4 < 0x7fffffffll && (long long)(Cin / 32) * 9 * cout_pad * 128 < 0x7fffffffll;
 }
 
+bool conv3x3_split16_ksplit_dma(int B, int H, int W, int Cin, int Cout, int cout_pad)
+{
+    static const int on = RPN_LAB_KNOB("RPN_KSPLIT_DMA", 1);
+    const char *v = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, false);
+    if (!on || !v || strcmp(v, "reg,64") != 0) return false;           // (the small-grid case of a DMA-capable layer)
+    const long long blocks64 = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 63) / 64);
+    const int chunks = Cin / 32, mid = ktree_cut(chunks, 2);
+    return blocks64 > 64 && blocks64 <= 128 && mid >= 2 && (chunks - mid) >= 2 && (chunks - mid) % 2 == 0;
+}
+
 int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)
 {
+    if (conv3x3_split16_ksplit_dma(B, H, W, Cin, Cout, cout_pad)) return 2;
     // (a K-tree layer only -- the caller checks conv3x3_split16_ktree_ok at its largest batch)  MobileNetV2 500 x 500, one
     // image: 0.292 -> 0.259 ms per step; 1024 x 1024: 0.395 -> 0.377.
     const char *v = conv3x3_split16_variant(B, H, W, Cin, Cout, cout_pad, false);
@@ -2513,6 +2552,20 @@ hipError_t launch_conv3x3_split16_ksplit(const void *x, const void *w, float *ou
     a.x = (const uint4 *)x; a.w = (const uint4 *)w; a.bias = nullptr; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.cout_pad = cout_pad;
     a.out_scale = out_scale; a.act = ACT_LINEAR; a.out_f32 = 1; a.slab_floats = slab_floats;
+    if (ksplit == 2 && conv3x3_split16_ksplit_dma(B, H, W, Cin, Cout, cout_pad)) {
+        // the persistent LDS-DMA kernel, two workgroups per 8 x 32 x 64 tile (static schedule: the two halves of a tile must not
+        // share a tile queue); every workgroup has exactly one tile on these grids
+        const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 7) / 8, n_tiles = (Cout + 63) / 64;
+        const long long m_tiles = (long long)tiles_x * tiles_y * B;
+        const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+        const long long slots = (long long)((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
+        if (m_tiles <= 0 || slots > 16) return hipErrorInvalidValue;      // 2 x 8 x slots workgroups: one tile each, one round
+        const unsigned pgrid = 8u * (unsigned)slots;
+        a.sched = nullptr;
+        if (f16) hipLaunchKernelGGL((conv3x3_split16_dma_kernel<true, false, 64, true>), dim3(pgrid, 2), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles);
+        else hipLaunchKernelGGL((conv3x3_split16_dma_kernel<false, false, 64, true>), dim3(pgrid, 2), dim3(512), 0, s, a, tiles_x, tiles_y, n_tiles);
+        return hipGetLastError();
+    }
     const int tiles_x = (W + TWS - 1) / TWS, tiles_y = (H + 3) / 4;
     const int n_tiles = (Cout + 63) / 64;
     const long long m_tiles = (long long)tiles_x * tiles_y * B;
