@@ -1447,25 +1447,13 @@ conv3x3_split16_dma4_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_til
     const int slot_stride = gridDim.x >> 3;
     const TileWalk walk{n_tiles, m_tiles, tiles_x, tiles_y, XN, XM, NTl, NTl * MTl, xcd, slot_stride, BN};
 
-    const int all_chunks = a.Cin >> 5;                // 32-channel slices (even)
-    // K tree split two ways (gridDim.y == 2; launch_conv3x3_split16_ksplit on grids of 65 .. 128 tiles): workgroup y walks the
-    // slices [cb, cb + chunks) = leaves 2y, 2y + 1 (ktree_cut's middle cut is even: whole slice pairs) and writes the RAW sum of
-    // its two leaves to slab y (the host passes no bias, a linear activation, float32 output); the RPN head adds the slabs
-    int cb = 0, chunks = all_chunks;
-    if constexpr (KTREE) {
-        if (gridDim.y == 2) {
-            const int mid = ktree_cut(all_chunks, 2);
-            cb = blockIdx.y ? mid : 0;
-            chunks = blockIdx.y ? all_chunks - mid : mid;
-            a.out = reinterpret_cast<float *>(a.out) + (size_t)blockIdx.y * a.slab_floats;
-        }
-    }
-    const int total_taps = chunks * 9, tap0 = cb * 9;
+    const int chunks = a.Cin >> 5;                    // 32-channel slices (even)
+    const int total_taps = chunks * 9;
     const int in_pix_stride = (a.Cin >> 4) * 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(a.x), (short)0, (int)((size_t)a.B * a.H * a.W * in_pix_stride * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)all_chunks * 9 * a.cout_pad * 128), 0x00020000);
+        const_cast<uint4 *>(a.w), (short)0, (int)((size_t)total_taps * a.cout_pad * 128), 0x00020000);
     const int w_tap_bytes = a.cout_pad * 128;
 
 #define halo_goff4(J, IM, Y0, X0) halo_source_offset<NW, A_INSTR, HP * PPP>((J), wave, lane, (IM), (Y0), (X0), a.H, a.W, in_pix_stride)

@@ -1765,7 +1765,11 @@ hipError_t launch_pw_x3(const float *x, long long P, int cin, int cout, const vo
     a.x = x; a.w = reinterpret_cast<const u32x4 *>(w); a.bias = bias; a.out = reinterpret_cast<unsigned *>(out);
     a.scale = scale; a.P = P; a.COUT = cout; a.status = status;
     // small grids (one image): 64-pixel x 32-channel tiles, hundreds of short workgroups; else 128 x 96
-    if (P <= 4096) {
+    static const int pw_tile = RPN_LAB_KNOB("RPN_PW_TILE", 0);     // 1: 64 x 32 tiles always; 2: 128 x 96 always; 3: 128 x 32
+    if (pw_tile == 3) {
+        const long long blocks = (P + 127) / 128 * (cout / 32);
+        hipLaunchKernelGGL((pw_x3_kernel<96, 32, 8>), dim3((unsigned)blocks), dim3(512), 0, s, a);
+    } else if ((P <= 4096 && pw_tile != 2) || pw_tile == 1) {
         const long long blocks = (P + 63) / 64 * (cout / 32);
         hipLaunchKernelGGL((pw_x3_kernel<96, 32, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
