@@ -111,13 +111,16 @@ hipError_t launch_pw_x3(const float *x, long long P, int cin, int cout, const vo
 // ir_hrx3_*_floats give their sizes in floats.
 bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual);
 size_t ir_hrx3_expand_floats(int cexp);
-size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride);
-void pack_ir_hrx3_expand(const float *w, int cin, int cexp, int stride, int shift, unsigned short *dst);
-void pack_ir_hrx3_project(const float *w, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst);
+// ce_ov: the block's chunk size when the model chose one (ir_hrx3_chunk_for: block 3, by the grid at the handle's max_batch);
+// 0 = the kernel family's default.  The same value must go to the packers and to the launcher.
+int ir_hrx3_chunk_for(int cin, int stride, long long tiles_at_max_batch);
+size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride, int ce_ov = 0);
+void pack_ir_hrx3_expand(const float *w, int cin, int cexp, int stride, int shift, unsigned short *dst, int ce_ov = 0);
+void pack_ir_hrx3_project(const float *w, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst, int ce_ov = 0);
 hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
                                 int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
                                 const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
-                                float *scratch, hipStream_t s);   // scratch: ir_block_x3_scratch_floats() (K tree of blocks 3 / 6), or null
+                                float *scratch, hipStream_t s, int ce_ov = 0);   // scratch: ir_block_x3_scratch_floats() (K tree of blocks 3 / 6), or null
 
 // Device word into which the split-format writers launched from THIS host thread flag float16 range violations
 // (RPN_STATUS_F16_RANGE); null = no reporting.  rpn_model_forward sets it around its launches.

@@ -2072,7 +2072,30 @@ static int ir_hrx3_b6()
     static const int v = RPN_LAB_KNOB("RPN_MN_B6", 48);
     return v;
 }
-static int ir_hrx3_ce(int cin, int stride) { return cin == 32 ? ir_hrx3_b6() : ((cin == 24 && stride == 1) ? 48 : 16); }
+static int ir_hrx3_b1()
+{
+    static const int v = RPN_LAB_KNOB("RPN_MN_B1CE", 32);              // block 1's chunk size: 16 | 32 | 48 (batch 8: 45.0 / 41.0 / 49.3 us)
+    return v == 16 || v == 48 ? v : 32;
+}
+static int ir_hrx3_b3()
+{
+    static const int v = RPN_LAB_KNOB("RPN_MN_B3CE", 0);               // block 3's chunk size forced: 16 | 48 (0: by grid, ir_hrx3_chunk_for)
+    return v == 48 ? 48 : 16;
+}
+static int ir_hrx3_ce(int cin, int stride, int ce_ov = 0)
+{
+    if (ce_ov) return ce_ov;
+    return cin == 32 ? ir_hrx3_b6() : (cin == 16 ? ir_hrx3_b1() : ((cin == 24 && stride == 1) ? 48 : ir_hrx3_b3()));
+}
+// Block 3 (24 -> 144 -> 32, stride 2) has two chunk sizes: 48 (three chunks = the tree's three leaves) on grids of at most 512
+// tiles -- one 500 x 500 or 1024 x 1024 image: 13.2 -> 12.4 us, 19.4 -> 14.7 us -- and 16 (nine chunks: more resident workgroups)
+// on larger ones (batch 8: 21.1 vs 24.1 us).  The chunk size shapes the packed weights AND the order in which a leaf's channels
+// enter its sum, so it is chosen once per model handle, from the grid at the handle's max_batch -- never per call.
+int ir_hrx3_chunk_for(int cin, int stride, long long tiles_at_max_batch)
+{
+    if (cin == 24 && stride == 2 && RPN_LAB_KNOB("RPN_MN_B3CE", 0) == 0) return tiles_at_max_batch <= 512 ? 48 : 16;
+    return 0;                                          // (0: the kernel family's default for this block)
+}
 
 bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual)
 {
@@ -2083,15 +2106,15 @@ bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool resid
 }
 
 size_t ir_hrx3_expand_floats(int cexp) { return (size_t)32 * cexp; }                      // K padded to 32: CEXP x 128 bytes
-size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride)
+size_t ir_hrx3_project_floats(int cin, int cexp, int cout, int stride, int ce_ov)
 {
-    const int ce = ir_hrx3_ce(cin, stride), ksp = (ce + 31) / 32, nbo = (cout + 15) / 16;
+    const int ce = ir_hrx3_ce(cin, stride, ce_ov), ksp = (ce + 31) / 32, nbo = (cout + 15) / 16;
     return (size_t)(cexp / ce) * nbo * ksp * 2 * 64 * 4;
 }
 
-void pack_ir_hrx3_expand(const float *w /* [cin][cexp] */, int cin, int cexp, int stride, int shift, unsigned short *dst)
+void pack_ir_hrx3_expand(const float *w /* [cin][cexp] */, int cin, int cexp, int stride, int shift, unsigned short *dst, int ce_ov)
 {
-    const int CE = ir_hrx3_ce(cin, stride), NBE = CE / 16;
+    const int CE = ir_hrx3_ce(cin, stride, ce_ov), NBE = CE / 16;
     const float mul = ldexpf(1.0f, shift);
     for (int c = 0; c < cexp / CE; ++c)
         for (int nb = 0; nb < NBE; ++nb)
@@ -2107,9 +2130,9 @@ void pack_ir_hrx3_expand(const float *w /* [cin][cexp] */, int cin, int cexp, in
                 }
 }
 
-void pack_ir_hrx3_project(const float *w /* [cexp][coutp] */, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst)
+void pack_ir_hrx3_project(const float *w /* [cexp][coutp] */, int cin, int cexp, int cout, int stride, int shift, unsigned short *dst, int ce_ov)
 {
-    const int CE = ir_hrx3_ce(cin, stride), KSP = (CE + 31) / 32, coutp = (cout + 15) / 16 * 16, NBO = coutp / 16;
+    const int CE = ir_hrx3_ce(cin, stride, ce_ov), KSP = (CE + 31) / 32, coutp = (cout + 15) / 16 * 16, NBO = coutp / 16;
     const float mul = ldexpf(1.0f, shift);
     for (int c = 0; c < cexp / CE; ++c)
         for (int nb = 0; nb < NBO; ++nb)
@@ -2140,7 +2163,7 @@ int ir_block_hrx3_ksplit(int cin, long long tiles, bool have_scratch)
 hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, int cexp, int cout, int stride, bool residual,
                                 int pad, int OH, int OW, const void *we, const float *be, const float *wd, const float *bd,
                                 const void *wp, const float *bp, float scale_e, float scale_p, float *out, unsigned *status,
-                                float *scratch, hipStream_t s)
+                                float *scratch, hipStream_t s, int ce_ov)
 {
     if (!ir_block_hrx3_supported(cin, cexp, cout, stride, residual)) return hipErrorInvalidValue;
     IrHrX3Args a{};
@@ -2168,8 +2191,11 @@ hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, in
         a.ksplit = 1;
         hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 16, 64, 2, false, 4>), dim3((unsigned)tiles), dim3(HR_THREADS), 0, s, a);
     }
+    else if (cin == 16 && ir_hrx3_b1() == 32) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 32, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (cin == 16 && ir_hrx3_b1() == 48) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 48, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 48, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (ir_hrx3_ce(cin, stride, ce_ov) == 48) { if (a.ksplit == 3) RPN_HRX3(3, 24, 144, 48, 32, 2, false, 3); else RPN_HRX3(1, 24, 144, 48, 32, 2, false, 3); }
     else if (a.ksplit == 3) RPN_HRX3(3, 24, 144, 16, 32, 2, false, 3);
     else RPN_HRX3(1, 24, 144, 16, 32, 2, false, 3);
 #undef RPN_HRX3

@@ -70,6 +70,7 @@ struct Op {
     bool ir_x3 = false;                // F16X3 only: the block's two GEMMs on the 16-bit MFMA (hi + lo float16 operands)
     bool ir_hrx3 = false;              // ... the high-resolution form (blocks 1-3: ir_block_hrx3_kernel; implies ir_x3)
     float ir_scale[2] = {1.0f, 1.0f};  // ... 2^-shift of the pre-scaled expand / projection weights
+    int ir_ce = 0;                     // ... chunk size chosen for this handle (ir_hrx3_chunk_for; 0: the kernel family's default)
     // OP_VGGB1 (VGG16 block 1 in one launch) reuses ir_off[0..3] = w1, b1, w2, b2 and ir_scale[0..1] = the two 2^-shift
 };
 
@@ -341,7 +342,10 @@ static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, 
                (RPN_KNOB("RPN_MN_X3", 1) != 0);
     op.ir_hrx3 = m->f16 && !stem && ir_block_hrx3_supported(ti.C, cexp, cout, stride, res) &&
                  (RPN_KNOB("RPN_MN_X3", 1) != 0) && (RPN_LAB_KNOB("RPN_MN_HRX3", 1) != 0);
-    if (op.ir_hrx3) op.ir_x3 = true;
+    if (op.ir_hrx3) {
+        op.ir_x3 = true;
+        op.ir_ce = ir_hrx3_chunk_for(ti.C, stride, (long long)((OW + 7) / 8) * ((OH + 3) / 4) * m->max_batch);
+    }
     op.out = add_tensor(m, name, OH, OW, cout);
     m->ops.push_back(op);
     const int oi = (int)m->ops.size() - 1;
@@ -532,7 +536,7 @@ static void plan_weights(rpn_model *m)
                                (size_t)op.cexp * coutp, coutp};
             if (op.ir_hrx3) {                                             // zero-padded fragment images: larger than the matrices
                 sizes[0] = ir_hrx3_expand_floats(op.cexp);
-                sizes[4] = ir_hrx3_project_floats(op.Cin, op.cexp, op.Cout, op.stride);
+                sizes[4] = ir_hrx3_project_floats(op.Cin, op.cexp, op.Cout, op.stride, op.ir_ce);
             }
             if (op.ir_x3) sizes[2] = ir_x3_dw_floats(op.cexp);           // depthwise taps + bias as one record per channel
             op.w_off = off;
@@ -727,7 +731,7 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
             if (op.ir_hrx3) {
                 const int sh = split_weight_shift(w.data(), w.size(), true);
                 std::vector<float> packed(ir_hrx3_expand_floats(p.Cout));
-                pack_ir_hrx3_expand(w.data(), p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                pack_ir_hrx3_expand(w.data(), p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()), op.ir_ce);
                 w.swap(packed);
                 op.ir_scale[0] = ldexpf(1.0f, -sh);
             } else if (op.ir_x3) {                         // hi + lo float16 fragments, same byte count
@@ -755,8 +759,8 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                 for (int n = 0; n < p.Cout; ++n) w[(size_t)k * coutp + n] = kernel[(size_t)k * p.Cout + n] * scale[n];
             if (op.ir_hrx3) {
                 const int sh = split_weight_shift(w.data(), w.size(), true);
-                std::vector<float> packed(ir_hrx3_project_floats(op.Cin, p.Cin, p.Cout, op.stride));
-                pack_ir_hrx3_project(w.data(), op.Cin, p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()));
+                std::vector<float> packed(ir_hrx3_project_floats(op.Cin, p.Cin, p.Cout, op.stride, op.ir_ce));
+                pack_ir_hrx3_project(w.data(), op.Cin, p.Cin, p.Cout, op.stride, sh, reinterpret_cast<unsigned short *>(packed.data()), op.ir_ce);
                 w.swap(packed);
                 op.ir_scale[1] = ldexpf(1.0f, -sh);
             } else if (op.ir_x3) {                         // (Cout % 16 == 0 for these blocks: coutp == Cout)
@@ -998,7 +1002,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
                 e = launch_ir_block_hrx3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.stride, op.ir_res, op.ir_pad, op.OH, op.OW,
                                          wb + op.ir_off[0], wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3],
                                          wb + op.ir_off[4], wb + op.ir_off[5], op.ir_scale[0], op.ir_scale[1],
-                                         tensor_ptr(m, op.out, d_imgs), m->d_status, m->d_ksplit, s);
+                                         tensor_ptr(m, op.out, d_imgs), m->d_status, m->d_ksplit, s, op.ir_ce);
             else if (op.ir_x3)
                 e = launch_ir_block_x3(x, B, op.H, op.W, op.Cin, op.cexp, op.Cout, op.ir_res, wb + op.ir_off[0],
                                        wb + op.ir_off[1], wb + op.ir_off[2], wb + op.ir_off[3], wb + op.ir_off[4],
