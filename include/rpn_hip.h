@@ -204,7 +204,11 @@ int rpn_model_set_layer(rpn_model *m, const char *name, const float *kernel, con
  * (models/rpn_vgg16.py:21).
  * A handle owns ONE activation arena and one set of inter-workgroup scratch (K-split partials and tickets): the forwards
  * of a handle must be ordered on one stream (or by events); for concurrent forwards on several streams create one handle
- * per stream (the reference's Keras model is not re-entrant either). */
+ * per stream (the reference's Keras model is not re-entrant either).
+ * Batch invariance: an image's outputs are bit-identical at every batch size B <= max_batch OF ONE HANDLE (split factors follow
+ * the grid, summation trees are fixed).  Two handles created with different max_batch may choose different weight packings
+ * (MobileNetV2 under F16X3: block 3's chunk size follows the grid at max_batch) and then agree within the float bound, not
+ * bit for bit. */
 int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float *d_reg, float *d_cls, void *stream);
 /* Sticky status flags of the forwards run so far (no reference counterpart: TF computes in float32 throughout).
  * RPN_STATUS_F16_RANGE: under RPN_PRECISION_F16X3 some activation did not fit float16 (|x| > 65504 or non-finite) when
