@@ -110,6 +110,8 @@ hipError_t launch_pw_x3(const float *x, long long P, int cin, int cout, const vo
 // expand GEMM's K is zero-padded to one 32-deep step, so the fragment images are LARGER than the float32 matrices --
 // ir_hrx3_*_floats give their sizes in floats.
 bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool residual);
+// blocks 4, 5 are supported by both f16x3 block kernels: whether this one is the faster at the handle's largest grid
+bool ir_block_hrx3_preferred(int cin, int stride, long long tiles_at_max_batch);
 size_t ir_hrx3_expand_floats(int cexp);
 // ce_ov: the block's chunk size when the model chose one (ir_hrx3_chunk_for: block 3, by the grid at the handle's max_batch);
 // 0 = the kernel family's default.  The same value must go to the packers and to the launcher.

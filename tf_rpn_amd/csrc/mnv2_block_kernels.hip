@@ -2102,7 +2102,21 @@ bool ir_block_hrx3_supported(int cin, int cexp, int cout, int stride, bool resid
     return (cin == 16 && cexp == 96 && cout == 24 && stride == 2 && !residual) ||
            (cin == 24 && cexp == 144 && cout == 24 && stride == 1 && residual) ||
            (cin == 24 && cexp == 144 && cout == 32 && stride == 2 && !residual) ||
-           (cin == 32 && cexp == 192 && cout == 64 && stride == 2 && !residual && ir_hrx3_b6() != 0);
+           (cin == 32 && cexp == 192 && cout == 64 && stride == 2 && !residual && ir_hrx3_b6() != 0) ||
+           (cin == 32 && cexp == 192 && cout == 32 && stride == 1 && residual);     // (blocks 4, 5: only where ir_block_hrx3_preferred)
+}
+
+// Blocks 4 and 5 (32 -> 192 -> 32, stride 1, residual) run on BOTH f16x3 block kernels: the 512-thread two-group pipeline with
+// its K split wins on small grids (one image: 12.0 vs 15.5 us at 500 x 500, 13.3 vs 15.7 at 1024 x 1024), this kernel's
+// 256-thread workgroups (four per CU instead of two) on large ones (batch 8, 1024 tiles: 21.9 -> 18.0 us).  The two kernels
+// sum in different orders, so -- like block 3's chunk size -- the choice is made once per model handle, from the grid at
+// its max_batch.  RPN_MN_B45HR (laboratory): 0 never, 1 always.
+bool ir_block_hrx3_preferred(int cin, int stride, long long tiles_at_max_batch)
+{
+    if (!(cin == 32 && stride == 1)) return true;
+    const int forced = RPN_LAB_KNOB("RPN_MN_B45HR", -1);
+    if (forced == 0 || forced == 1) return forced == 1;
+    return tiles_at_max_batch >= 768;
 }
 
 size_t ir_hrx3_expand_floats(int cexp) { return (size_t)32 * cexp; }                      // K padded to 32: CEXP x 128 bytes
@@ -2183,7 +2197,10 @@ hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, in
     a.tickets = scratch ? reinterpret_cast<unsigned *>(scratch + (size_t)128 * 6 * 32 * 96) : nullptr;
     const long long nb = tiles * a.ksplit;
 #define RPN_HRX3(KS_, ...) hipLaunchKernelGGL((ir_block_hrx3_kernel<__VA_ARGS__, KS_>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a)
-    if (cin == 32 && ir_hrx3_b6() == 48) {
+    if (cin == 32 && stride == 1) {                  // (blocks 4, 5 on large grids: ir_block_hrx3_preferred)
+        a.ksplit = 1;
+        hipLaunchKernelGGL((ir_block_hrx3_kernel<32, 192, 48, 32, 1, true>), dim3((unsigned)tiles), dim3(HR_THREADS), 0, s, a);
+    } else if (cin == 32 && ir_hrx3_b6() == 48) {
         if (a.ksplit == 4) RPN_HRX3(4, 32, 192, 48, 64, 2, false, 4);
         else if (a.ksplit == 2) RPN_HRX3(2, 32, 192, 48, 64, 2, false, 4);
         else RPN_HRX3(1, 32, 192, 48, 64, 2, false, 4);

@@ -341,6 +341,7 @@ static int add_irblock(rpn_model *m, const std::string &name, int in, int cexp, 
     op.ir_x3 = m->f16 && !stem && ir_block_x3_supported(ti.C, cexp, cout, stride, res) &&
                (RPN_KNOB("RPN_MN_X3", 1) != 0);
     op.ir_hrx3 = m->f16 && !stem && ir_block_hrx3_supported(ti.C, cexp, cout, stride, res) &&
+                 ir_block_hrx3_preferred(ti.C, stride, (long long)((OW + 7) / 8) * ((OH + 3) / 4) * m->max_batch) &&
                  (RPN_KNOB("RPN_MN_X3", 1) != 0) && (RPN_LAB_KNOB("RPN_MN_HRX3", 1) != 0);
     if (op.ir_hrx3) {
         op.ir_x3 = true;
