@@ -703,7 +703,8 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
     if (!rpn_head_supported(512, ncols) || P <= 0 || (P + 31) / 32 > 0x7fffffffll) return hipErrorInvalidValue;
     // a grid of fewer than 256 workgroups (one image): 16 pixels per workgroup instead of 32 -- its operand, up to four slabs of
     // 2 KB per pixel, is read at one CU's bandwidth per workgroup
-    const int MB = (P + 31) / 32 < 256 ? 1 : 2;
+    static const int mb1_max = RPN_LAB_KNOB("RPN_HEAD_MB1", 256);      // 32-pixel workgroups from this many on (16-pixel ones below)
+    const int MB = (P + 31) / 32 < mb1_max ? 1 : 2;
     const bool px4 = MB == 1 && (P + 15) / 16 <= 64 && n_slabs > 1;     // <= 64 workgroups of up to four slabs: 4 pixels each instead
     const dim3 grid((unsigned)(px4 ? (P + 3) / 4 : (P + 16 * MB - 1) / (16 * MB)));
     const int NB = (ncols + 15) / 16;

@@ -2085,7 +2085,7 @@ static int ir_hrx3_b3()
 static int ir_hrx3_ce(int cin, int stride, int ce_ov = 0)
 {
     if (ce_ov) return ce_ov;
-    return cin == 32 ? ir_hrx3_b6() : (cin == 16 ? ir_hrx3_b1() : ((cin == 24 && stride == 1) ? 48 : ir_hrx3_b3()));
+    return cin == 32 ? ir_hrx3_b6() : (cin == 16 ? ir_hrx3_b1() : ((cin == 24 && stride == 1) ? (RPN_LAB_KNOB("RPN_MN_B2CE", 48) == 16 ? 16 : 48) : ir_hrx3_b3()));
 }
 // Block 3 (24 -> 144 -> 32, stride 2) has two chunk sizes: 48 (three chunks = the tree's three leaves) on grids of at most 512
 // tiles -- one 500 x 500 or 1024 x 1024 image: 13.2 -> 12.4 us, 19.4 -> 14.7 us -- and 16 (nine chunks: more resident workgroups)
@@ -2211,6 +2211,7 @@ hipError_t launch_ir_block_hrx3(const float *x, int B, int H, int W, int cin, in
     else if (cin == 16 && ir_hrx3_b1() == 32) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 32, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (cin == 16 && ir_hrx3_b1() == 48) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 48, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (cin == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<16, 96, 16, 24, 2, false>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
+    else if (stride == 1 && ir_hrx3_ce(cin, stride, ce_ov) == 16) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 16, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((ir_block_hrx3_kernel<24, 144, 48, 24, 1, true>), dim3((unsigned)nb), dim3(HR_THREADS), 0, s, a);
     else if (ir_hrx3_ce(cin, stride, ce_ov) == 48) { if (a.ksplit == 3) RPN_HRX3(3, 24, 144, 48, 32, 2, false, 3); else RPN_HRX3(1, 24, 144, 48, 32, 2, false, 3); }
     else if (a.ksplit == 3) RPN_HRX3(3, 24, 144, 16, 32, 2, false, 3);
