@@ -250,6 +250,28 @@ def test_mobilenet_v2_batch_invariance_across_ksplit_factors(img, fm):
     assert np.abs(reg[:1].cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls[:1].cpu().numpy() - ref[1]).max() <= 1e-4
 
 
+def test_mobilenet_v2_handles_of_different_max_batch_agree_within_the_bound():
+    """Kernel choices that change the summation order are made ONCE PER HANDLE, from the grid at its max_batch (block 3's
+    chunk size, blocks 4-5 on the 256-thread or the 512-thread block kernel): every batch size of one handle gives the same
+    bits (test above), two handles of different max_batch agree within the float bound, not necessarily bit for bit -- the
+    contract include/rpn_hip.h states.  Both stay within 1e-4 of the float64 oracle."""
+    hp = bo.get_hyper_params("mobilenet_v2")
+    weights = synthetic_weights("mobilenet_v2", hp, seed=2)
+    imgs = torch.rand((1, 500, 500, 3), generator=torch.Generator().manual_seed(3)).cuda()
+    outs = []
+    for mb in (1, 8):
+        model = RPNModel("mobilenet_v2", hp, precision="f16x3", max_batch=mb)
+        model.set_weights(weights)
+        reg, cls = model.predict_on_batch(imgs)
+        outs.append((reg.clone(), cls.clone()))
+        kernels = {op["name"]: op["kernel"] for op in model.ops()}
+        assert ("hr_f16x3" in kernels["block_4_project"]) == (mb == 8), kernels["block_4_project"]
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2e-5 and (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-5
+    ref = cv.rpn_forward("mobilenet_v2", imgs.cpu().numpy(), weights, dtype=torch.float64)
+    for reg, cls in outs:
+        assert np.abs(reg.cpu().numpy() - ref[0]).max() <= 1e-4 and np.abs(cls.cpu().numpy() - ref[1]).max() <= 1e-4
+
+
 @pytest.mark.parametrize("backbone,precision", [("mobilenet_v2", "f16x3"), ("vgg16", "f16x3"), ("vgg16", "bf16x3")])
 def test_rpn_conv_k_tree_same_bits_at_every_split_factor(backbone, precision):
     """rpn_conv in the split-precision modes is a K TREE: four fixed leaves of K, value (l0 + l1) + (l2 + l3).  One image
