@@ -104,6 +104,14 @@ struct NmsArgs {
     unsigned *cl_ctl;
     unsigned long long *cl_band;
     // area pruning of the tests against the boxes selected in earlier chunks (prune_bin): 0 = off
+    int band1_mult;          // first band = band1_mult x the boxes wanted: 5 (round 3: 3).  On a conv head's outputs -- smooth score
+                             // fields, heavily overlapping boxes: ~2 900 candidates visited for 300 boxes on the bench model's --
+                             // the walk then finishes inside the first band instead of paying a second select + order pass (83 ->
+                             // 73 us at batch 8, IoU 0.7); on configs[2]'s spread-out permutation scores the larger band costs 1 %
+    int band1_sat;           // ... but band1_sat x (3) on a SATURATED head (band_select_linear: >= 128 scores in the top bin --
+                             // MobileNetV2's random-init heads: 330 scores >= 0.9995 of 9 216): ordering a large band of equal scores
+                             // costs more than a second band (one 500 x 500 image 61.9 -> 64.3 us, configs[4] in cluster mode 56.8 ->
+                             // 97.6 us with 5 x); the cluster path always takes 3 x
     int prune;
     float prune_lo, prune_hi;   // a pair can only pass the IoU test if area_a * prune_lo <= area_b <= area_a * prune_hi
 };
@@ -281,7 +289,7 @@ __device__ __forceinline__ int linear_sub_bin(float s, int d) { return (int)fmin
 
 __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
                                           unsigned long long hi_bound, int want, int cap, unsigned *hist, int *ctl,
-                                          unsigned long long *thr_out, int *count, int *bin_out)
+                                          unsigned long long *thr_out, int *count, int *bin_out, int want_sat = 0, int cap_sat = 0)
 {
     constexpr int NB = 2048;
     const int tid = fresh_tid();
@@ -311,6 +319,13 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
     }
     __syncthreads();
     if (fill) sc.cached = true;
+    // The alternative band size for a SATURATED head -- the top bin (scores >= 2047 / 2048) alone holds 128 candidates or more:
+    // hundreds of equal or nearly equal scores make a large band expensive to order (ranked by counting inside a sub-bin), so such
+    // heads keep the small first band.  (workgroup-uniform: every thread reads the same word)
+    if (want_sat > 0 && hist[NB - 1] >= 128u) {
+        want = want_sat;
+        cap = cap_sat;
+    }
     hist_suffix_find(hist, hist + 4096, want, ctl, reinterpret_cast<unsigned *>(ctl) + 12);
     __syncthreads();
     const int d = ctl[0], n = ctl[1];
@@ -791,7 +806,7 @@ nms_kernel(NmsArgs p)
         // threshold, clustered boxes -- takes 2 bands instead of 4; up to what the histogram ordering handles (2 keys
         // per thread).  A band that is too large costs little: its chunks are only built as far as the walk gets.
         const int by_yield = (int)min((long long)want_left * visited / max(have - have_before, 1) * 2, 1792ll);
-        const int band_target = visited == 0 ? min(kBandTarget, max(512, 3 * want_left)) : max(512, by_yield);
+        const int band_target = visited == 0 ? min(min(kBandTarget, 1792), max(512, p.band1_mult * want_left)) : max(512, by_yield);
         have_before = have;
         const int band_cap = band_target <= 960 ? 1024 : kBandCap;
         unsigned long long thr = 0ull;
@@ -803,7 +818,8 @@ nms_kernel(NmsArgs p)
             lin_bin = cl_bin;
         } else if (!p.linear_select ||
             !band_select_linear(src, N, p.score_thr, hi_bound, band_target, band_cap, hist, ctl + CTL_SEL, &thr, &band_expected,
-                                &lin_bin)) {
+                                &lin_bin, visited == 0 ? max(512, p.band1_sat * want_left) : 0,
+                                max(512, p.band1_sat * want_left) <= 960 ? 1024 : kBandCap)) {
             lin_bin = -1;
             thr = radix_select<kNmsThreads>([&](int i) { return make_key(src(i), p.score_thr, i); }, N, hi_bound,
                                             band_target, band_cap, hist, ctl + CTL_SEL, &band_expected);
@@ -1371,6 +1387,12 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     p.cluster = cluster_size(p.B * p.C, p.N);
     if (p.cluster > 1 && (!d_workspace || workspace_bytes < stage_bytes(p.B, p.C, p.max_sel) + cluster_bytes(p.B * p.C, p.cluster, p.N)))
         p.cluster = 1;
+    // first band: 5 x the boxes wanted, 3 x on a saturated head (NmsArgs::band1_mult / band1_sat)
+    {
+        static const int b1 = RPN_LAB_KNOB("RPN_NMS_BAND1", 5), bs = RPN_LAB_KNOB("RPN_NMS_BAND1SAT", 3);    // (A/B timing)
+        p.band1_mult = b1 > 0 ? b1 : 5;
+        p.band1_sat = bs;
+    }
     // area pruning: a threshold in [0.3, 1) (a candidate's run of area bins is then at most 18 of the 64) on the fast test path
     static const int prune = RPN_KNOB("RPN_NMS_PRUNE", 1);
     p.prune = prune && fast && p.iou_thr >= 0.3f && p.iou_thr < 1.0f && lds_layout(p.max_sel, 0, 1).total <= kLdsLimit;
