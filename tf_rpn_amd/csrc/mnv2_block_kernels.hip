@@ -1829,7 +1829,14 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
     static_assert((NLEAF == 1 || NLEAF == 3 || NLEAF == 4) && NCHUNK % NLEAF == 0, "projection tree");
     constexpr int LEAFC = NCHUNK / NLEAF;                                 // chunks per leaf
-    __shared__ __attribute__((aligned(16))) float Es[MH * SEP];
+    // Halo-row pitch of the E -> D image.  With 48-channel chunks a 32-lane read group of the depthwise covers channels 32 .. 47 of
+    // one pixel group and 0 .. 15 of the next, one halo ROW further on: at the natural pitch that is IW * SEP * S = 520 | 1768 floats
+    // = 8 banks (mod 32) away -- half of the group's lanes collide (15 % of these instantiations' LDS cycles, round 4 counters).
+    // A pitch of 12 | 18 pixels makes it 16 banks: conflict-free.  The E side writes through per-lane row offsets (eoff).
+    constexpr int IWP = CE == 48 ? (S == 1 ? 12 : 18) : IW;
+    constexpr int ES_ROWS = IWP == IW ? MH : ((MH + IW - 1) / IW) * IWP;
+    static_assert(IWP >= IW, "pitch");
+    __shared__ __attribute__((aligned(16))) float Es[ES_ROWS * SEP];
     __shared__ u32x4 DsF[2 * KSP * 2 * 64];                               // [mb 2][ks][hi|lo][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1859,6 +1866,8 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     // ---- A operand of the expand GEMM: this wave's halo pixels (M-blocks wave, wave + 4, ...) as hi / lo fragments ----------
     u32x4 xh[MBW], xl[MBW];
     float vmul[MBW * 4];                 // 1 where this lane's expand output (row 4 lk + i of M-block mbi) is a pixel of the image, else 0
+    int eoff[IWP == IW ? 1 : MBW * 4];   // (padded pitch only) Es offset of that output's halo pixel
+    (void)eoff;
 #pragma unroll
     for (int mbi = 0; mbi < MBW; ++mbi) {
         const int m = (wave + 4 * mbi) * 16 + lr;
@@ -1887,6 +1896,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
             const int mo = (wave + 4 * mbi) * 16 + 4 * lk + i;
             const int oy = mo / IW, ox = mo - oy * IW;
             vmul[mbi * 4 + i] = (mo < NH && gy0 + oy >= 0 && gy0 + oy < a.H && gx0 + ox >= 0 && gx0 + ox < a.W) ? 1.0f : 0.0f;
+            if constexpr (IWP != IW) eoff[mbi * 4 + i] = (oy * IWP + ox) * SEP;
         }
     }
     const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
@@ -1920,7 +1930,8 @@ ir_block_hrx3_kernel(IrHrX3Args a)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             // (* 1 or * 0: ReLU6's output is finite and >= 0, so the product is the value itself or +0)
-                            Es[(mb * 16 + 4 * lk + i) * SEP + nb * 16 + lr] = relu6f(e[i] * a.scale_e + be_r[nb]) * vmul[mbi * 4 + i];
+                            Es[(IWP == IW ? (mb * 16 + 4 * lk + i) * SEP : eoff[mbi * 4 + i]) + nb * 16 + lr] =
+                                relu6f(e[i] * a.scale_e + be_r[nb]) * vmul[mbi * 4 + i];
                     }
                 }
             }
@@ -1947,7 +1958,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int x = 0; x < WW; ++x) win[r][x] = Es[((py * S + r) * IW + dx0 * S + x) * SEP + dc];
+                    for (int x = 0; x < WW; ++x) win[r][x] = Es[((py * S + r) * IWP + dx0 * S + x) * SEP + dc];
 #pragma unroll
                 for (int px = 0; px < DCOLS; ++px) {
                     float acc = wd_r[9];
