@@ -1829,11 +1829,11 @@ ir_block_hrx3_kernel(IrHrX3Args a)
     static_assert(!RES || (S == 1 && CIN == COUT), "residual needs stride 1 and Cin == Cout");
     static_assert((NLEAF == 1 || NLEAF == 3 || NLEAF == 4) && NCHUNK % NLEAF == 0, "projection tree");
     constexpr int LEAFC = NCHUNK / NLEAF;                                 // chunks per leaf
-    // Halo-row pitch of the E -> D image.  With 48-channel chunks a 32-lane read group of the depthwise covers channels 32 .. 47 of
-    // one pixel group and 0 .. 15 of the next, one halo ROW further on: at the natural pitch that is IW * SEP * S = 520 | 1768 floats
-    // = 8 banks (mod 32) away -- half of the group's lanes collide (15 % of these instantiations' LDS cycles, round 4 counters).
-    // A pitch of 12 | 18 pixels makes it 16 banks: conflict-free.  The E side writes through per-lane row offsets (eoff).
-    constexpr int IWP = CE == 48 ? (S == 1 ? 12 : 18) : IW;
+    // Halo-row pitch of the E -> D image (IWP > IW: a padded pitch, E then writes through per-lane row offsets `eoff`).  Tried for the
+    // 48-channel chunks, whose depthwise lane groups used to straddle two pixel groups one halo row apart (8 banks mod 32: 15 % of
+    // those instantiations' LDS cycles): a pitch of 12 | 18 pixels fixed the reads and broke the E writes of rows that cross a halo
+    // row (12.4 %).  The depthwise mapping below (one pixel group per WAVE, 48 of its 64 lanes active) removes the straddle instead.
+    constexpr int IWP = IW;
     constexpr int ES_ROWS = IWP == IW ? MH : ((MH + IW - 1) / IW) * IWP;
     static_assert(IWP >= IW, "pitch");
     __shared__ __attribute__((aligned(16))) float Es[ES_ROWS * SEP];
@@ -1899,7 +1899,9 @@ ir_block_hrx3_kernel(IrHrX3Args a)
             if constexpr (IWP != IW) eoff[mbi * 4 + i] = (oy * IWP + ox) * SEP;
         }
     }
-    const int dc = tid % CE, dg = tid / CE;                              // depthwise: channel, pixel group
+    // depthwise: channel, pixel group.  CE = 48: one group per wave (lanes 48 .. 63 idle) -- with tid / 48 a 32-lane LDS read group
+    // covered the tail of one pixel group and the head of the next
+    const int dc = CE == 48 ? (tid & 63) : tid % CE, dg = CE == 48 ? (tid >> 6) : tid / CE;
     const int dy0 = (dg * PXG) / HR_T, dx0 = (dg * PXG) % HR_T;
     f32x4 pacc[NJ];
     f32x4 tsum[NLEAF > 1 ? NJ : 1], usum[NLEAF == 4 ? NJ : 1];          // the tree so far; leaf 2 of a four-leaf tree
@@ -1939,7 +1941,7 @@ ir_block_hrx3_kernel(IrHrX3Args a)
         __syncthreads();
         HR_STAMP(HRV, 2 + 3 * c);
         // ---- D(c): depthwise 3x3 + bias + ReLU6 (float32), hi / lo float16 into the projection's A image ---------------------
-        if (dg < DG) {
+        if (dg < DG && dc < CE) {
             float wd_r[10];                  // one 48-byte record per channel (pack_ir_x3_dw): three 16-byte loads instead of ten 4-byte ones
             {
                 const float4 *rec = reinterpret_cast<const float4 *>(a.wd) + ((size_t)c * CE + dc) * 3;
