@@ -73,6 +73,23 @@ class Proposer(object):
         if self.overlap_nms:
             import os
             self._nms_stream = torch.cuda.Stream()
+            # Hardware-queue ordering (measured): an RCCL communicator created (eagerly, with device_id) BEFORE this
+            # side stream has run anything takes the hardware queues first, and the NMS stream then shares a queue with the conv
+            # stream -- the NMS / conv overlap disappears (3.25 vs 3.05 ms per step).  So both streams run a trivial operation
+            # here, at construction: a process group initialised after the Proposer exists cannot get in between.  When one
+            # exists already there is nothing to repair from here: say so once.
+            with torch.cuda.stream(self._nms_stream):
+                self._valid.zero_()
+            torch.cuda.current_stream().wait_stream(self._nms_stream)
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                    import warnings
+                    warnings.warn("tf_rpn_amd.Proposer(overlap_nms=True) created AFTER the RCCL process group: the NMS side stream "
+                                  "may share a hardware queue with the conv stream (no overlap).  Create the Proposer first, then "
+                                  "call init_process_group (bench.py does).", RuntimeWarning, stacklevel=2)
+            except Exception:
+                pass
             # "go" handshake (speed only; RPN_NMS_HANDSHAKE=0 turns it off for A/B runs): the conv stack of batch k+1
             # is ordered behind the side stream's WAIT for batch k's head outputs, so that the NMS workgroups (1024
             # threads x 127 VGPRs: each needs a CU to itself) are dispatched at the kernel boundary, while the CUs are
