@@ -129,6 +129,27 @@ def test_propose_is_graph_capturable():
             assert torch.equal(o, w)
 
 
+def test_proposer_pool_matches_a_single_proposer():
+    """Two pipelines in flight (ProposerPool): every batch of a sequence gives the proposals a single Proposer gives, bit for bit
+    (each pipeline is a Proposer of its own; only the overlap on the device differs)."""
+    from tf_rpn_amd.predictor import ProposerPool
+    hp = dict(bo.get_hyper_params("mobilenet_v2", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("mobilenet_v2", hp, seed=5)
+    single = Proposer("mobilenet_v2", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    pool = ProposerPool(2, "mobilenet_v2", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    gen = torch.Generator().manual_seed(9)
+    seq = [torch.rand((2, 160, 160, 3), generator=gen).cuda() for _ in range(4)]
+    want = [[t.clone() for t in single.propose(x)] for x in seq]
+    got = [pool.propose_async(x) for x in seq]         # two pipelines x two output slots each: all four stay intact
+    pool.wait()
+    torch.cuda.synchronize()
+    for k in range(len(seq)):
+        for g, w in zip(got[k], want[k]):
+            assert torch.equal(g, w), k
+    for g, w in zip(pool.propose(seq[1]), want[1]):
+        assert torch.equal(g, w)
+
+
 def test_pipelined_distributed_path_world1():
     """The N > 1 code path (record packing + all-gather one step behind the convs) on a world-size-1 RCCL group:
     gathered records must equal the serial proposals, in order, including the flushed last batch."""
