@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "librpn_oracle.so")
+_SO = os.environ.get("RPN_ORACLE_SO") or os.path.join(_HERE, "_build", "librpn_oracle.so")   # (env: the sanitizer build)
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -22,7 +22,7 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 def build(force=False):
     src = os.path.join(_HERE, "rpn_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["san"] if _SO.endswith("_san.so") else []))
     return _SO
 
 

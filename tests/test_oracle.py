@@ -287,3 +287,26 @@ def test_nms_restatements_against_recalled_tf_unit_test_vectors(impl):
         ob, osc, oc, ov, _oi = run(boxes, scores, per_class, total, iou, thr, clip)
         assert int(ov[0]) == wv, name
         assert np.array_equal(ob[0], wb) and np.array_equal(osc[0], ws) and (oc[0] == 0).all(), name
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """The plain-C restatement is the checker of every GPU parity test: run this module's tests again in a child process on an
+    AddressSanitizer + UBSan build of oracle/rpn_oracle.c (``make -C oracle san``; libasan preloaded into the child's python), so
+    that an out-of-bounds read or signed overflow in the CHECKER cannot pass as agreement.  (Sanitizers run on the CPU build only;
+    the GPU pool has no ASan.)"""
+    import subprocess
+    import sys
+    if os.environ.get("RPN_ORACLE_SO"):
+        pytest.skip("already inside the sanitizer child")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan for this gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "san"])
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               RPN_ORACLE_SO=os.path.join(root, "oracle", "_build", "librpn_oracle_san.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " passed" in r.stdout and "1 skipped" in r.stdout, r.stdout[-500:]
