@@ -518,9 +518,11 @@ stem_block_kernel(IrArgs a)
     constexpr int SEP = 36, SD = 34;                                      // row strides of Es / Ds (see ir_block_kernel)
     constexpr int KS = 7;                                                 // k-steps of Conv1 (K = 27 -> 28)
     static_assert(ST_TH == 8 || ST_TH == 4, "tile");
-    constexpr int XD_FLOATS = PR * PSTR > ST_TH * ST_TW * SD ? PR * PSTR : ST_TH * ST_TW * SD;
-    __shared__ __attribute__((aligned(16))) float XD[XD_FLOATS];          // the image patch, then Ds
-    __shared__ __attribute__((aligned(16))) float Es[MB * 16 * SEP];
+    // Ds overlays Es (every depthwise thread holds its 3 x 18 window in registers before the first Ds element is written: one more
+    // barrier), so that the workgroup needs 37 KB instead of 45: FOUR workgroups per CU instead of three (registers allow four)
+    constexpr int ES_FLOATS = MB * 16 * SEP > ST_TH * ST_TW * SD ? MB * 16 * SEP : ST_TH * ST_TW * SD;
+    __shared__ __attribute__((aligned(16))) float XD[PR * PSTR];          // the image patch
+    __shared__ __attribute__((aligned(16))) float Es[ES_FLOATS];          // Conv1's outputs on the halo, then Ds
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -621,18 +623,19 @@ stem_block_kernel(IrArgs a)
                 e[16] = in ? relu6f(eacc[mbi][1][i] + be1) : 0.0f;
             }
     }
-    __syncthreads();                                                      // Es complete; the patch is dead
+    __syncthreads();                                                      // Es complete
 
     // ---- D: depthwise 3x3 + bias + ReLU6: thread = (channel dc, output row dg), 16 outputs ----------------------------
 #ifndef RPN_EXP_STEM_NOD
     {
         const float *es = Es + (drow * IW + dcol0) * SEP + dc;
-        float *ds = XD + (drow * ST_TW + dcol0) * SD + dc;
+        float *ds = Es + (drow * ST_TW + dcol0) * SD + dc;
         float win[3][DPX + 2];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int x = 0; x < DPX + 2; ++x) win[r][x] = es[(r * IW + x) * SEP];
+        __syncthreads();                                                  // all windows are in registers: Ds may overwrite Es
 #pragma unroll
         for (int px = 0; px < DPX; ++px) {
             float acc = wd_r[9];
@@ -655,7 +658,7 @@ stem_block_kernel(IrArgs a)
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-            for (int mbi = 0; mbi < PMW; ++mbi) pa[kk][mbi] = XD[((PMW * wave + mbi) * 16 + lr) * SD + 4 * kk + lk];
+            for (int mbi = 0; mbi < PMW; ++mbi) pa[kk][mbi] = Es[((PMW * wave + mbi) * 16 + lr) * SD + 4 * kk + lk];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
