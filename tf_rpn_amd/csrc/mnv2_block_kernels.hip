@@ -507,7 +507,7 @@ constexpr int ST_TW = 16, ST_THREADS = 256;
 // ST_TH x 16 output pixels per workgroup: 8 (45 KB of LDS, three workgroups per CU) or 4 (25 KB, six; 1.7x instead of 1.4x
 // redundant Conv1 work on the halo, but twice the resident workgroups to cover the phases' round trips).
 template <int ST_TH>
-__global__ void __launch_bounds__(ST_THREADS)
+__global__ void __launch_bounds__(ST_THREADS, ST_TH == 8 ? 5 : 1)
 stem_block_kernel(IrArgs a)
 {
     constexpr int IH = ST_TH + 2, IW = ST_TW + 2, NH = IH * IW;          // halo on Conv1's grid: 10 x 18 = 180 | 6 x 18 = 108 pixels
@@ -521,8 +521,9 @@ stem_block_kernel(IrArgs a)
     // Ds overlays Es (every depthwise thread holds its 3 x 18 window in registers before the first Ds element is written: one more
     // barrier), so that the workgroup needs 37 KB instead of 45: FOUR workgroups per CU instead of three (registers allow four)
     constexpr int ES_FLOATS = MB * 16 * SEP > ST_TH * ST_TW * SD ? MB * 16 * SEP : ST_TH * ST_TW * SD;
-    __shared__ __attribute__((aligned(16))) float XD[PR * PSTR];          // the image patch
-    __shared__ __attribute__((aligned(16))) float Es[ES_FLOATS];          // Conv1's outputs on the halo, then Ds
+    static_assert(PR * PSTR <= ES_FLOATS, "the patch fits under Es");
+    __shared__ __attribute__((aligned(16))) float Es[ES_FLOATS];          // the image patch, then Conv1's outputs on the halo, then Ds
+    float *const XD = Es;                                                  // (the patch is dead once E's gathers are in registers)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -600,6 +601,7 @@ stem_block_kernel(IrArgs a)
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int mbi = 0; mbi < MBW; ++mbi) av[kk][mbi] = XD[xbase[mbi] + xoff[kk]];     // all 21 gathers in flight
+        __syncthreads();                                                  // every gather has landed: Es may overwrite the patch
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
