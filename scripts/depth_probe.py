@@ -1,5 +1,5 @@
 """Throughput of D independent proposal pipelines (each its own model handle, conv stream and NMS side stream) fed alternately:
-does a second / third single-image step in flight fill the chip?  usage: python scripts/depth_probe.py [c1|c5|b8|vgg1] ..."""
+does a second / third single-image step in flight fill the chip?  usage: python scripts/depth_probe.py [c1|c5|b8|vgg1|vgg8] ..."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from tf_rpn_amd.utils import train_utils
 hp_c5 = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64, anchor_ratios=[1., 2., .5, 3., 1. / 3.]))
 hp_mn = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=500, feature_map_shape=32, anchor_ratios=[1., 2., .5]))
 hp_vgg = dict(train_utils.get_hyper_params("vgg16"))
-cfgs = {"c1": ("mobilenet_v2", hp_mn, 1), "c5": ("mobilenet_v2", hp_c5, 1), "b8": ("mobilenet_v2", hp_mn, 8), "vgg1": ("vgg16", hp_vgg, 1)}
+cfgs = {"c1": ("mobilenet_v2", hp_mn, 1), "c5": ("mobilenet_v2", hp_c5, 1), "b8": ("mobilenet_v2", hp_mn, 8), "vgg1": ("vgg16", hp_vgg, 1), "vgg8": ("vgg16", hp_vgg, 8)}
 for tag in (sys.argv[1:] or ["c1", "c5"]):
     bb, hp, B = cfgs[tag]
     w = synthetic_weights(bb, hp, seed=1)
