@@ -580,6 +580,36 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
                          "launches_per_step": tot[dom][2], "avg_launch_ms": round(tot[dom][0] / tot[dom][2], 4)}}
 
 
+def pool_leg(backbone, hp, weights, B, precision, iou_threshold, imgs, steps, warmup, in_flight=2):
+    """The same `steps` steps over `in_flight` independent pipelines fed round robin (predictor.ProposerPool: each its own model
+    handle and streams): the second batch's kernels fill the CUs the first leaves idle (the small kernels of a MobileNetV2 step;
+    VGG16 at batch 8, whose persistent layers own whole CUs, does not gain: 2 888 vs 2 928 images/s, scripts/depth_probe.py vgg8).  Reported BESIDE the one-pipeline figure, which keeps its meaning from earlier
+    rounds -- and its per-kernel roofline: under two pipelines a kernel's start-to-end time includes waiting for the other
+    pipeline's workgroups to leave the CUs."""
+    import torch
+
+    from tf_rpn_amd.predictor import ProposerPool
+    pool = ProposerPool(in_flight, backbone, hyper_params=hp, weights=weights, precision=precision, max_batch=B,
+                        iou_threshold=iou_threshold)
+    for _ in range(warmup):
+        pool.propose_async(imgs)
+    pool.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pool.propose_async(imgs)
+    pool.wait()
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t0
+    res = {"value": round(B * steps / dt2, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / steps, 4), "steps": steps,
+           "checks": {"f16_range": any(bool(q.rpn_model.status(reset=False)["f16_range"]) for q in pool.pipelines)
+                      if precision == "f16x3" else False,
+                      "valid_min": min(int(q._last["valid"][:B].min().item()) for q in pool.pipelines)}}
+    del pool
+    torch.cuda.empty_cache()
+    return res
+
+
 def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmup=3, in_flight=0):
     """One of the other BASELINE.json configs at its per-GPU batch, in this same run: whole hot path (conv stack ->
     head -> decode -> NMS(300), NMS of step k overlapped with the convs of step k+1), synthetic images and weights of
@@ -629,29 +659,8 @@ def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmu
            "ms_per_image": round(1e3 * dt / steps / B, 4), "latency_ms_one_step_unpipelined": round(lat[len(lat) // 2], 4),
            "steps": steps, "dtype": precision, "conv_launches_per_step": n_launches, "checks": leg_checks}
     if in_flight > 1:
-        # the same `steps` steps over `in_flight` independent pipelines fed round robin (ProposerPool: each its own model handle
-        # and streams): a second batch's small kernels fill the CUs the first leaves idle.  Reported BESIDE the one-pipeline
-        # figure above, which keeps its meaning from earlier rounds.
-        from tf_rpn_amd.predictor import ProposerPool
-        pool = ProposerPool(in_flight, backbone, hyper_params=hp, weights=weights, precision=precision, max_batch=B,
-                            iou_threshold=iou_threshold)
-        for _ in range(max(warmup, 2 * in_flight)):
-            pool.propose_async(imgs)
-        pool.wait()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            pool.propose_async(imgs)
-        pool.wait()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        out["pipelines_in_flight_%d" % in_flight] = {
-            "value": round(B * steps / dt2, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / steps, 4), "steps": steps,
-            "checks": {"f16_range": any(bool(q.rpn_model.status(reset=False)["f16_range"]) for q in pool.pipelines)
-                       if precision == "f16x3" else False,
-                       "valid_min": min(int(q._last["valid"][:B].min().item()) for q in pool.pipelines)}}
-        del pool
-        torch.cuda.empty_cache()
+        out["pipelines_in_flight_%d" % in_flight] = pool_leg(backbone, hp, weights, B, precision, iou_threshold, imgs, steps,
+                                                             max(warmup, 2 * in_flight), in_flight)
     del imgs
     return out
 

@@ -76,6 +76,11 @@ int rpn_abi_version(void);
 const char *rpn_last_error(void);
 /* number of visible HIP devices (0 when there is none); never fails */
 int rpn_device_count(void);
+/* Stream diagnostic: enqueue ONE wave on `stream` that sleeps for `microseconds` (0 .. 10000) of the device's real-time counter.
+ * HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); two streams that share a queue run one behind
+ * the other.  The predictor loop (predictor.py:46-60 restated with the NMS of batch k beside the convs of batch k + 1) needs its
+ * two streams on DIFFERENT queues: spin both and compare the elapsed time (tf_rpn_amd/predictor.py: _streams_overlap). */
+int rpn_stream_spin(void *stream, int microseconds);
 
 /* ------------------------------------------------------------------------------------
  * generate_anchors(hyper_params) -> (A,4)            utils/bbox_utils.py:23-46 (+ :3-21)

@@ -129,6 +129,27 @@ def test_propose_is_graph_capturable():
             assert torch.equal(o, w)
 
 
+def test_side_stream_runs_beside_the_conv_stream_whatever_was_created_before():
+    """HIP maps streams onto four hardware queues in creation order (the default stream's included): a Proposer created after a
+    few other streams used to get an NMS stream that SHARED the conv stream's queue -- same results, no overlap, 35 % slower at
+    one image.  The Proposer now tests its side stream (rpn_stream_spin: one sleeping wave per stream) and draws another."""
+    from tf_rpn_amd import predictor as P
+    cur = torch.cuda.current_stream()
+    scrambled = [torch.cuda.Stream() for _ in range(7)]              # whatever the process created before
+    for s in scrambled:
+        P._streams_overlap(cur, s)
+    shared = [s for s in scrambled if not P._streams_overlap(cur, s)]
+    hp = dict(bo.get_hyper_params("mobilenet_v2", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("mobilenet_v2", hp, seed=5)
+    for _ in range(3):                                               # three in a row: each draws from torch's pool where the last stopped
+        prop = Proposer("mobilenet_v2", hyper_params=dict(hp), weights=weights, max_batch=1, precision="f16x3", overlap_nms=True)
+        assert P._streams_overlap(cur, prop._nms_stream)
+    if shared:                                                       # the probe itself tells the two cases apart
+        assert not P._streams_overlap(cur, shared[0])
+    with pytest.raises(ValueError):
+        P.L.check(P.L.lib().rpn_stream_spin(P.L.vp(cur.cuda_stream), 20000), "rpn_stream_spin")
+
+
 def test_proposer_pool_matches_a_single_proposer():
     """Two pipelines in flight (ProposerPool): every batch of a sequence gives the proposals a single Proposer gives, bit for bit
     (each pipeline is a Proposer of its own; only the overlap on the device differs)."""

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "rpn_abi_version": (ctypes.c_int, []),
     "rpn_last_error": (ctypes.c_char_p, []),
     "rpn_device_count": (ctypes.c_int, []),
+    "rpn_stream_spin": (ctypes.c_int, [vp, ctypes.c_int]),
     "rpn_generate_anchors": (ctypes.c_int, [ctypes.c_double, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
                                             ctypes.c_int, vp, vp]),
     "rpn_decode": (ctypes.c_int, [vp, ctypes.c_int, vp, c_float_p, ctypes.c_int, ctypes.c_int, vp, vp]),

@@ -18,12 +18,52 @@ from . import _lib as L
 from .utils import bbox_utils, train_utils
 
 
+def _streams_overlap(a, b, microseconds=200):
+    """True when work on HIP streams ``a`` and ``b`` runs CONCURRENTLY.  HIP maps streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, default 4, the default stream's included) in creation order -- measured (scripts/queue_probe.py): of ten
+    streams {0, 7}, {1, 6}, {2, 5, 9} and {3, 4, 8} share one -- so whether two streams share a queue depends on what else the
+    process has created; on a shared queue the NMS of batch k would run BEHIND the convs of batch k + 1 instead of beside them,
+    silently.  One sleeping wave on each stream (rpn_stream_spin): beside each other they take ~1x, behind each other ~2x."""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    L.check(L.lib().rpn_stream_spin(L.vp(a.cuda_stream), microseconds), "rpn_stream_spin")
+    L.check(L.lib().rpn_stream_spin(L.vp(b.cuda_stream), microseconds), "rpn_stream_spin")
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) < 1.5e-6 * microseconds + 30e-6
+
+
+def _concurrent_side_stream(must=None, should=(), tries=8):
+    """A new stream that runs beside stream ``must`` (default: the current stream) and, if one of ``tries`` candidates does, beside
+    every stream of ``should`` as well (torch hands out pooled streams round robin; each is tested with _streams_overlap).
+    RuntimeWarning when no candidate runs beside ``must`` (e.g. GPU_MAX_HW_QUEUES=1): results stay correct, the overlap is lost."""
+    must = must if must is not None else torch.cuda.current_stream()
+    best, best_n = None, -1
+    for _ in range(tries):
+        s = torch.cuda.Stream()
+        _streams_overlap(must, s)                                           # (a stream's first launch is slow: not judged)
+        if not _streams_overlap(must, s):
+            if best is None:
+                best, best_n = s, -1
+            continue
+        n = sum(1 for o in should if _streams_overlap(o, s))
+        if n == len(should):
+            return s
+        if n > best_n:
+            best, best_n = s, n
+    if best_n < 0:
+        import warnings
+        warnings.warn("tf_rpn_amd: no side stream runs concurrently with the conv stream (hardware queues shared: "
+                      "GPU_MAX_HW_QUEUES?); the NMS / conv overlap is lost, results are unaffected", RuntimeWarning, stacklevel=3)
+    return best
+
+
 class Proposer(object):
     """anchors once (predictor.py:46), then ``propose(imgs)`` per batch."""
 
     def __init__(self, backbone="vgg16", hyper_params=None, weights="synthetic", precision="f32",
                  max_batch=8, iou_threshold=0.7, score_threshold=float("-inf"), seed=1, overlap_nms=False,
-                 check_range=True):
+                 check_range=True, avoid_streams=()):
         if backbone == "mobilenet_v2":
             from .models.rpn_mobilenet_v2 import get_model
         else:
@@ -72,7 +112,7 @@ class Proposer(object):
         self.overlap_nms = bool(overlap_nms)
         if self.overlap_nms:
             import os
-            self._nms_stream = torch.cuda.Stream()
+            self._nms_stream = _concurrent_side_stream(should=tuple(avoid_streams))
             # Hardware-queue ordering (measured): an RCCL communicator created (eagerly, with device_id) BEFORE this
             # side stream has run anything takes the hardware queues first, and the NMS stream then shares a queue with the conv
             # stream -- the NMS / conv overlap disappears (3.25 vs 3.05 ms per step).  So both streams run a trivial operation
@@ -348,8 +388,17 @@ class ProposerPool(object):
         if n < 1:
             raise ValueError("ProposerPool needs n >= 1 pipelines")
         kwargs["overlap_nms"] = True
-        self.pipelines = [Proposer(*args, **kwargs) for _ in range(int(n))]
-        self.streams = [torch.cuda.Stream() for _ in range(int(n))]
+        # every pipeline's conv stream and NMS side stream on hardware queues of their own where the device has them (four by
+        # default: exactly two pipelines' worth) -- each new stream is tested against the ones already taken
+        self.pipelines, self.streams, taken = [], [], []
+        for _ in range(int(n)):
+            s = _concurrent_side_stream(must=taken[0] if taken else None, should=tuple(taken))
+            with torch.cuda.stream(s):
+                p = Proposer(*args, avoid_streams=tuple(taken), **kwargs)
+            torch.cuda.current_stream().wait_stream(s)
+            self.pipelines.append(p)
+            self.streams.append(s)
+            taken += [s, p._nms_stream]
         self._ready = [torch.cuda.Event() for _ in range(int(n))]
         self._k = 0
         p0 = self.pipelines[0]
