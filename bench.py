@@ -837,6 +837,9 @@ def main():
     if overlap and use_dist:
         prop.flush_distributed(gather_bufs)
     torch.cuda.synchronize()
+    # the communicator's streams exist now (the steps above ran its first all-gathers): make sure the NMS side stream still runs
+    # BESIDE the conv stream (HIP assigns its four hardware queues in creation order; a shared queue serialises the two silently)
+    side_stream_ok = prop.ensure_side_stream() if overlap else None
     dom = dominant_kernel(model.profile_ms()[0])
     dom_mask = [op["kernel"] == dom for op in ops]
     model.set_profiling_mask(dom_mask)
@@ -1027,6 +1030,7 @@ def main():
                                       if overlap else "serial on the conv stream"},
             "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "nms_stream_concurrent": side_stream_ok,      # measured (predictor._streams_overlap), rank 0
             "per_rank": per_rank,
             "sustained": sustained,
             "sustained_images_per_s": None if sustained is None else sustained["images_per_s"],

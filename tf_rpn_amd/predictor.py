@@ -227,6 +227,22 @@ class Proposer(object):
             torch.cuda.current_stream().wait_event(self._last["nms_done"])
         self._poll_range()
 
+    def ensure_side_stream(self):
+        """Re-test the NMS side stream against the current stream (e.g. after an RCCL communicator or other libraries created their
+        streams: hardware queues are assigned in creation order) and draw a new one if the two have come to share a queue.
+        Synchronises the device; not for the hot path.  Returns True when the side stream runs beside the current stream."""
+        if not self.overlap_nms:
+            return False
+        cur = torch.cuda.current_stream()
+        if _streams_overlap(cur, self._nms_stream):
+            return True
+        torch.cuda.synchronize()                                            # nothing in flight on the stream being retired
+        self._nms_stream = _concurrent_side_stream(must=cur)
+        with torch.cuda.stream(self._nms_stream):
+            self._valid.zero_()
+        cur.wait_stream(self._nms_stream)
+        return _streams_overlap(cur, self._nms_stream)
+
     def _poll_range(self):
         if self.check_range and self.rpn_model.precision in ("f16x3", "fp16x3"):
             self.rpn_model.raise_on_range_error()
