@@ -24,13 +24,20 @@ def _streams_overlap(a, b, microseconds=200):
     streams {0, 7}, {1, 6}, {2, 5, 9} and {3, 4, 8} share one -- so whether two streams share a queue depends on what else the
     process has created; on a shared queue the NMS of batch k would run BEHIND the convs of batch k + 1 instead of beside them,
     silently.  One sleeping wave on each stream (rpn_stream_spin): beside each other they take ~1x, behind each other ~2x."""
-    import time
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    L.check(L.lib().rpn_stream_spin(L.vp(a.cuda_stream), microseconds), "rpn_stream_spin")
-    L.check(L.lib().rpn_stream_spin(L.vp(b.cuda_stream), microseconds), "rpn_stream_spin")
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) < 1.5e-6 * microseconds + 30e-6
+    # device timestamps (events), not the host's clock: the host may be descheduled between the calls; and up to three rounds --
+    # a shared queue NEVER shows the short time, so one short round settles it
+    for _ in range(3):
+        e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize()
+        e0.record(a)
+        L.check(L.lib().rpn_stream_spin(L.vp(a.cuda_stream), microseconds), "rpn_stream_spin")
+        L.check(L.lib().rpn_stream_spin(L.vp(b.cuda_stream), microseconds), "rpn_stream_spin")
+        ea.record(a)
+        eb.record(b)
+        torch.cuda.synchronize()
+        if max(e0.elapsed_time(ea), e0.elapsed_time(eb)) < 1.5e-3 * microseconds:
+            return True
+    return False
 
 
 def _concurrent_side_stream(must=None, should=(), tries=8):
@@ -41,7 +48,6 @@ def _concurrent_side_stream(must=None, should=(), tries=8):
     best, best_n = None, -1
     for _ in range(tries):
         s = torch.cuda.Stream()
-        _streams_overlap(must, s)                                           # (a stream's first launch is slow: not judged)
         if not _streams_overlap(must, s):
             if best is None:
                 best, best_n = s, -1
@@ -397,17 +403,20 @@ class ProposerPool(object):
         if n < 1:
             raise ValueError("ProposerPool needs n >= 1 pipelines")
         kwargs["overlap_nms"] = True
-        # every pipeline's conv stream and NMS side stream on hardware queues of their own where the device has them (four by
-        # default: exactly two pipelines' worth) -- each new stream is tested against the ones already taken
-        self.pipelines, self.streams, taken = [], [], []
+        # Hardware queues (four by default, the caller's stream holds one): each pipeline's conv stream gets a queue of its own,
+        # the pipelines' NMS side streams may SHARE the fourth -- never the caller's: propose_async records its "images ready" event
+        # on the caller's stream, and on a shared queue that event would wait behind an NMS (measured: configs[0] 0.164 instead of
+        # 0.125 ms per step).  Each new stream is tested against the ones it must run beside (_streams_overlap).
+        caller = torch.cuda.current_stream()
+        self.pipelines, self.streams, side = [], [], []
         for _ in range(int(n)):
-            s = _concurrent_side_stream(must=taken[0] if taken else None, should=tuple(taken))
+            s = _concurrent_side_stream(must=caller, should=tuple(self.streams + side))
             with torch.cuda.stream(s):
-                p = Proposer(*args, avoid_streams=tuple(taken), **kwargs)
-            torch.cuda.current_stream().wait_stream(s)
+                p = Proposer(*args, avoid_streams=(caller,) + tuple(self.streams), **kwargs)
+            caller.wait_stream(s)
             self.pipelines.append(p)
             self.streams.append(s)
-            taken += [s, p._nms_stream]
+            side.append(p._nms_stream)
         self._ready = [torch.cuda.Event() for _ in range(int(n))]
         self._k = 0
         p0 = self.pipelines[0]
