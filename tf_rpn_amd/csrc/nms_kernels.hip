@@ -68,7 +68,9 @@ constexpr int kChunkWords = kChunk / 64;
 // LDS slot of chunk candidate j = 16 * piece + jj: row jj of a 16 x 16 transpose, the piece XOR-swizzled by the row's upper
 // two bits.  Threads that differ in the piece (step B2) and threads that cover a group's 4 pieces x 4 rows (step B1) both read
 // 16 different 16-byte columns.
-__device__ __forceinline__ int cslot2(int jj, int piece) { return (jj << 4) | (piece ^ (jj & 12)); }
+constexpr int kPieceBits = kChunk == 512 ? 5 : 4;                    // log2 of the chunk's 16-candidate pieces
+static_assert((16 << kPieceBits) == kChunk, "chunk size");
+__device__ __forceinline__ int cslot2(int jj, int piece) { return (jj << kPieceBits) | (piece ^ (jj & 12)); }
 __device__ __forceinline__ int cslot(int j) { return cslot2(j & 15, j >> 4); }
 constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int kLoadBatch = 9;          // score loads in flight per thread in the passes over all N scores (9 x 1024 threads cover the 8649 / 9216 anchors of one 500 x 500 image in one round)
