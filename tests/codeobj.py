@@ -49,3 +49,41 @@ def kernels(so_path):
                     for k in meta.get("amdhsa.kernels", []):
                         out[k[".name"]] = k
     return out
+
+
+def short_name(mangled):
+    """`_ZN3rpn18conv_igemm_f32_dmaILi2ELi2ELi2ELi2ELb0EEEvNS_8ConvArgsEiii` -> `conv_igemm_f32_dma<2,2,2,2,false>` (the library's
+    kernels live in namespace rpn and take integer / bool template arguments only); anything else is returned unchanged."""
+    m = re.match(r"_ZN3rpn(\d+)", mangled)
+    if not m:
+        return mangled
+    start = m.end()
+    n = int(m.group(1))
+    name, rest = mangled[start:start + n], mangled[start + n:]
+    if not rest.startswith("I"):
+        return name
+    args, pos = [], 1
+    while pos < len(rest) and rest[pos] != "E":
+        a = re.match(r"L([a-z])(n?\d+)E", rest[pos:])
+        if not a:
+            return mangled
+        v = a.group(2).replace("n", "-")
+        args.append({"0": "false", "1": "true"}[v] if a.group(1) == "b" else v)
+        pos += a.end()
+    return "%s<%s>" % (name, ",".join(args))
+
+
+def table(so_path):
+    """{short kernel name: (VGPRs incl. AGPRs, SGPR spills, VGPR spills, scratch bytes, LDS bytes, max workgroup size)}"""
+    out = {}
+    for name, k in kernels(so_path).items():
+        # (.vgpr_count is the unified allocation: architectural registers + AGPRs)
+        out[short_name(name)] = (k[".vgpr_count"], k.get(".sgpr_spill_count", 0), k.get(".vgpr_spill_count", 0), k[".private_segment_fixed_size"],
+                                 k[".group_segment_fixed_size"], k[".max_flat_workgroup_size"])
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    for nm, row in sorted(table(sys.argv[1]).items()):
+        print("%-64s vgpr %3d  sgpr-spill %3d  vgpr-spill %3d  scratch %4d  lds %6d  wg %4d" % ((nm,) + row))

@@ -171,6 +171,37 @@ def test_proposer_pool_matches_a_single_proposer():
         assert torch.equal(g, w)
 
 
+def test_proposer_pool_input_freed_and_reallocated_between_calls():
+    """The caller drops each batch right after handing it over and immediately allocates + fills same-sized tensors on ITS stream
+    (what ``pool.propose_async(next_batch())`` does): the pipeline stream must still read the original pixels -- ProposerPool tells
+    the caching allocator that the pipeline's stream uses the block (``record_stream``)."""
+    from tf_rpn_amd.predictor import ProposerPool
+    hp = dict(bo.get_hyper_params("mobilenet_v2", img_size=160, feature_map_shape=10))
+    weights = synthetic_weights("mobilenet_v2", hp, seed=5)
+    single = Proposer("mobilenet_v2", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    pool = ProposerPool(2, "mobilenet_v2", hyper_params=dict(hp), weights=weights, max_batch=2, precision="f16x3")
+    gen = torch.Generator().manual_seed(11)
+    host = [torch.rand((2, 160, 160, 3), generator=gen) for _ in range(6)]
+    want = [[t.clone() for t in single.propose(h.cuda())] for h in host]
+    torch.cuda.synchronize()
+    got = []
+    for h in host:
+        x = h.cuda()
+        out = pool.propose_async(x)
+        got.append([t for t in out])
+        del x, out
+        junk = [torch.full((2, 160, 160, 3), float("nan"), device="cuda") for _ in range(3)]   # would land in the freed block
+        del junk
+        if len(got) % 2 == 0:                       # the pool's two pipelines x two output slots: collect before they are reused
+            pool.wait()
+            torch.cuda.synchronize()
+            for k in (len(got) - 2, len(got) - 1):
+                got[k] = [t.clone() for t in got[k]]
+    for k in range(len(host)):
+        for g, w in zip(got[k], want[k]):
+            assert torch.equal(g, w), k
+
+
 def test_pipelined_distributed_path_world1():
     """The N > 1 code path (record packing + all-gather one step behind the convs) on a world-size-1 RCCL group:
     gathered records must equal the serial proposals, in order, including the flushed last batch."""

@@ -113,7 +113,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // matrix pipe busy 78 % of the time with the waves parked at the slice barrier for 18 % of theirs (profiles/r03_f32_pmc.txt).
 // With it the 128 x 128 tile takes 104 VGPRs, accumulators included: up to four workgroups per CU (33 KB of LDS each) whose
 // barrier waits cover one another.  Same instruction sequence per accumulator, same bits: 705 -> 722 images/s.
-template <int WM, int WN, int MI, int NI, bool GENERIC>
+template <int WM, int WN, int MI, int NI, bool GENERIC, bool POOL>
 __global__ void __launch_bounds__(kConvThreads, 2)
 conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -352,7 +352,7 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 //     this kernel at every tile width, so an image's bits do not depend on the batch it is in (tests: batch invariance).
 //   B tile: the packed weight rows of the slice, [16][BN] floats, a linear copy (BN / 64 instructions per wave; at BN = 32
 //     two waves issue one each).
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, bool POOL>
 __global__ void __launch_bounds__(kConvThreads, 2)
 conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -508,8 +508,8 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 
 bool conv_f32_uses_dma(int tile_n, int generic);
 
-template <int WM, int WN, int MI, int NI>
-static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
+template <int WM, int WN, int MI, int NI, bool POOL>
+static hipError_t launch_variant_p(const ConvArgs &a, hipStream_t stream)
 {
     constexpr int BN = WN * NI * 32;
     const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
@@ -517,20 +517,28 @@ static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
     const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (a.ps.generic)
-        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                            stream, a, tiles_x, tiles_y, n_tiles);
     else {
         // (laboratory builds: RPN_F32_DMA=0: register-staged kernel everywhere, 2: DMA kernel everywhere; same bits)
         // the DMA kernel on the 128-wide tile (+2.5 ... 3.6 % per layer); the narrower tiles are what small grids get (two
         // workgroups per CU: nothing covers the DMA's longer latency there -- 31 x 31 x 512 at batch 8: 0.406 against 0.341 ms)
         if (conv_f32_uses_dma(BN, 0))
-            hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream, a,
+            hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream, a,
                                tiles_x, tiles_y, n_tiles);
         else
-            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                                stream, a, tiles_x, tiles_y, n_tiles);
     }
     return hipGetLastError();
+}
+
+// The fused 2 x 2 pool (ConvArgs::pool) is a TEMPLATE parameter of the kernels: as a run-time branch of the epilogue it took
+// the un-pooled 128 x 128 instantiations from 92 / 106 to 227 registers (round 4; tests/test_host.py now holds the budgets).
+template <int WM, int WN, int MI, int NI>
+static hipError_t launch_variant(const ConvArgs &a, hipStream_t stream)
+{
+    return a.pool ? launch_variant_p<WM, WN, MI, NI, true>(a, stream) : launch_variant_p<WM, WN, MI, NI, false>(a, stream);
 }
 
 // Output channels per workgroup tile (128 | 64 | 32) of the f32 implicit-GEMM conv for a layer: the widest tile that

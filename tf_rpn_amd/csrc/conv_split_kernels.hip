@@ -2512,7 +2512,13 @@ bool conv3x3_split16_ksplit_dma(int B, int H, int W, int Cin, int Cout, int cout
     if (!on || !v || strcmp(v, "reg,64") != 0) return false;           // (the small-grid case of a DMA-capable layer)
     const long long blocks64 = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * ((Cout + 63) / 64);
     const int chunks = Cin / 32, mid = ktree_cut(chunks, 2);
-    return blocks64 > 64 && blocks64 <= 128 && mid >= 2 && (chunks - mid) >= 2 && (chunks - mid) % 2 == 0;
+    // the launcher's one-round grid: 2 x 8 x slots workgroups with slots <= 16 (n_tiles / m_tiles rounded up to the XCD split --
+    // the same arithmetic as launch_conv3x3_split16_ksplit, so the predicate never says yes to a grid the launcher refuses)
+    const int n_tiles = (Cout + 63) / 64;
+    const long long m_tiles = (long long)((W + 31) / 32) * ((H + 7) / 8) * B;
+    const int XN = n_tiles >= 8 ? 8 : (n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1)), XM = 8 / XN;
+    const long long slots = (long long)((n_tiles + XN - 1) / XN) * ((m_tiles + XM - 1) / XM);
+    return blocks64 > 64 && blocks64 <= 128 && slots <= 16 && mid >= 2 && (chunks - mid) >= 2 && (chunks - mid) % 2 == 0;
 }
 
 int conv3x3_split16_ksplit(int B, int H, int W, int Cin, int Cout, int cout_pad)

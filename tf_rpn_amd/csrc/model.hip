@@ -158,9 +158,11 @@ static int add_param(rpn_model *m, int op, const std::string &name, const std::s
 // producer only learns that its output is SPLIT16 when its consumer is added.
 static bool is_pw_x3(const rpn_model *m, const Op &op)
 {
+    static const int knob = RPN_KNOB("RPN_MN_X3", 1);      // read ONCE per process: weight packing (set_layer), kernel choice
+                                                           // (forward) and op_info must agree whatever happens to the environment
     return op.kind == OP_CONV && op.f32_out_split && m->f16 && op.R == 1 && op.S == 1 && op.stride == 1 && op.act == ACT_RELU6 &&
            op.residual < 0 && !op.ps.generic && pw_x3_supported(op.Cin, op.Cout) && op.ps.floats() == (size_t)op.Cin * op.Cout &&
-           (RPN_KNOB("RPN_MN_X3", 1) != 0);
+           knob != 0;
 }
 
 // Float32 graph: a float32 implicit-GEMM conv directly followed by its 2 x 2 max-pool (VGG16 block*_pool) runs as ONE kernel,
@@ -170,6 +172,10 @@ static bool f32_pool_fused(const rpn_model *m, size_t i)
 {
     if (m->keep_all || i + 1 >= m->ops.size()) return false;
     const Op &op = m->ops[i], &nx = m->ops[i + 1];
+    // the un-pooled tensor is never written when fused: the pool must be its ONLY reader (no residual, tap or returned feature map)
+    if (op.out == m->feat_tensor) return false;
+    for (size_t j = 0; j < m->ops.size(); ++j)
+        if (j != i + 1 && (m->ops[j].in == op.out || m->ops[j].residual == op.out)) return false;
     return op.kind == OP_CONV && !op.split && !op.cin3 && !op.f32_out_split && op.residual < 0 && op.act != ACT_SIGMOID &&
            nx.kind == OP_POOL && !nx.split && nx.in == op.out && (RPN_LAB_KNOB("RPN_F32_POOLFUSE", 1) != 0);
 }

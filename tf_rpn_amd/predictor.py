@@ -188,6 +188,8 @@ class Proposer(object):
         deltas, scores = self.forward(imgs)
         ob, osc, oi, ov = self._boxes[:B], self._scores[:B], self._idx[:B], self._valid[:B]
         self.decode_nms(deltas, scores, B, ob, osc, oi, ov)
+        # (this non-overlapped form never synchronises, so it never polls the float16 range word: call ``wait()`` -- which polls --
+        # before trusting the proposals of weights that may leave the float16 range)
         return ob, osc, ov, oi
 
     def propose_async(self, imgs):
@@ -250,7 +252,12 @@ class Proposer(object):
         return _streams_overlap(cur, self._nms_stream)
 
     def _poll_range(self):
+        """The float16 range poll copies one word back and synchronises the stream: impossible inside a stream capture (hipGraph),
+        where it is skipped -- a captured step must be built with ``check_range=False`` semantics in mind and polled by the caller
+        outside the graph (``rpn_model.raise_on_range_error()``)."""
         if self.check_range and self.rpn_model.precision in ("f16x3", "fp16x3"):
+            if torch.cuda.is_current_stream_capturing():
+                return
             self.rpn_model.raise_on_range_error()
 
     def propose_unfused(self, imgs):
@@ -431,6 +438,10 @@ class ProposerPool(object):
         if ordered:                                           # the images are ready where the caller produced them
             self._ready[i].record(torch.cuda.current_stream())
             s.wait_event(self._ready[i])
+        # The conv stack reads ``imgs`` on the pipeline's stream, not on the stream that allocated it: tell the caching allocator,
+        # or a caller that drops the tensor right after this call (``pool.propose_async(next_batch())``) gets the block handed to
+        # its next allocation while the convs are still reading it.
+        imgs.record_stream(s)
         with torch.cuda.stream(s):
             return self.pipelines[i].propose_async(imgs)
 
