@@ -41,9 +41,11 @@ for B, kind in ((8, "perm"), (8, "model-like"), (8, "model"), (64, "perm")):
     ob = torch.zeros((B, 300, 4), device="cuda"); osc = torch.zeros((B, 300), device="cuda")
     oi = torch.zeros((B, 300), dtype=torch.int32, device="cuda"); ov = torch.zeros((B,), dtype=torch.int32, device="cuda")
     keep, vptr = L.host_floats(VAR)
+    wsb = int(L.lib().rpn_nms_workspace_bytes(B, A, 1, 300, 300))
+    ws = torch.empty((max(16, wsb),), dtype=torch.uint8, device="cuda")
     def run():
         L.check(L.lib().rpn_decode_nms(L.ptr(a), L.ptr(d), vptr, L.ptr(s), B, A, 300, THR, float("-inf"), 1, L.ptr(ob),
-                                       L.ptr(osc), L.ptr(oi), L.ptr(ov), L.vp(0), 0, L.stream_ptr()), "nms")
+                                       L.ptr(osc), L.ptr(oi), L.ptr(ov), L.ptr(ws), wsb, L.stream_ptr()), "nms")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

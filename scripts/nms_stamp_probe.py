@@ -1,7 +1,8 @@
 """Phase stamps of the NMS kernel (a -DRPN_NMS_STAMP build: RPN_HIP_LIB=ab/nmsstamp.so).  Prints, for workgroup 0 and the
 median over workgroups, the cycles between consecutive stamps with their phase codes:
 1 start, 2 band selected, 3 band compacted, 4 band sorted, 5 chunk set up, 6 step A, 7 step B, 8 walk (wave 0), 9 group done,
-10 greedy done, 11 outputs written."""
+10 greedy done, 11 outputs written; 33 band select entered, 34 histogram zeroed (30: barrier behind it), 35 score pass done (31: barrier), 32 threshold found;
+40 order: cursors zeroed, 43 keys scattered (41: barrier), 42 ranked."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

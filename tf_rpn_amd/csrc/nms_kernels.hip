@@ -56,6 +56,24 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#ifdef RPN_NMS_STAMP
+// Debug build only (-DRPN_NMS_STAMP, scripts/nms_stamp_probe.py): cycle stamps of thread 0 at the phase boundaries of the first 64
+// workgroups, in program order.  The stamp index lives in (static) LDS so that the band functions can stamp too.
+__device__ unsigned long long g_nms_stamps[64 * 512];
+__device__ __forceinline__ int &nms_stamp_idx() { __shared__ int idx; return idx; }
+#define NMS_STAMP(code)                                                                                       \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && nms_stamp_idx() < 512)                                     \
+            g_nms_stamps[blockIdx.x * 512 + nms_stamp_idx()++] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); \
+    } while (0)
+extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), (size_t)n * 8);
+}
+#else
+#define NMS_STAMP(code) ((void)0)
+#endif
+
 constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
 constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
@@ -295,11 +313,14 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
 {
     constexpr int NB = 2048;
     const int tid = fresh_tid();
+    NMS_STAMP(33);
     // hist[0, 2048): the bins; hist[2048, 4096): the 2048 sub-bins of the TOP bin, filled in the same pass -- a saturated
     // sigmoid puts most of a head's 61 440 scores there, and the refinement below then needs no pass of its own
     for (int i = tid; i < 2 * NB; i += kNmsThreads) hist[i] = 0u;
     const bool fill = sc.cache != nullptr && !sc.cached;          // this pass also copies the scores into the LDS cache
+    NMS_STAMP(34);
     __syncthreads();
+    NMS_STAMP(30);
     for (int base = tid; base < N; base += kLoadBatch * kNmsThreads) {
         float sb[kLoadBatch];
 #pragma unroll
@@ -319,7 +340,9 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
             }
         }
     }
+    NMS_STAMP(35);
     __syncthreads();
+    NMS_STAMP(31);
     if (fill) sc.cached = true;
     // The alternative band size for a SATURATED head -- the top bin (scores >= 2047 / 2048) alone holds 128 candidates or more:
     // hundreds of equal or nearly equal scores make a large band expensive to order (ranked by counting inside a sub-bin), so such
@@ -333,6 +356,7 @@ __device__ inline bool band_select_linear(ScoreSrc &sc, int N, float score_thr,
     const int d = ctl[0], n = ctl[1];
     const int in_d = d > 0 ? (int)hist[d] : 0;
     __syncthreads();                        // (ctl is reused below and by the caller)
+    NMS_STAMP(32);
     *bin_out = d;
     if (d == -1) { *thr_out = 0ull; *count = 0; return true; }
     if (d == -2) { *thr_out = 1ull; *count = n; *bin_out = -1; return true; }       // (bin 0 included: no histogram order)
@@ -440,12 +464,15 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d_mai
     if (fat) atomicOr(flag, 1u);
     __syncthreads();
     if (*flag != 0u) return false;
+    NMS_STAMP(40);
     // scatter: the band's keys to their segments
     for_each_band_key([&](unsigned long long key) {
         const int b = seg_of(key);
         band[boff[b] + atomicAdd(&cur[b], 1u)] = key;
     });
+    NMS_STAMP(43);
     __syncthreads();
+    NMS_STAMP(41);
     // rank inside the segment (keys are unique); up to two keys per thread (n <= 2048)
     unsigned long long key[2] = {0ull, 0ull};
     int pos[2] = {-1, -1};
@@ -468,6 +495,7 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d_mai
         }
     }
     __syncthreads();                         // every key is in a register: `order` aliases `band`
+    NMS_STAMP(42);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
         if (pos[u] >= 0) {
@@ -484,24 +512,6 @@ __device__ inline bool band_order_linear(ForEachKey for_each_band_key, int d_mai
 #define NMS_STOP_AT(n) do { if (p.stop_after == (n)) return; } while (0)
 #else
 #define NMS_STOP_AT(n) ((void)0)
-#endif
-#ifdef RPN_NMS_STAMP
-__device__ unsigned long long g_nms_stamps[64 * 512];
-#define NMS_STAMP(code)                                                                                       \
-    do {                                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < 64 && nms_sidx < 512)                                            \
-            g_nms_stamps[blockIdx.x * 512 + nms_sidx++] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); \
-    } while (0)
-extern "C" int rpn_debug_read_nms_stamps(unsigned long long *out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nms_stamps), (size_t)n * 8);
-}
-#define NMS_SIDX_PARAM , int &nms_sidx
-#define NMS_SIDX_ARG , nms_sidx
-#else
-#define NMS_STAMP(code) ((void)0)
-#define NMS_SIDX_PARAM
-#define NMS_SIDX_ARG
 #endif
 
 
@@ -602,7 +612,7 @@ __device__ __forceinline__ bool cluster_histogram(const ClusterCtx &cl, int k, u
 //      to its region (count in ctr[16 + g]); ranks other than the leader have arrived at barrier 2 and must leave.
 __device__ inline int cluster_first_band(const ClusterCtx &cl, const ScoreSrc &sc, int N, float score_thr,
                                          int want, int cap, unsigned *hist, int *ctl, unsigned long long *lds_keys,
-                                         unsigned long long *thr_out, int *count, int *bin_out NMS_SIDX_PARAM)
+                                         unsigned long long *thr_out, int *count, int *bin_out)
 {
     const int tid = fresh_tid(), lane = tid & 63;
     const int per = (N + cl.G - 1) / cl.G;
@@ -727,7 +737,7 @@ __global__ void __launch_bounds__(kNmsThreads)
 nms_kernel(NmsArgs p)
 {
 #ifdef RPN_NMS_STAMP
-    int nms_sidx = 0;
+    if (threadIdx.x == 0) nms_stamp_idx() = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsLayout L = lds_layout(p.max_sel, p.cache_n, p.prune);
@@ -789,7 +799,7 @@ nms_kernel(NmsArgs p)
             const int band_target = min(kBandTarget, max(512, 3 * max_sel));
             const int band_cap = band_target <= 960 ? 1024 : kBandCap;
             cl_state = cluster_first_band(cl, src, N, p.score_thr, band_target, band_cap, hist, ctl + CTL_SEL, band, &cl_thr,
-                                          &cl_count, &cl_bin NMS_SIDX_ARG);
+                                          &cl_count, &cl_bin);
         }
         if (cl.g != 0) return;                 // the leader goes on alone (with the cluster's band, or from scratch)
         __syncthreads();
@@ -1007,7 +1017,9 @@ nms_kernel(NmsArgs p)
                 // (A) the group's candidates against the boxes selected in EARLIER chunks (this chunk's selections reach
                 //     later groups through the row ORs below): thread (candidate = tid / 16, part = tid % 16) tests selected
                 //     boxes part, part + 16, ... (LDS broadcast within a part).  Done per group, so a chunk that completes
-                //     the output after one group tests 64 x nsel pairs, not 256 x nsel.
+                //     the output after one group tests 64 x nsel pairs, not 256 x nsel.  (Round 5: batches of several groups per
+                //     interval measured SLOWER -- 124 -> 132 us at configs[2], IoU 0.5 -- although thread 0's own step (A) took
+                //     6.8 k cycles for four groups against 4 x 3.5 k: the interval [B2, A, B1] overlaps its pieces well as it is.)
                 if (nsel > 0) {
                     const int tid = fresh_tid(), lane = tid & 63;
                     const int il = tid >> 4, part = tid & 15;
