@@ -3,7 +3,10 @@ ONE GPU.  Each rank runs the HIP path on its `shard_bounds` slice; the records a
 staged through host memory HERE ONLY (the product calls torch.distributed.all_gather_into_tensor on device tensors, which
 is RCCL on a real multi-GPU node; this machine has one GPU, and RCCL does not run two ranks on one device).
 
-argv: total out_dir      env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
+With a third argument "nccl" (tests/test_gpu_distributed.py::test_two_ranks_rccl, only where >= 2 devices are visible) each rank
+takes the device LOCAL_RANK and the records travel by RCCL, device to device, exactly as in the product.
+
+argv: total out_dir [nccl]      env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
 Writes out_dir/rank<r>.npz with the gathered records of the three code paths; exit code 0 when it ran to the end.
 """
 import os
@@ -24,7 +27,13 @@ from tf_rpn_amd.utils import train_utils
 def main():
     total, out_dir = int(sys.argv[1]), sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rccl = len(sys.argv) > 3 and sys.argv[3] == "nccl"
+    device = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+    if rccl:
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     real_all_gather = dist.all_gather_into_tensor
 
     def staged_all_gather(out, inp, *a, **k):       # device -> host -> gloo -> host -> device (the test's stand-in for RCCL)
@@ -33,9 +42,10 @@ def main():
         real_all_gather(host_out, inp.detach().cpu().contiguous(), *a, **k)
         out.copy_(host_out.to(out.device))
 
-    dist.all_gather_into_tensor = staged_all_gather
+    if not rccl:
+        dist.all_gather_into_tensor = staged_all_gather
     try:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(device)
         hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
         weights = synthetic_weights("vgg16", hp, seed=5)
         imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11))     # same on every rank
@@ -59,6 +69,8 @@ def main():
         res["pipe_step1"] = compact_gathered(second, total, world).cpu().numpy()
         last = prop2.flush_distributed(gather_bufs)
         res["pipe_step2"] = compact_gathered(last, total, world).cpu().numpy()
+        if rccl:        # the communicator's streams exist now: the NMS side stream must still run beside the conv stream
+            res["side_stream_ok"] = np.array([1 if prop2.ensure_side_stream() else 0])
         torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
         dist.barrier()

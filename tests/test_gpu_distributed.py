@@ -42,3 +42,30 @@ def test_two_ranks_on_one_gpu_match_single_process(total, tmp_path):
         for key in ("serial", "serial_buf", "pipe_step1", "pipe_step2"):
             assert got[key].shape == want.shape, (rank, key, got[key].shape)
             assert np.array_equal(got[key].view(np.uint32), want.view(np.uint32)), (rank, key)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible devices (the 1-GPU pool skips it; the 8-GPU node runs it)")
+def test_two_ranks_rccl(tmp_path):
+    """The same two-rank run with each rank on a device of its own and the proposal records gathered by RCCL (backend "nccl"),
+    device to device -- `propose_distributed` and two `propose_distributed_pipelined` steps + flush: the gathered records equal the
+    single-process proposals bit for bit, and the NMS side stream still runs beside the conv stream once the communicator's own
+    streams exist (hardware-queue aliasing).  The reference has no counterpart (utils/io_utils.py:52-59 is one
+    process); the split is SURVEY.md section 8e's."""
+    sys.path.insert(0, ROOT)
+    from bench import spawn_ranks
+    total = 7
+    rc, _out = spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(total), str(tmp_path), "nccl"],
+                           timeout=900)
+    assert rc == 0
+    hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    train_utils.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    weights = synthetic_weights("vgg16", hp, seed=5)
+    imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11)).cuda()
+    prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=total, iou_threshold=0.7)
+    boxes, scores, valid, _ = prop.propose(imgs)
+    want = prop.pack_records(boxes, scores, valid).cpu().numpy()
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert int(got["side_stream_ok"][0]) == 1, rank
+        for key in ("serial", "serial_buf", "pipe_step1", "pipe_step2"):
+            assert np.array_equal(got[key].view(np.uint32), want.view(np.uint32)), (rank, key)

@@ -2448,7 +2448,9 @@ hipError_t launch_conv3x3_split16(const void *x, const void *w, const float *bia
         // slower than this one: laboratory builds only, RPN_S16_W4=1)
         static const int w4 = RPN_LAB_KNOB("RPN_S16_W4", 0);
         const long long out_bytes4 = (long long)B * (pool ? H >> 1 : H) * (pool ? W >> 1 : W) * Cout * 4;
-        if (BN == 128 && w4 && !a.sched && out_bytes4 < 0x7fffffffll) {
+        // (w4 = 1: every 128-wide layer; w4 > 1: only the layers with Cin == w4 -- round 5: block2_conv1 alone, K = 576, where the
+        // epilogue is 15 % of a tile's time)
+        if (BN == 128 && (w4 == 1 || w4 == Cin) && !a.sched && out_bytes4 < 0x7fffffffll) {
 #define RPN_L16D4(F16_, POOL_)                                                                                       \
     hipLaunchKernelGGL((conv3x3_split16_dma4_kernel<F16_, POOL_>), dim3(pgrid), dim3(256), 0, s, a, tiles_x, tiles_y, n_tiles)
             if (f16) { if (pool) { RPN_L16D4(true, true); } else { RPN_L16D4(true, false); } }
