@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "f16x3": 2500.0 / 3.0}   # MI355X_MICROARCH.md: f32 MFMA; dense 16-bit MFMA / 3 products
+PEAK_TFLOPS = {"f32": 157.3, "f32w": 157.3, "bf16x3": 2500.0 / 3.0, "f16x3": 2500.0 / 3.0}   # MI355X_MICROARCH.md: f32 MFMA; dense 16-bit MFMA / 3 products
 
 
 def spawn_ranks(n, cmd, env=None, timeout=None, poll=0.2):
@@ -141,7 +141,7 @@ def parse_args():
                          "anchors per cell, 1 image per GPU = batch 8 on 8 GPUs)")
     ap.add_argument("--backbone", default=None, choices=["vgg16", "mobilenet_v2"])
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f32w", "bf16x3", "f16x3"],
                     help="conv arithmetic: exact f32 MFMA, or f32 operands carried as hi+lo bf16/f16 halves with 3 MFMAs per "
                          "product and f32 accumulation (DESIGN.md 4.1: f16x3 measures as accurate as exact f32)")
     ap.add_argument("--iou-threshold", type=float, default=0.7)
@@ -525,18 +525,23 @@ def c3_traffic():
     return {}, None
 
 
-def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmup=2, heads=None):
+def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmup=2, heads=None, precision="f32", keep_heads=None):
     """The parity-clean arithmetic beside the headline (report both): the same workload with every conv
     on the exact float32 MFMA (v_mfma_f32_32x32x2_f32: float32 products, float32 accumulation in a fixed order per
     output -- within a channel quad the products are taken in the order 0, 2, 1, 3 by conv_igemm_f32 / conv_igemm_f32_dma
     and 0, 1, 2, 3 by the generic layers; deterministic and batch-invariant, but not the bits of a sequential-K fmaf chain),
     timed over `steps` steps in this same run, with the dominant kernel's fraction of the 157.3 TFLOP/s f32-MFMA peak from
     a per-op event pass.  `heads` = the headline path's (reg, cls) head outputs for the same images: their largest
-    absolute difference from this path's is returned as `max_abs_diff_vs_headline` (the bench line's self-check)."""
+    absolute difference from this path's is returned as `max_abs_diff_vs_headline` (the bench line's self-check).
+    precision="f32w" (the `f32_winograd` leg): the 3x3 convs as float32 Winograd F(2x2, 3x3) on the same float32 MFMA (float32
+    operands and accumulation, 2.25 x fewer multiply-adds, another summation order: a precision of its own, never the
+    parity-clean `exact_f32` row).  Its `roofline.achieved` prices the multiply-adds the kernel EXECUTES (the direct conv's / 2.25)
+    against the 157.3 TFLOP/s peak; `effective_tflops` is the direct conv's flops over the same time.  `keep_heads`: a list that
+    receives this path's (reg, cls) head outputs; `heads` may then be the exact-f32 leg's."""
     import torch
 
     from tf_rpn_amd.predictor import Proposer
-    prop = Proposer(backbone, hyper_params=hp, weights=weights, precision="f32", max_batch=B,
+    prop = Proposer(backbone, hyper_params=hp, weights=weights, precision=precision, max_batch=B,
                     iou_threshold=iou_threshold, overlap_nms=True)
     for _ in range(warmup):
         prop.propose_async(imgs)
@@ -559,25 +564,35 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     model.set_profiling(0)
     tot = {}
     for op, t in zip(ops, ms):
-        d = tot.setdefault(op["kernel"], [0.0, 0.0, 0])
+        d = tot.setdefault(op["kernel"], [0.0, 0.0, 0, 0.0])
         d[0] += t
-        d[1] += op["flops_per_image"] * B
+        d[1] += op["flops_per_image"] * B / (2.25 if op["arith"] == "f32w" else 1.0)      # multiply-adds executed
         d[2] += op["launches"]
+        d[3] += op["flops_per_image"] * B                                                  # the direct conv's
     dom = max(tot, key=lambda k: tot[k][0])
     achieved = tot[dom][1] / (tot[dom][0] * 1e-3) / 1e12
     diff = None
-    if heads is not None:
+    if heads is not None or keep_heads is not None:
         d32, s32 = prop.forward(imgs)
         torch.cuda.synchronize()
-        diff = {"reg": float((d32.reshape(-1) - heads[0].reshape(-1)).abs().max().item()),
-                "cls": float((s32.reshape(-1) - heads[1].reshape(-1)).abs().max().item())}
+        if heads is not None:
+            diff = {"reg": float((d32.reshape(-1) - heads[0].reshape(-1)).abs().max().item()),
+                    "cls": float((s32.reshape(-1) - heads[1].reshape(-1)).abs().max().item())}
+        if keep_heads is not None:
+            keep_heads.extend([d32.clone(), s32.clone()])
     del prop
     torch.cuda.empty_cache()
-    return {"value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4),
-            "steps": steps, "dtype": "f32", "max_abs_diff_vs_headline": diff,
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS["f32"],
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["f32"], 4),
-                         "launches_per_step": tot[dom][2], "avg_launch_ms": round(tot[dom][0] / tot[dom][2], 4)}}
+    out = {"value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4),
+           "steps": steps, "dtype": precision, "max_abs_diff_vs_headline": diff,
+           "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS["f32"],
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["f32"], 4),
+                        "launches_per_step": tot[dom][2], "avg_launch_ms": round(tot[dom][0] / tot[dom][2], 4)}}
+    if precision == "f32w":
+        out["max_abs_diff_vs_exact_f32"] = out.pop("max_abs_diff_vs_headline")
+        out["roofline"]["effective_tflops"] = round(tot[dom][3] / (tot[dom][0] * 1e-3) / 1e12, 3)
+        out["note"] = ("3x3 convs as float32 Winograd F(2x2,3x3) on the f32 MFMA: float32 operands and accumulation, 1 / 2.25 of the "
+                       "multiply-adds, another summation order -- not the parity-clean `exact_f32` row")
+    return out
 
 
 def pool_leg(backbone, hp, weights, B, precision, iou_threshold, imgs, steps, warmup, in_flight=2):
@@ -987,7 +1002,7 @@ def main():
         for op, ms in zip(ops, last_ms):
             d = by_kernel.setdefault(op["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
             d["ms"] += ms
-            d["flops"] += op["flops_per_image"] * B
+            d["flops"] += op["flops_per_image"] * B / (2.25 if op["arith"] == "f32w" else 1.0)   # (Winograd: the multiply-adds executed)
             d["launches"] += op["launches"]
         d = by_kernel[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -1014,6 +1029,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "dtype_note": {"f32": "float32 in, float32 MFMA accumulate (exact)",
+                           "f32w": "float32 in, float32 MFMA accumulate; the 3x3 convs as Winograd F(2x2,3x3): 1 / 2.25 of the multiply-adds, another summation order",
                            "f16x3": "float32 operands as hi+lo float16 halves, 3 MFMAs per product, float32 accumulate",
                            "bf16x3": "float32 operands as hi+lo bfloat16 halves, 3 MFMAs per product, float32 accumulate"
                            }[args.precision],
@@ -1049,8 +1065,15 @@ def main():
             if args.precision != "f32":
                 d_h, s_h = prop.forward(imgs)
                 heads = (d_h.clone(), s_h.clone())
-                out["exact_f32"] = exact_f32_leg(args.backbone, hp, weights, B, args.iou_threshold, imgs, heads=heads)
+                exact_heads = []
+                out["exact_f32"] = exact_f32_leg(args.backbone, hp, weights, B, args.iou_threshold, imgs, heads=heads, keep_heads=exact_heads)
                 checks["max_abs_diff_vs_exact_f32"] = out["exact_f32"]["max_abs_diff_vs_headline"]
+                if args.precision != "f32w":
+                    # float32 Winograd beside it (a precision of its own; its check is against the exact-f32 head outputs)
+                    out["f32_winograd"] = exact_f32_leg(args.backbone, hp, weights, B, args.iou_threshold, imgs, heads=tuple(exact_heads),
+                                                        precision="f32w")
+                    checks["f32_winograd_max_abs_diff_vs_exact_f32"] = out["f32_winograd"]["max_abs_diff_vs_exact_f32"]
+                del exact_heads
                 if args.precision == "f16x3":
                     checks["f16_range"] = checks["f16_range"] or bool(model.status(reset=False)["f16_range"])
             if args.config == "c2" and args.backbone == "vgg16" and B == 8:
@@ -1095,7 +1118,9 @@ def main():
         checks["other_configs_failed"] = legs_bad
         checks["ok"] = not (bool(legs_bad) or checks["f16_range"] or checks["valid_min"] < 1 or not checks["proposals_finite"]
                             or checks.get("any_rank_failed", False)
-                            or (diff is not None and max(diff.values()) > checks["tolerance"]))
+                            or (diff is not None and max(diff.values()) > checks["tolerance"])
+                            or (checks.get("f32_winograd_max_abs_diff_vs_exact_f32") is not None
+                                and max(checks["f32_winograd_max_abs_diff_vs_exact_f32"].values()) > checks["tolerance"]))
         print(json.dumps(out), flush=True)
         if not checks["ok"]:
             sys.stderr.write("bench.py: self-check FAILED: %s\n" % json.dumps(checks))

@@ -70,7 +70,10 @@ typedef enum rpn_backbone { RPN_BACKBONE_VGG16 = 0, RPN_BACKBONE_MOBILENET_V2 = 
  * hi*hi + hi*lo + lo*hi on the 16-bit MFMA with float32 accumulation (product error ~2^-16 / ~2^-21
  * relative; measured against the 1e-4 parity bound in tests/, never assumed).  F16X3 requires
  * |activation| < 65504.  All other layers stay on the float32 kernels. */
-typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1, RPN_PRECISION_F16X3 = 2 } rpn_precision;
+typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1, RPN_PRECISION_F16X3 = 2,
+                             RPN_PRECISION_F32W = 3 /* float32 Winograd F(2x2,3x3) for the 3x3 convs: float32 operands and
+                                                       accumulation, 2.25x fewer multiplications, another summation order */
+} rpn_precision;
 
 int rpn_abi_version(void);
 const char *rpn_last_error(void);

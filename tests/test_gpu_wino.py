@@ -1,0 +1,116 @@
+"""GPU suite: precision "f32w" -- the 3x3 convs as Winograd F(2x2, 3x3) on the float32 MFMA (tf_rpn_amd/csrc/conv_wino_kernels.hip).
+Float32 operands and accumulation, another summation order than the direct conv: compared with a float64 torch conv of the same
+layer (models/rpn_vgg16.py:16-18 are keras Conv2D(3x3, 'same') + ReLU) at 1e-5 x the output scale -- ten times tighter than the
+path's 1e-4 contract, and what the direct float32 kernel is held to in tests/test_gpu_conv.py (2e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import conv_oracle as cv
+from tf_rpn_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(x, w, b, act, precision):
+    xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    bd = torch.from_numpy(b).cuda() if b is not None else None
+    B, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    L.check(L.lib().rpn_conv2d(L.ptr(xd), B, H, W, Cin, L.ptr(wd), L.ptr(bd), 3, 3, Cout, 1, 1, 1, H, W, L.ACTS[act],
+                               L.PRECISIONS[precision], L.ptr(out), L.stream_ptr()), "rpn_conv2d")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+WINO_CASES = [
+    # B, H, W, Cin, Cout, act
+    (1, 16, 16, 8, 64, "linear"),        # one exact workgroup tile, one slice
+    (1, 16, 16, 64, 64, "relu"),
+    (2, 31, 31, 512, 512, "relu"),       # block5 / rpn_conv: odd size, ragged tiles, 64 slices
+    (2, 17, 23, 24, 96, "relu"),         # ragged everywhere, Cout % 64 == 32
+    (1, 125, 125, 128, 256, "relu"),     # block3_conv1
+    (3, 5, 7, 16, 32, "relu6"),          # smaller than a tile
+    (1, 33, 1, 8, 32, "linear"),         # one column
+    (2, 62, 62, 256, 512, "relu"),       # block4_conv1
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_winograd_conv_against_float64(case):
+    B, H, W, Cin, Cout, act = case
+    rng = np.random.RandomState(abs(hash(case[:5])) % (2 ** 31))
+    x = rng.uniform(-1, 1, size=(B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(Cout,)).astype(np.float32)
+    ref = cv.conv2d_nhwc(x, w, b, stride=1, pad=(1, 1, 1, 1), act=act, dtype=torch.float64)
+    got = _conv(x, w, b, act, "f32w")
+    assert not np.isnan(got).any(), "some outputs were never written"
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= 1e-5 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
+    direct = _conv(x, w, b, act, "f32")
+    assert float(np.abs(got - direct).max()) <= 1e-5 * scale
+
+
+def test_winograd_conv_repeats_bit_identically_and_is_batch_invariant():
+    rng = np.random.RandomState(3)
+    x = rng.uniform(-1, 1, size=(4, 40, 36, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, 128)) * 0.06).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(128,)).astype(np.float32)
+    full = _conv(x, w, b, "relu", "f32w")
+    assert np.array_equal(full, _conv(x, w, b, "relu", "f32w"))
+    for i in range(4):
+        assert np.array_equal(full[i:i + 1], _conv(x[i:i + 1], w, b, "relu", "f32w"))
+
+
+def test_winograd_conv_refuses_what_it_cannot_do():
+    x = torch.zeros((1, 8, 8, 12), device="cuda")
+    w = torch.zeros((3, 3, 12, 32), device="cuda")
+    out = torch.zeros((1, 8, 8, 32), device="cuda")
+    st = L.lib().rpn_conv2d(L.ptr(x), 1, 8, 8, 12, L.ptr(w), None, 3, 3, 32, 1, 1, 1, 8, 8, L.ACTS["relu"], L.PRECISIONS["f32w"],
+                            L.ptr(out), L.stream_ptr())
+    assert st != 0
+
+
+def test_vgg16_forward_in_f32w_at_full_size_against_float64():
+    """The whole VGG16 + RPN head graph under precision "f32w" (every 3x3 conv but block1_conv1 -- Cin = 3 -- on the Winograd
+    kernel, block*_pool inside its epilogue) at 500 x 500 against the float64 torch graph: the path's 1e-4 contract on deltas and
+    objectness (models/rpn_vgg16.py:16-21), bit-identical outputs for an image alone and inside a batch, and the same bits with
+    the pools as separate kernels (keep_activations)."""
+    from oracle import bbox_oracle as bo
+    from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+    hp = bo.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    imgs = np.random.RandomState(2).uniform(0, 1, size=(2, 500, 500, 3)).astype(np.float32)
+    ref_reg, ref_cls = cv.rpn_forward("vgg16", imgs[:1], weights, dtype=torch.float64)
+    model = RPNModel("vgg16", hp, precision="f32w", max_batch=2)
+    model.set_weights(weights)
+    reg, cls = model.predict_on_batch(imgs)
+    assert np.abs(reg[:1] - ref_reg).max() <= 1e-4, np.abs(reg[:1] - ref_reg).max()
+    assert np.abs(cls[:1] - ref_cls).max() <= 1e-4, np.abs(cls[:1] - ref_cls).max()
+    kinds = {op["name"]: (op["kernel"], op["arith"]) for op in model.ops()}
+    assert kinds["block3_conv2"] == ("conv3x3_wino_f32<16x16x64>", "f32w") and kinds["rpn_conv"][1] == "f32w"
+    assert kinds["block1_conv1"][1] == "f32"
+    assert "fused:maxpool_f32" in [k for k, _ in kinds.values()]
+    reg1, cls1 = model.predict_on_batch(imgs[1:2])
+    assert np.array_equal(reg1, reg[1:2]) and np.array_equal(cls1, cls[1:2])
+    keep = RPNModel("vgg16", hp, precision="f32w", max_batch=1, keep_activations=True)
+    keep.set_weights(weights)
+    regk, clsk = keep.predict_on_batch(imgs[:1])
+    assert np.array_equal(regk, reg[:1]) and np.array_equal(clsk, cls[:1])
+
+
+def test_mobilenet_v2_rpn_conv_in_f32w():
+    from oracle import bbox_oracle as bo
+    from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+    hp = bo.get_hyper_params("mobilenet_v2", img_size=160, feature_map_shape=10)
+    weights = synthetic_weights("mobilenet_v2", hp, seed=3)
+    imgs = np.random.RandomState(4).uniform(0, 1, size=(2, 160, 160, 3)).astype(np.float32)
+    ref = cv.rpn_forward("mobilenet_v2", imgs, weights, dtype=torch.float64)
+    model = RPNModel("mobilenet_v2", hp, precision="f32w", max_batch=2)
+    model.set_weights(weights)
+    reg, cls = model.predict_on_batch(imgs)
+    assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
+    assert {op["name"]: op["arith"] for op in model.ops()}["rpn_conv"] == "f32w"

@@ -20,7 +20,7 @@ c_int_p = ctypes.POINTER(ctypes.c_int)
 vp = ctypes.c_void_p
 
 RPN_OK, RPN_ERR_INVALID, RPN_ERR_NO_DEVICE, RPN_ERR_WORKSPACE, RPN_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16x3": 1, "f16x3": 2, "fp16x3": 2}
+PRECISIONS = {"f32": 0, "fp32": 0, "float32": 0, "bf16x3": 1, "f16x3": 2, "fp16x3": 2, "f32w": 3}
 BACKBONES = {"vgg16": 0, "mobilenet_v2": 1}
 STATUS_F16_RANGE = 1
 ACTS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "relu6": 3}

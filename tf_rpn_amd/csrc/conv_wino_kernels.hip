@@ -1,0 +1,329 @@
+// conv_wino_kernels.hip -- 3x3 stride-1 'same' convolution as Winograd F(2x2, 3x3) on the float32 MFMA (precision "f32w").
+//
+// The exact-float32 implicit GEMM (conv_kernels.hip) is bound by the float32 matrix pipe: 157.3 TFLOP/s / 156.55 GFLOP per VGG16
+// image = 1005 images/s at 100 %.  Winograd's minimal filtering computes each 2 x 2 output tile of a 3 x 3 conv from
+// a 4 x 4 input patch with 16 multiplications per (input channel, output channel) instead of 36: 2.25 x fewer MFMA flops, all still
+// float32 multiply-adds with float32 accumulation -- the transforms only add and subtract (the filter transform's halves are exact
+// in binary).  The sums are taken in another order than the direct conv's, so the results differ from it by rounding (measured
+// against float64: 2-3e-6 at |y| ~ 4, the direct float32 kernel 1-2e-6; the contract of this path is 1e-4): it is a precision of
+// its own ("f32w"), never a silent replacement of "f32".
+//   y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        (Lavin & Gray; g: 3 x 3 filter, d: 4 x 4 input patch)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// One launch, everything fused: a workgroup (512 threads = 8 waves, one per CU: 108 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16
+// output pixels x 64 output channels and walks the input channels in slices of 8:
+//   * the slice's 18 x 18 x 8 input patch: buffer loads (out-of-image = out-of-range offset = zeros) -> registers -> LDS `raw`,
+//     channel-major planes;
+//   * the slice's 16 transformed filter matrices U[xi][8][64] (32 KB, packed that way by pack_weights_wino_host): LDS-DMA straight
+//     into the buffer the MFMAs are not reading;
+//   * B^T d B by all 512 threads (tile = tid & 63, channel = tid >> 6: 16 LDS reads, 32 adds, 16 LDS writes) -> V[xi][8][64 tiles];
+//   * 16 independent GEMMs M[xi] += V[xi]^T U[xi]: wave w owns xi = 2 w, 2 w + 1 for all 64 tiles x 64 channels (8 accumulator
+//     blocks of 32 x 32 = 128 registers), 32 x mfma_f32_32x32x2 per slice and wave, one LDS read per MFMA;
+//   * epilogue in four quarters (32 tiles x 32 channels): accumulators -> LDS [xi][tile][channel], A^T M A + bias + activation by
+//     (tile, channel) pairs, 128-byte NHWC stores (or, `pool`, the max of the tile's 2 x 2 outputs = MaxPooling2D(2, 2)).
+// Every output's sum order is fixed by (slice, channel pair) alone: an image's bits do not depend on the batch it is in.
+#include "conv_kernels.h"
+#include "rpn_common.h"
+
+#include <vector>
+
+namespace rpn {
+
+using f32x16_w = __attribute__((ext_vector_type(16))) float;
+using f32x4_w = __attribute__((ext_vector_type(4))) float;
+using u32x4_w = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int kWinoThreads = 512;
+constexpr int kWinoKS = 8;                  // input channels per slice
+constexpr int kWinoBN = 64;                 // output channels per workgroup
+constexpr int kWinoTT = 8;                  // Winograd tiles per workgroup side (8 x 8 tiles = 16 x 16 output pixels)
+constexpr int kRawPitch = 20, kRawPlane = 18 * kRawPitch;       // raw[channel][18][20] (18 columns used)
+constexpr int kUFloats = 16 * kWinoKS * kWinoBN;                // 8192 floats = 32 KB per slice and N tile
+constexpr int kVFloats = 16 * kWinoKS * 64;                     // V[xi][k][tile]
+
+size_t wino_weight_floats(int Cin, int Cout) { return (size_t)((Cout + kWinoBN - 1) / kWinoBN) * (Cin / kWinoKS) * kUFloats; }
+bool wino_supported(int Cin, int Cout) { return Cin >= kWinoKS && Cin % kWinoKS == 0 && Cout >= 32 && Cout % 32 == 0; }
+
+// HWIO (3,3,Cin,Cout) -> U = G g G^T per (c, n), laid out [n_tile][slice][xi = 4 i + j][k][64]; scale[n] (BatchNorm fold) or null.
+// Computed in double and rounded once (the halves are exact, the sums of three weights are not).
+void pack_weights_wino_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst)
+{
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int n_tiles = (Cout + kWinoBN - 1) / kWinoBN, n_slices = Cin / kWinoKS;
+    for (int nt = 0; nt < n_tiles; ++nt)
+        for (int s = 0; s < n_slices; ++s)
+            for (int k = 0; k < kWinoKS; ++k)
+                for (int nn = 0; nn < kWinoBN; ++nn) {
+                    const int c = s * kWinoKS + k, n = nt * kWinoBN + nn;
+                    double g[3][3];
+                    for (int r = 0; r < 3; ++r)
+                        for (int q = 0; q < 3; ++q)
+                            g[r][q] = n < Cout ? (double)hwio[((size_t)(r * 3 + q) * Cin + c) * Cout + n] * (scale ? (double)scale[n] : 1.0) : 0.0;
+                    double t[4][3];
+                    for (int i = 0; i < 4; ++i)
+                        for (int q = 0; q < 3; ++q) t[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) {
+                            const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                            dst[(((size_t)nt * n_slices + s) * 16 + (4 * i + j)) * (kWinoKS * kWinoBN) + k * kWinoBN + nn] = (float)u;
+                        }
+                }
+}
+
+struct WinoArgs {
+    const float *x;          // (B,H,W,Cin) float32 NHWC
+    const float *u;          // pack_weights_wino_host
+    const float *bias;       // (Cout) or null
+    float *out;              // (B,H,W,Cout), or pooled (B,H/2,W/2,Cout)
+    int B, H, W, Cin, Cout;
+    int act, pool;
+};
+
+__device__ __forceinline__ float wino_act(float v, int act)
+{
+    if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ACT_RELU6) return v < 0.0f ? 0.0f : (v > 6.0f ? 6.0f : v);
+    return v;
+}
+
+__device__ __forceinline__ int wino_xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+#define RPN_WINO_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+__global__ void __launch_bounds__(kWinoThreads, 1)
+conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) float Us[2][kUFloats];       // 64 KB: the slice's transformed filters, double-buffered
+    __shared__ __attribute__((aligned(16))) float Vs[kVFloats];          // 32 KB: the slice's transformed input (epilogue: + Us = M staging)
+    __shared__ __attribute__((aligned(16))) float raw[kWinoKS * kRawPlane];   // 11.25 KB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = wg % n_tiles;
+    int mt = wg / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * 2 * kWinoTT, ox0 = tx * 2 * kWinoTT, n0 = nt * kWinoBN;
+
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
+    const int n_slices = a.Cin / kWinoKS;
+    constexpr unsigned kOob = 0x80000000u;
+    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), (short)0, (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
+    const float *ubase = a.u + (size_t)nt * n_slices * kUFloats;
+    const long long ubytes = (long long)n_slices * kUFloats * 4;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
+
+    // this thread's pieces of a slice's raw patch: piece = (pixel of the 18 x 18 patch, half = 4 channels); 648 pieces
+    unsigned r_off[2];                     // byte offset of (pixel, channel 4 * half) in slice 0, or kOob
+    int r_lds[2];                          // float index of raw[4 * half][py][px]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = tid + j * kWinoThreads;
+        const int half = piece & 1, pix = piece >> 1;
+        const int py = pix / 18, px = pix - py * 18;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = piece < 648 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin + 4 * half) * 4) : kOob;
+        r_lds[j] = (4 * half) * kRawPlane + py * kRawPitch + px;
+    }
+    const bool second = tid + kWinoThreads < 648;
+    const bool wave_second = wave * 64 + kWinoThreads < 648;       // (uniform) this wave issues the second raw load at all
+
+    f32x16_w acc[2][2][2];                 // [xi - 2 wave][M block][N block]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][mb][nb][e] = 0.0f;
+
+    // prologue: slice 0's filters by DMA, its raw patch through registers
+    u32x4_w rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], 0, 0);
+    u32x4_w rr1 = {0u, 0u, 0u, 0u};
+    if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[0][(wave * 4 + q) * 256]), 16, (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), 0, 0, 0);
+
+    const int t_tile = tid & 63, t_c = tid >> 6;                    // transform role: (tile, channel of the slice)
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const int kh = lane >> 5, l31 = lane & 31;
+
+    for (int s = 0; s < n_slices; ++s) {
+        const int cur = s & 1;
+        // ---- raw patch of slice s: registers -> LDS (channel-major planes)
+        {
+            const f32x4_w v0 = __builtin_bit_cast(f32x4_w, rr0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[r_lds[0] + i * kRawPlane] = v0[i];
+            if (second) {
+                const f32x4_w v1 = __builtin_bit_cast(f32x4_w, rr1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) raw[r_lds[1] + i * kRawPlane] = v1[i];
+            }
+        }
+        __syncthreads();
+        // ---- next slice's operands on their way (registers / the other filter buffer) under this slice's work
+        if (s + 1 < n_slices) {
+            const int cb = (s + 1) * kWinoKS * 4;
+            rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], cb, 0);
+            if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], cb, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[cur ^ 1][(wave * 4 + q) * 256]), 16,
+                                                         (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), (s + 1) * kUFloats * 4, 0, 0);
+        }
+        // ---- input transform V = B^T d B of (tile, channel)
+        {
+            const float *rp = raw + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
+                const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
+                d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
+            }
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+            float *vp = Vs + t_c * 64 + t_tile;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vp[(4 * i + 0) * (kWinoKS * 64)] = t[i][0] - t[i][2];
+                vp[(4 * i + 1) * (kWinoKS * 64)] = t[i][1] + t[i][2];
+                vp[(4 * i + 2) * (kWinoKS * 64)] = t[i][2] - t[i][1];
+                vp[(4 * i + 3) * (kWinoKS * 64)] = t[i][1] - t[i][3];
+            }
+        }
+        // the DMA of THIS slice's filters (issued one slice ago, or in the prologue) has landed: everything but the loads issued
+        // just above -- 2 register loads + 4 DMAs per thread, fewer on threads without a second piece and on the last slice
+        if (s + 1 < n_slices) {
+            if (wave_second) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // ---- 16 GEMMs: this wave's two xi, 64 tiles x 64 channels, k pairs (2 kp, 2 kp + 1)
+        {
+            const float *U = Us[cur];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xi = 2 * wave + j;
+                const float *vb = Vs + xi * (kWinoKS * 64) + l31;
+                const float *ub = U + xi * (kWinoKS * kWinoBN) + l31;
+#pragma unroll
+                for (int kp = 0; kp < kWinoKS / 2; ++kp) {
+                    const int k = 2 * kp + kh;
+                    const float a0 = vb[k * 64], a1 = vb[k * 64 + 32];
+                    const float b0 = ub[k * kWinoBN], b1 = ub[k * kWinoBN + 32];
+                    acc[j][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[j][0][0], 0, 0, 0);
+                    acc[j][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[j][0][1], 0, 0, 0);
+                    acc[j][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[j][1][0], 0, 0, 0);
+                    acc[j][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[j][1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                    // V and raw are rewritten by the next slice
+    }
+
+    // ---- epilogue: four quarters (M block, N block); M staging [xi][32 tiles][32 channels] = 64 KB over Us
+    float *Ms = &Us[0][0];
+    const int e_n = tid & 31;               // output role: channel of the quarter, tiles e_t0 and e_t0 + 16 of the quarter
+    const int e_t0 = tid >> 5;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xi = 2 * wave + j;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;            // tile of the block
+                    Ms[(xi * 32 + row) * 32 + l31] = acc[j][mb][nb][e];
+                }
+            }
+            __syncthreads();
+            const int n = n0 + nb * 32 + e_n;
+            const float bias = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tl = e_t0 + 16 * h;                                   // tile inside the block
+                const int tile = mb * 32 + tl;
+                const int tyy = tile >> 3, txx = tile & 7;
+                float m[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) m[i][jj] = Ms[((4 * i + jj) * 32 + tl) * 32 + e_n];
+                float r[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    r[0][jj] = m[0][jj] + m[1][jj] + m[2][jj];
+                    r[1][jj] = m[1][jj] - m[2][jj] - m[3][jj];
+                }
+                float y[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    y[i][0] = r[i][0] + r[i][1] + r[i][2];
+                    y[i][1] = r[i][1] - r[i][2] - r[i][3];
+                }
+                const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
+                if (n < a.Cout) {
+                    if (a.pool) {
+                        // MaxPooling2D(2, 2) 'valid': the tile's four outputs are one window; max commutes with + bias and
+                        // the monotone activation; a window that reaches past an odd edge is dropped
+                        const int PH = a.H >> 1, PW = a.W >> 1, py = oy >> 1, px = ox >> 1;
+                        if (py < PH && px < PW) {
+                            const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+                            a.out[(((size_t)img * PH + py) * PW + px) * a.Cout + n] = wino_act(v + bias, a.act);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj)
+                                if (oy + i < a.H && ox + jj < a.W)
+                                    a.out[(((size_t)img * a.H + oy + i) * a.W + ox + jj) * a.Cout + n] = wino_act(y[i][jj] + bias, a.act);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+#undef RPN_WINO_LDS_PTR
+
+hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias, float *out, int B, int H, int W, int Cin,
+                               int Cout, int act, bool pool, hipStream_t s)
+{
+    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
+    if ((long long)H * W * Cin * 4 > 0x7fffffffll) return hipErrorInvalidValue;
+    WinoArgs a{};
+    a.x = x; a.u = u; a.bias = bias; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act; a.pool = pool ? 1 : 0;
+    const int tiles_x = (W + 2 * kWinoTT - 1) / (2 * kWinoTT), tiles_y = (H + 2 * kWinoTT - 1) / (2 * kWinoTT);
+    const int n_tiles = (Cout + kWinoBN - 1) / kWinoBN;
+    const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles;
+    if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv3x3_wino_f32_kernel, dim3((unsigned)nblocks), dim3(kWinoThreads), 0, s, a, tiles_x, tiles_y, n_tiles);
+    return hipGetLastError();
+}
+
+}  // namespace rpn

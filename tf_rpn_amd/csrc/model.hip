@@ -60,6 +60,7 @@ struct Op {
     bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
     bool f32_out_split = false;        // float32 implicit-GEMM conv writing SPLIT16 directly (its consumer is a split conv)
+    bool wino = false;                 // precision F32W: 3x3 stride-1 'same' conv as float32 Winograd F(2x2, 3x3) (conv_wino_kernels.hip)
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
     // OP_IRBLOCK (one fused MobileNetV2 block; Cin / Cout = block input / output channels, stride = the depthwise's):
     int cexp = 0;                      // expanded channels
@@ -80,7 +81,8 @@ using namespace rpn;
 
 struct rpn_model {
     int backbone = 0, img_size = 0, K = 0, precision = 0, max_batch = 0;
-    bool use_split = false, f16 = false;   // precision != F32: eligible 3x3 convs use the split kernel
+    bool use_split = false, f16 = false;   // precision BF16X3 / F16X3: eligible 3x3 convs use the split kernel
+    bool wino = false;                     // precision F32W: eligible 3x3 convs use the float32 Winograd kernel
     int F = 0, feat_tensor = -1;
     bool keep_all = false;
     std::vector<Tensor> tensors;
@@ -215,6 +217,8 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     op.cin3_mfma = op.cin3 && m->use_split && m->f16 && (Cout == 32 || Cout == 64) &&
                    (RPN_LAB_KNOB("RPN_CIN3_MFMA", 1) != 0);
     op.out_f32 = split && force_f32_out;
+    op.wino = m->wino && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == ti.H && OW == ti.W && residual < 0 &&
+              act != ACT_SIGMOID && !op.cin3 && !ti.external && wino_supported(ti.C, Cout);
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
@@ -516,6 +520,11 @@ static void plan_weights(rpn_model *m)
             off += (split_weight_bytes(op.Cin, op.Cout) / sizeof(float) + 63) & ~(size_t)63;
             op.b_off = off;
             off += (size_t)split_cout_pad(op.Cout);
+        } else if (op.kind == OP_CONV && op.wino) {
+            op.w_off = off;
+            off += (wino_weight_floats(op.Cin, op.Cout) + 63) & ~(size_t)63;
+            op.b_off = off;
+            off += (size_t)op.ps.cout_pad;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             op.w_off = off;
             off += (op.ps.floats() + 63) & ~(size_t)63;
@@ -599,13 +608,15 @@ extern "C" int rpn_model_create(int backbone, int img_size, int anchor_count, in
     RPN_REQUIRE(anchor_count >= 1 && anchor_count <= 64, "rpn_model_create: anchor_count %d out of range",
                 anchor_count);
     RPN_REQUIRE(max_batch >= 1, "rpn_model_create: max_batch must be >= 1");
-    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3,
+    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3 ||
+                    precision == RPN_PRECISION_F32W,
                 "rpn_model_create: unknown precision %d", precision);
     rpn_model *m = new rpn_model();
     m->backbone = backbone; m->img_size = img_size; m->K = anchor_count; m->precision = precision;
     m->max_batch = max_batch;
-    m->use_split = precision != RPN_PRECISION_F32;
+    m->use_split = precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3;
     m->f16 = precision == RPN_PRECISION_F16X3;
+    m->wino = precision == RPN_PRECISION_F32W;
     if (backbone == RPN_BACKBONE_VGG16) build_vgg16(m);
     else build_mobilenet_v2(m);
     m->F = m->tensors[m->feat_tensor].H;
@@ -842,6 +853,11 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
                                 hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
+    } else if (op.wino) {
+        std::vector<float> packed(wino_weight_floats(p.Cin, p.Cout));
+        pack_weights_wino_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, packed.data());
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float), hipMemcpyHostToDevice));
     } else if (is_pw_x3(m, op)) {
         // [Cin][Cout] with BatchNorm folded, then the power-of-two pre-scale and the fragment-major hi / lo float16 image
         std::vector<float> w((size_t)p.Cin * p.Cout);
@@ -977,6 +993,12 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
         } else if (is_pw_x3(m, op)) {
             e = launch_pw_x3(x, (long long)B * op.H * op.W, op.Cin, op.Cout, m->d_weights + op.w_off, m->d_weights + op.b_off,
                              op.out_scale, tensor_ptr(m, op.out, d_imgs), m->d_status, s);
+        } else if (op.kind == OP_CONV && op.wino) {
+            const bool pool = f32_pool_fused(m, oi);                    // + block*_pool: a Winograd tile's 2 x 2 outputs are one window
+            e = launch_conv3x3_wino(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
+                                    tensor_ptr(m, pool ? m->ops[oi + 1].out : op.out, d_imgs), B, op.H, op.W, op.Cin, op.Cout, op.act,
+                                    pool, s);
+            skip_next = pool;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
             a.x = x;
@@ -1136,6 +1158,8 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
             snprintf(kname32, sizeof kname32, "rpn_head_splitk<%d>", (op.Cout + 15) / 16);
         else if (is_pw_x3(m, op))
             snprintf(kname32, sizeof kname32, "pw_f16x3<%d,%d>", op.Cin, op.Cout);
+        else if (op.kind == OP_CONV && op.wino)
+            snprintf(kname32, sizeof kname32, "conv3x3_wino_f32<16x16x64>");      // (fl above: the direct conv's flops; 2.25 x fewer are executed)
         else
         {
             const int bn32 = conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout);
@@ -1180,6 +1204,7 @@ extern "C" int rpn_model_op_arith(const rpn_model *m, int i)
     const Op &op = m->ops[i];
     const bool x3 = (op.kind == OP_CONV && (op.split || op.cin3_mfma)) || op.kind == OP_VGGB1 || (op.kind == OP_IRBLOCK && op.ir_x3) ||
                     is_pw_x3(m, op);
+    if (op.kind == OP_CONV && op.wino) return RPN_PRECISION_F32W;     // float32 MFMA, 1 / 2.25 of the direct conv's multiply-adds
     return x3 ? (m->f16 ? RPN_PRECISION_F16X3 : RPN_PRECISION_BF16X3) : RPN_PRECISION_F32;
 }
 
@@ -1253,10 +1278,30 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
                     OH >= 1 && OW >= 1 && pad_t >= 0 && pad_l >= 0,
                 "rpn_conv2d: bad geometry");
     RPN_REQUIRE(act >= 0 && act <= 3, "rpn_conv2d: bad activation %d", act);
-    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3,
+    RPN_REQUIRE(precision == RPN_PRECISION_F32 || precision == RPN_PRECISION_BF16X3 || precision == RPN_PRECISION_F16X3 ||
+                    precision == RPN_PRECISION_F32W,
                 "rpn_conv2d: unknown precision %d", precision);
     RPN_REQUIRE_DEVICE();
     hipStream_t s = as_stream(stream);
+    if (precision == RPN_PRECISION_F32W) {
+        // float32 Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1 only; transforms and packs the weights on the host
+        if (!(R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && wino_supported(Cin, Cout) &&
+              act != ACT_SIGMOID))
+            return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the Winograd path needs 3x3 s1 'same', Cin %% 8 == 0, Cout %% 32 == 0");
+        const size_t wcount = (size_t)9 * Cin * Cout;
+        std::vector<float> hw(wcount), packed(wino_weight_floats(Cin, Cout));
+        RPN_HIP_CHECK(hipMemcpy(hw.data(), d_w, wcount * sizeof(float), hipMemcpyDeviceToHost));
+        pack_weights_wino_host(hw.data(), nullptr, Cin, Cout, packed.data());
+        float *d_u = nullptr;
+        RPN_HIP_CHECK(hipMalloc(&d_u, packed.size() * sizeof(float)));
+        hipError_t e = hipMemcpy(d_u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_conv3x3_wino(d_x, d_u, d_bias, d_out, B, H, W, Cin, Cout, act, false, s);
+        const hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(d_u);
+        if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(f32w): launch failed: %s", hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(f32w): kernel failed: %s", hipGetErrorString(e2));
+        return RPN_OK;
+    }
     if (precision != RPN_PRECISION_F32) {
         // x3-split path: 3x3 / stride 1 / pad 1 only; converts x to SPLIT16 and packs the weights on the host
         if (!(R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && Cin % 16 == 0 &&

@@ -214,7 +214,7 @@ class RPNModel(object):
             kernel = kb.value.decode()
             out.append({"name": nb.value.decode(), "kernel": kernel, "flops_per_image": fl.value,
                         "bytes_per_image": by.value,
-                        "arith": {0: "f32", 1: "bf16x3", 2: "f16x3"}[lib.rpn_model_op_arith(self._h, i)],
+                        "arith": {0: "f32", 1: "bf16x3", 2: "f16x3", 3: "f32w"}[lib.rpn_model_op_arith(self._h, i)],
                         "launches": 0 if kernel.startswith("fused:") else 1})
         return out
 

@@ -514,7 +514,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--nms", action="store_true", help="NMS(test_nms_topn) proposals instead of the plain top-k")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f32w", "bf16x3", "f16x3"])
     ap.add_argument("--out", default=None, help="write the proposals as JSON here (default: stdout)")
     args = ap.parse_args(argv)
     io_utils.is_valid_backbone(args.backbone)
