@@ -9,7 +9,7 @@
 // its own ("f32w"), never a silent replacement of "f32".
 //   y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        (Lavin & Gray; g: 3 x 3 filter, d: 4 x 4 input patch)
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
-// One launch, everything fused: a workgroup (512 threads = 8 waves, one per CU: 108 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16
+// One launch, everything fused: a workgroup (512 threads = 8 waves, one per CU: 150 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16
 // output pixels x 64 output channels and walks the input channels in slices of 8:
 //   * the slice's 18 x 18 x 8 input patch: buffer loads (out-of-image = out-of-range offset = zeros) -> registers -> LDS `raw`,
 //     channel-major planes;
@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(kWinoThreads, 1)
 conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) float Us[2][kUFloats];       // 64 KB: the slice's transformed filters, double-buffered
-    __shared__ __attribute__((aligned(16))) float Vs[kVFloats];          // 32 KB: the slice's transformed input (epilogue: + Us = M staging)
-    __shared__ __attribute__((aligned(16))) float raw[kWinoKS * kRawPlane];   // 11.25 KB
+    __shared__ __attribute__((aligned(16))) float Vs[2][kVFloats];       // 64 KB: the slice's transformed input, double-buffered
+    __shared__ __attribute__((aligned(16))) float raws[2][kWinoKS * kRawPlane];   // 22.5 KB: the slice's input patch, double-buffered
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,7 +135,6 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         r_lds[j] = (4 * half) * kRawPlane + py * kRawPitch + px;
     }
     const bool second = tid + kWinoThreads < 648;
-    const bool wave_second = wave * 64 + kWinoThreads < 648;       // (uniform) this wave issues the second raw load at all
 
     f32x16_w acc[2][2][2];                 // [xi - 2 wave][M block][N block]
 #pragma unroll
@@ -147,85 +146,101 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][mb][nb][e] = 0.0f;
 
-    // prologue: slice 0's filters by DMA, its raw patch through registers
-    u32x4_w rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], 0, 0);
-    u32x4_w rr1 = {0u, 0u, 0u, 0u};
-    if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[0][(wave * 4 + q) * 256]), 16, (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), 0, 0, 0);
-
     const int t_tile = tid & 63, t_c = tid >> 6;                    // transform role: (tile, channel of the slice)
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     const int kh = lane >> 5, l31 = lane & 31;
 
+    // the pieces of the pipeline (all indices wave-uniform; no DMA builtin inside a lambda: the host pass drops the kernel's stub)
+#define RPN_WINO_DMA_U(SLICE, BUF)                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[BUF][(wave * 4 + q) * 256]), 16,                 \
+                                                 (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), (SLICE) * kUFloats * 4, 0, 0)
+    auto raw_to_lds = [&](const u32x4_w &q0, const u32x4_w &q1, int buf) {          // this thread's pieces -> channel-major planes
+        float *raw = raws[buf];
+        const f32x4_w v0 = __builtin_bit_cast(f32x4_w, q0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[r_lds[0] + i * kRawPlane] = v0[i];
+        if (second) {
+            const f32x4_w v1 = __builtin_bit_cast(f32x4_w, q1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[r_lds[1] + i * kRawPlane] = v1[i];
+        }
+    };
+    auto transform = [&](int buf) {                                  // V[buf] = B^T d B of (tile, channel) from raws[buf]
+        const float *rp = raws[buf] + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
+            const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
+            d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
+        }
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j];
+            t[1][j] = d[1][j] + d[2][j];
+            t[2][j] = d[2][j] - d[1][j];
+            t[3][j] = d[1][j] - d[3][j];
+        }
+        float *vp = Vs[buf] + t_c * 64 + t_tile;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vp[(4 * i + 0) * (kWinoKS * 64)] = t[i][0] - t[i][2];
+            vp[(4 * i + 1) * (kWinoKS * 64)] = t[i][1] + t[i][2];
+            vp[(4 * i + 2) * (kWinoKS * 64)] = t[i][2] - t[i][1];
+            vp[(4 * i + 3) * (kWinoKS * 64)] = t[i][1] - t[i][3];
+        }
+    };
+
+    // ---- prologue: slice 0 complete (raw -> V[0], U[0]), slice 1's raw patch in LDS
+    u32x4_w rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], 0, 0);
+    u32x4_w rr1 = {0u, 0u, 0u, 0u};
+    if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], 0, 0);
+    RPN_WINO_DMA_U(0, 0);
+    raw_to_lds(rr0, rr1, 0);
+    if (n_slices > 1) {
+        rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], kWinoKS * 4, 0);
+        if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], kWinoKS * 4, 0);
+    }
+    __syncthreads();
+    transform(0);
+    if (n_slices > 1) raw_to_lds(rr0, rr1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- steady state, ONE barrier per slice.  Between the barriers of iteration s a wave runs, in any interleaving the
+    // scheduler likes: the MFMAs of slice s (V[s & 1], U[s & 1]); the transform of slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1],
+    // last read by the MFMAs of slice s - 1); the register loads of slice s + 2's patch and, at the end, their way into
+    // raws[s & 1] (last read by the transform of slice s); the DMA of slice s + 1's filters into U[(s + 1) & 1].
     for (int s = 0; s < n_slices; ++s) {
         const int cur = s & 1;
-        // ---- raw patch of slice s: registers -> LDS (channel-major planes)
-        {
-            const f32x4_w v0 = __builtin_bit_cast(f32x4_w, rr0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) raw[r_lds[0] + i * kRawPlane] = v0[i];
-            if (second) {
-                const f32x4_w v1 = __builtin_bit_cast(f32x4_w, rr1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) raw[r_lds[1] + i * kRawPlane] = v1[i];
-            }
-        }
-        __syncthreads();
-        // ---- next slice's operands on their way (registers / the other filter buffer) under this slice's work
-        if (s + 1 < n_slices) {
-            const int cb = (s + 1) * kWinoKS * 4;
+#ifndef RPN_EXP_WINO_NOLOAD      /* timing experiments (wrong results): NOLOAD = no global traffic inside the slice loop */
+        if (s + 2 < n_slices) {
+            const int cb = (s + 2) * kWinoKS * 4;
             rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], cb, 0);
             if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], cb, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[cur ^ 1][(wave * 4 + q) * 256]), 16,
-                                                         (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), (s + 1) * kUFloats * 4, 0, 0);
         }
-        // ---- input transform V = B^T d B of (tile, channel)
-        {
-            const float *rp = raw + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
-            float d[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
-                const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
-                d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
-            }
-            float t[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j];
-                t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j];
-                t[3][j] = d[1][j] - d[3][j];
-            }
-            float *vp = Vs + t_c * 64 + t_tile;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vp[(4 * i + 0) * (kWinoKS * 64)] = t[i][0] - t[i][2];
-                vp[(4 * i + 1) * (kWinoKS * 64)] = t[i][1] + t[i][2];
-                vp[(4 * i + 2) * (kWinoKS * 64)] = t[i][2] - t[i][1];
-                vp[(4 * i + 3) * (kWinoKS * 64)] = t[i][1] - t[i][3];
-            }
-        }
-        // the DMA of THIS slice's filters (issued one slice ago, or in the prologue) has landed: everything but the loads issued
-        // just above -- 2 register loads + 4 DMAs per thread, fewer on threads without a second piece and on the last slice
         if (s + 1 < n_slices) {
-            if (wave_second) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RPN_WINO_DMA_U(s + 1, cur ^ 1);
         }
-        __syncthreads();
-        // ---- 16 GEMMs: this wave's two xi, 64 tiles x 64 channels, k pairs (2 kp, 2 kp + 1)
+#endif
+        // Waves w and w + 4 share a SIMD: the upper four transform FIRST, so that one wave of every SIMD feeds the matrix pipe while
+        // the other does the transform's vector / LDS work (+1 %: both in the same order left the pipe idle while both transformed).
+#ifndef RPN_EXP_WINO_NOTRANSFORM
+        if (wave >= 4 && s + 1 < n_slices) transform(cur ^ 1);
+#endif
+        // ---- 16 GEMMs: this wave's two xi, 64 tiles x 64 channels, k pairs (2 kp, 2 kp + 1).  (Requesting all 32 fragment values
+        // of the slice first and issuing the 32 MFMAs back to back behind a scheduling barrier measured 6 % SLOWER: the compiler's own
+        // order interleaves the transform's vector / LDS instructions with the MFMAs.)
+#ifndef RPN_EXP_WINO_NOMFMA
         {
             const float *U = Us[cur];
+            const float *V = Vs[cur];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int xi = 2 * wave + j;
-                const float *vb = Vs + xi * (kWinoKS * 64) + l31;
+                const float *vb = V + xi * (kWinoKS * 64) + l31;
                 const float *ub = U + xi * (kWinoKS * kWinoBN) + l31;
 #pragma unroll
                 for (int kp = 0; kp < kWinoKS / 2; ++kp) {
@@ -239,8 +254,17 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
                 }
             }
         }
-        __syncthreads();                    // V and raw are rewritten by the next slice
+#endif
+#ifndef RPN_EXP_WINO_NOTRANSFORM
+        if (wave < 4 && s + 1 < n_slices) transform(cur ^ 1);
+#endif
+#ifndef RPN_EXP_WINO_NOLOAD
+        if (s + 2 < n_slices) raw_to_lds(rr0, rr1, cur);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // slice s + 1's filters have landed
+        __syncthreads();
     }
+#undef RPN_WINO_DMA_U
 
     // ---- epilogue: four quarters (M block, N block); M staging [xi][32 tiles][32 channels] = 64 KB over Us
     float *Ms = &Us[0][0];
