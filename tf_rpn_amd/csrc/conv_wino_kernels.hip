@@ -9,17 +9,24 @@
 // its own ("f32w"), never a silent replacement of "f32".
 //   y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        (Lavin & Gray; g: 3 x 3 filter, d: 4 x 4 input patch)
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
-// One launch, everything fused: a workgroup (512 threads = 8 waves, one per CU: 150 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16
-// output pixels x 64 output channels and walks the input channels in slices of 8:
-//   * the slice's 18 x 18 x 8 input patch: buffer loads (out-of-image = out-of-range offset = zeros) -> registers -> LDS `raw`,
-//     channel-major planes;
+// One launch, everything fused: a workgroup (768 threads, one per CU: 150 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16 output
+// pixels x 64 output channels and walks the input channels in slices of 8, ONE workgroup barrier per slice, two wave roles:
+//   STAGING waves 8 .. 11 (one per SIMD), one slice ahead of the MFMAs:
+//   * the slice's 18 x 18 x 8 input patch: buffer loads (out-of-image = out-of-range offset = zeros) -> registers -> LDS `raws`,
+//     channel-major planes, double-buffered;
 //   * the slice's 16 transformed filter matrices U[xi][8][64] (32 KB, packed that way by pack_weights_wino_host): LDS-DMA straight
 //     into the buffer the MFMAs are not reading;
-//   * B^T d B by all 512 threads (tile = tid & 63, channel = tid >> 6: 16 LDS reads, 32 adds, 16 LDS writes) -> V[xi][8][64 tiles];
+//   * B^T d B per (tile, channel): 8 LDS reads, 32 adds, 16 LDS writes -> V[xi][8][64 tiles], double-buffered;
+//   MFMA waves 0 .. 7 (two per SIMD):
 //   * 16 independent GEMMs M[xi] += V[xi]^T U[xi]: wave w owns xi = 2 w, 2 w + 1 for all 64 tiles x 64 channels (8 accumulator
-//     blocks of 32 x 32 = 128 registers), 32 x mfma_f32_32x32x2 per slice and wave, one LDS read per MFMA;
+//     blocks of 32 x 32 = 128 registers), 32 x mfma_f32_32x32x2 per slice and wave, one LDS read per MFMA, the operands of the
+//     next group of four MFMAs requested before the current group is issued;
 //   * epilogue in four quarters (32 tiles x 32 channels): accumulators -> LDS [xi][tile][channel], A^T M A + bias + activation by
 //     (tile, channel) pairs, 128-byte NHWC stores (or, `pool`, the max of the tile's 2 x 2 outputs = MaxPooling2D(2, 2)).
+// Measured (VGG16, batch 8, round 5; timing experiments -DRPN_EXP_WINO_*): with the staging compiled out the slice loop runs at
+// 0.87 of the f32 MFMA rate (block3_conv2 0.556 ms -- the same ceiling the direct kernel shows without its gather); with it 0.685 ms:
+// on this chip a SIMD's vector-ALU / LDS-issue work is ADDED to its float32-MFMA time, whichever wave it comes from (one instruction
+// stream for everything: 0.694; roles: 0.685; the transform alone ~11 %, the patch + filter staging ~9 %).
 // Every output's sum order is fixed by (slice, channel pair) alone: an image's bits do not depend on the batch it is in.
 #include "conv_kernels.h"
 #include "rpn_common.h"
@@ -32,7 +39,7 @@ using f32x16_w = __attribute__((ext_vector_type(16))) float;
 using f32x4_w = __attribute__((ext_vector_type(4))) float;
 using u32x4_w = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int kWinoThreads = 512;
+constexpr int kWinoThreads = 768;              // 8 MFMA waves + 4 staging waves
 constexpr int kWinoKS = 8;                  // input channels per slice
 constexpr int kWinoBN = 64;                 // output channels per workgroup
 constexpr int kWinoTT = 8;                  // Winograd tiles per workgroup side (8 x 8 tiles = 16 x 16 output pixels)
@@ -121,20 +128,123 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const long long ubytes = (long long)n_slices * kUFloats * 4;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
 
-    // this thread's pieces of a slice's raw patch: piece = (pixel of the 18 x 18 patch, half = 4 channels); 648 pieces
-    unsigned r_off[2];                     // byte offset of (pixel, channel 4 * half) in slice 0, or kOob
-    int r_lds[2];                          // float index of raw[4 * half][py][px]
+    // Wave roles: waves 0 .. 7 are the MFMA waves (two per SIMD), waves 8 .. 11 (one per SIMD) the STAGING waves -- they fetch the
+    // raw patches, run the input transform and issue the filter DMAs, so that the MFMA waves' instruction streams hold nothing but
+    // fragment reads and MFMAs (with everything in one stream the transform's ~700 cycles and the staging's ~570 per slice were
+    // simply added to the MFMAs' 4096: a wave waiting for the matrix pipe cannot issue its vector instructions either).
+    const bool stager = wave >= 8;
+    const int hid = tid - 512;             // staging thread 0 .. 255
+    // a staging thread's pieces of a slice's raw patch: piece = (pixel of the 18 x 18 patch, half = 4 channels); 648 pieces
+    unsigned r_off[3];                     // byte offset of (pixel, channel 4 * half) in slice 0, or kOob
+    int r_lds[3];                          // float index of raw[4 * half][py][px]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int piece = tid + j * kWinoThreads;
+    for (int j = 0; j < 3; ++j) {
+        const int piece = hid + j * 256;
         const int half = piece & 1, pix = piece >> 1;
         const int py = pix / 18, px = pix - py * 18;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool v = piece < 648 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const bool v = stager && piece < 648 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin + 4 * half) * 4) : kOob;
         r_lds[j] = (4 * half) * kRawPlane + py * kRawPitch + px;
     }
-    const bool second = tid + kWinoThreads < 648;
+    const bool third = hid + 512 < 648;
+
+    const int t_tile = hid & 63, t_c0 = hid >> 6;                   // transform role: tile, channels t_c0 and t_c0 + 4 of the slice
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int sw = wave - 8;               // staging wave 0 .. 3
+
+    // the pieces of the pipeline (all indices wave-uniform; no DMA builtin inside a lambda: the host pass drops the kernel's stub)
+#define RPN_WINO_DMA_U(SLICE, BUF)                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[BUF][(sw * 8 + q) * 256]), 16,                   \
+                                                 (unsigned)(((sw * 8 + q) * 256 + lane * 4) * 4), (SLICE) * kUFloats * 4, 0, 0)
+#define RPN_WINO_LOAD_RAW(CB)                                                                                               \
+    do {                                                                                                                    \
+        rr[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (CB), 0);                                              \
+        rr[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (CB), 0);                                              \
+        if (third) rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);                                   \
+    } while (0)
+    u32x4_w rr[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    auto raw_to_lds = [&](int buf) {                                 // this thread's pieces -> channel-major planes
+        float *raw = raws[buf];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < 2 || third) {
+                const f32x4_w v = __builtin_bit_cast(f32x4_w, rr[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) raw[r_lds[j] + i * kRawPlane] = v[i];
+            }
+    };
+    auto transform = [&](int buf) {                                  // V[buf] = B^T d B of (tile, channel) from raws[buf]
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int t_c = t_c0 + 4 * r;
+            const float *rp = raws[buf] + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
+                const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
+                d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
+            }
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+            float *vp = Vs[buf] + t_c * 64 + t_tile;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vp[(4 * i + 0) * (kWinoKS * 64)] = t[i][0] - t[i][2];
+                vp[(4 * i + 1) * (kWinoKS * 64)] = t[i][1] + t[i][2];
+                vp[(4 * i + 2) * (kWinoKS * 64)] = t[i][2] - t[i][1];
+                vp[(4 * i + 3) * (kWinoKS * 64)] = t[i][1] - t[i][3];
+            }
+        }
+    };
+
+    // The two roles are two separate instruction streams with the same NUMBER of workgroup barriers (2 + n_slices + 8): the
+    // accumulators are live in the MFMA waves' stream only (one stream for both roles: 392 spilled registers at the 168 a
+    // twelve-wave workgroup may have).
+    if (stager) {
+        // ---- prologue: slice 0 complete (raw -> V[0], U[0]), slice 1's raw patch in LDS
+        RPN_WINO_LOAD_RAW(0);
+        RPN_WINO_DMA_U(0, 0);
+        raw_to_lds(0);
+        if (n_slices > 1) RPN_WINO_LOAD_RAW(kWinoKS * 4);
+        __syncthreads();
+        transform(0);
+        if (n_slices > 1) raw_to_lds(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- steady state, ONE barrier per slice.  Between the barriers of iteration s the MFMA waves run the MFMAs of slice s
+        // (V[s & 1], U[s & 1]); the staging waves transform slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1], last read by the MFMAs
+        // of slice s - 1), fetch slice s + 2's patch into registers and, at the end, into raws[s & 1] (last read by the transform
+        // of slice s), and DMA slice s + 1's filters into U[(s + 1) & 1].
+        for (int s = 0; s < n_slices; ++s) {
+            const int cur = s & 1;
+#ifdef RPN_EXP_WINO_NOSTAGE      /* timing experiment (wrong results): the staging waves only keep the barriers */
+            (void)cur;
+            __syncthreads();
+            continue;
+#endif
+            if (s + 2 < n_slices) RPN_WINO_LOAD_RAW((s + 2) * kWinoKS * 4);
+            if (s + 1 < n_slices) {
+                RPN_WINO_DMA_U(s + 1, cur ^ 1);
+                transform(cur ^ 1);
+            }
+            if (s + 2 < n_slices) raw_to_lds(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slice s + 1's filters have landed
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int q = 0; q < 8; ++q) __syncthreads();                 // the epilogue's barriers (four quarters x 2)
+        return;
+    }
 
     f32x16_w acc[2][2][2];                 // [xi - 2 wave][M block][N block]
 #pragma unroll
@@ -145,130 +255,45 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][mb][nb][e] = 0.0f;
-
-    const int t_tile = tid & 63, t_c = tid >> 6;                    // transform role: (tile, channel of the slice)
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int kh = lane >> 5, l31 = lane & 31;
-
-    // the pieces of the pipeline (all indices wave-uniform; no DMA builtin inside a lambda: the host pass drops the kernel's stub)
-#define RPN_WINO_DMA_U(SLICE, BUF)                                                                                          \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[BUF][(wave * 4 + q) * 256]), 16,                 \
-                                                 (unsigned)(((wave * 4 + q) * 256 + lane * 4) * 4), (SLICE) * kUFloats * 4, 0, 0)
-    auto raw_to_lds = [&](const u32x4_w &q0, const u32x4_w &q1, int buf) {          // this thread's pieces -> channel-major planes
-        float *raw = raws[buf];
-        const f32x4_w v0 = __builtin_bit_cast(f32x4_w, q0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) raw[r_lds[0] + i * kRawPlane] = v0[i];
-        if (second) {
-            const f32x4_w v1 = __builtin_bit_cast(f32x4_w, q1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) raw[r_lds[1] + i * kRawPlane] = v1[i];
-        }
-    };
-    auto transform = [&](int buf) {                                  // V[buf] = B^T d B of (tile, channel) from raws[buf]
-        const float *rp = raws[buf] + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
-        float d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
-            const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
-            d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
-        }
-        float t[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = d[0][j] - d[2][j];
-            t[1][j] = d[1][j] + d[2][j];
-            t[2][j] = d[2][j] - d[1][j];
-            t[3][j] = d[1][j] - d[3][j];
-        }
-        float *vp = Vs[buf] + t_c * 64 + t_tile;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vp[(4 * i + 0) * (kWinoKS * 64)] = t[i][0] - t[i][2];
-            vp[(4 * i + 1) * (kWinoKS * 64)] = t[i][1] + t[i][2];
-            vp[(4 * i + 2) * (kWinoKS * 64)] = t[i][2] - t[i][1];
-            vp[(4 * i + 3) * (kWinoKS * 64)] = t[i][1] - t[i][3];
-        }
-    };
-
-    // ---- prologue: slice 0 complete (raw -> V[0], U[0]), slice 1's raw patch in LDS
-    u32x4_w rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], 0, 0);
-    u32x4_w rr1 = {0u, 0u, 0u, 0u};
-    if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], 0, 0);
-    RPN_WINO_DMA_U(0, 0);
-    raw_to_lds(rr0, rr1, 0);
-    if (n_slices > 1) {
-        rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], kWinoKS * 4, 0);
-        if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], kWinoKS * 4, 0);
-    }
     __syncthreads();
-    transform(0);
-    if (n_slices > 1) raw_to_lds(rr0, rr1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    // ---- steady state, ONE barrier per slice.  Between the barriers of iteration s a wave runs, in any interleaving the
-    // scheduler likes: the MFMAs of slice s (V[s & 1], U[s & 1]); the transform of slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1],
-    // last read by the MFMAs of slice s - 1); the register loads of slice s + 2's patch and, at the end, their way into
-    // raws[s & 1] (last read by the transform of slice s); the DMA of slice s + 1's filters into U[(s + 1) & 1].
     for (int s = 0; s < n_slices; ++s) {
         const int cur = s & 1;
-#ifndef RPN_EXP_WINO_NOLOAD      /* timing experiments (wrong results): NOLOAD = no global traffic inside the slice loop */
-        if (s + 2 < n_slices) {
-            const int cb = (s + 2) * kWinoKS * 4;
-            rr0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], cb, 0);
-            if (second) rr1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], cb, 0);
-        }
-        if (s + 1 < n_slices) {
-            RPN_WINO_DMA_U(s + 1, cur ^ 1);
-        }
-#endif
-        // Waves w and w + 4 share a SIMD: the upper four transform FIRST, so that one wave of every SIMD feeds the matrix pipe while
-        // the other does the transform's vector / LDS work (+1 %: both in the same order left the pipe idle while both transformed).
-#ifndef RPN_EXP_WINO_NOTRANSFORM
-        if (wave >= 4 && s + 1 < n_slices) transform(cur ^ 1);
-#endif
-        // ---- 16 GEMMs: this wave's two xi, 64 tiles x 64 channels, k pairs (2 kp, 2 kp + 1).  (Requesting all 32 fragment values
-        // of the slice first and issuing the 32 MFMAs back to back behind a scheduling barrier measured 6 % SLOWER: the compiler's own
-        // order interleaves the transform's vector / LDS instructions with the MFMAs.)
-#ifndef RPN_EXP_WINO_NOMFMA
         {
+            // ---- 16 GEMMs: this wave's two xi, 64 tiles x 64 channels, k pairs (2 kp, 2 kp + 1); the operands of group g + 1 (4
+            // MFMAs: one xi, one k pair) are requested before the MFMAs of group g are issued, into the other register set
             const float *U = Us[cur];
             const float *V = Vs[cur];
+            float av[2][2], bv[2][2];
+            auto ld = [&](int g, int buf) {
+                const int xi = 2 * wave + (g >> 2), k = 2 * (g & 3) + kh;
+                const float *vb = V + xi * (kWinoKS * 64) + l31 + k * 64;
+                const float *ub = U + xi * (kWinoKS * kWinoBN) + l31 + k * kWinoBN;
+                av[buf][0] = vb[0]; av[buf][1] = vb[32];
+                bv[buf][0] = ub[0]; bv[buf][1] = ub[32];
+            };
+            constexpr int kCross = 0x2 | 0x4 | 0x10 | 0x200;        // what may cross: VALU, SALU, VMEM, DS writes
+            ld(0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int xi = 2 * wave + j;
-                const float *vb = V + xi * (kWinoKS * 64) + l31;
-                const float *ub = U + xi * (kWinoKS * kWinoBN) + l31;
-#pragma unroll
-                for (int kp = 0; kp < kWinoKS / 2; ++kp) {
-                    const int k = 2 * kp + kh;
-                    const float a0 = vb[k * 64], a1 = vb[k * 64 + 32];
-                    const float b0 = ub[k * kWinoBN], b1 = ub[k * kWinoBN + 32];
-                    acc[j][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[j][0][0], 0, 0, 0);
-                    acc[j][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[j][0][1], 0, 0, 0);
-                    acc[j][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[j][1][0], 0, 0, 0);
-                    acc[j][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[j][1][1], 0, 0, 0);
-                }
+            for (int g = 0; g < 8; ++g) {
+                if (g + 1 < 8) ld(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(kCross);
+                const int j = g >> 2, bf = g & 1;
+                acc[j][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf][0], bv[bf][0], acc[j][0][0], 0, 0, 0);
+                acc[j][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf][0], bv[bf][1], acc[j][0][1], 0, 0, 0);
+                acc[j][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf][1], bv[bf][0], acc[j][1][0], 0, 0, 0);
+                acc[j][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf][1], bv[bf][1], acc[j][1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(kCross);
             }
         }
-#endif
-#ifndef RPN_EXP_WINO_NOTRANSFORM
-        if (wave < 4 && s + 1 < n_slices) transform(cur ^ 1);
-#endif
-#ifndef RPN_EXP_WINO_NOLOAD
-        if (s + 2 < n_slices) raw_to_lds(rr0, rr1, cur);
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // slice s + 1's filters have landed
         __syncthreads();
     }
 #undef RPN_WINO_DMA_U
+#undef RPN_WINO_LOAD_RAW
 
     // ---- epilogue: four quarters (M block, N block); M staging [xi][32 tiles][32 channels] = 64 KB over Us
     float *Ms = &Us[0][0];
-    const int e_n = tid & 31;               // output role: channel of the quarter, tiles e_t0 and e_t0 + 16 of the quarter
+    const int e_n = tid & 31;               // output role (the 512 threads of the MFMA waves): channel of the quarter, tiles e_t0 and e_t0 + 16
     const int e_t0 = tid >> 5;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
