@@ -53,10 +53,11 @@ def bench_name(k):
     if m: return "conv3x3_split<%s>" % prec(m.group(5))
     m = re.search(r"pw_x3_kernel<(\d+), (\d+), (\d+)>", k)
     if m: return "pw_f16x3<%s,576>" % m.group(1)
-    m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)>", k)
+    m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", k)        # (, POOL since round 5)
     if m: return "conv_igemm_f32_dma<128x%d>" % (32 * int(m.group(2)) * int(m.group(4)))
-    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>", k)
     if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
+    if "conv3x3_wino_f32_kernel" in k: return "conv3x3_wino_f32<16x16x64>"
     return short(k)
 
 
@@ -91,12 +92,13 @@ def traffic(prefix, out, note, workload=None, subdirs=None, rename=False):
 
 copy("bench_default.json", "%s_f16x3_bench_default.json" % tag)
 copy("bench_default_layers.txt", "%s_f16x3_bench_layers.txt" % tag)
-for cfg in ("c1", "c4", "c5", "mn8", "f32"):
+for cfg in ("c1", "c4", "c5", "mn8", "f32", "f32w"):
     copy("bench_%s.json" % cfg, "%s_%s_bench.json" % (tag, cfg))
     copy("bench_%s_layers.txt" % cfg, "%s_%s_bench_layers.txt" % (tag, cfg))
 copy("bbox_c3.json", "%s_c3_bbox_kernels.json" % tag)
 for part in ("A", "B"):
     copy("device_%s.txt" % part, "%s_device_%s.txt" % (tag, part))
+copy("bw_probe.txt", "%s_bw_probe.txt" % tag)
 stats(os.path.join(src, "c3_stats", "c3_kernel_stats.csv"), "%s_c3_kernel_stats.csv" % tag)
 traffic("c3", "%s_c3_traffic.json" % tag,
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) of scripts/bench_bbox.py: B=64, A=8649 (vgg16) and 9216 (mobilenet_v2), G=42")
@@ -104,6 +106,7 @@ traffic("c3", "%s_c3_traffic.json" % tag,
 import subprocess
 for run, name, wl in (("vgg_f16x3", "f16x3", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f16x3"}),
                       ("vgg_f32", "f32", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f32"}),
+                      ("vgg_f32w", "f32w", {"backbone": "vgg16", "img_size": 500, "batch": 8, "precision": "f32w"}),
                       ("mn8", "mn8", {"backbone": "mobilenet_v2", "img_size": 500, "batch": 8, "precision": "f16x3"}),
                       ("c5", "c5", {"backbone": "mobilenet_v2", "img_size": 1024, "batch": 1, "precision": "f16x3"}),
                       ("c1", "c1", {"backbone": "mobilenet_v2", "img_size": 500, "batch": 1, "precision": "f16x3"})):
