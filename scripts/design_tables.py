@@ -28,8 +28,7 @@ def layers(path):
 
 
 line = json.load(open(P("f16x3_bench_default.json")))
-dev = open(P("device_A.txt")).read().split("\n") if os.path.exists(P("device_A.txt")) else [""]
-w("### 5.1 The driver's line (`profiles/%s_f16x3_bench_default.json`; device: %s)\n" % (TAG, " ".join(dev[0].split()[2:]) or "MI355X"))
+w("### 5.1 The driver's line (`profiles/%s_f16x3_bench_default.json`; one MI355X (gfx950) of the pool: devices differ by +-4 %%, `%s_device_A.txt`)\n" % (TAG, TAG))
 r = line["roofline"]
 w("| leg | value | ms per step | dominant kernel | achieved | peak | frac | note |")
 w("|---|---|---|---|---|---|---|---|")
@@ -121,10 +120,28 @@ for wl in ("f16x3", "f32", "f32w", "mn8", "c5", "c1", "c3"):
     path = P("%s_bench_kernel_stats.csv" % wl) if wl != "c3" else P("c3_kernel_stats.csv")
     if not os.path.exists(path):
         continue
-    rows = sorted(csv.DictReader(open(path)), key=lambda r_: -float(r_["TotalDurationNs"]))[:4]
+    rows = sorted((r_ for r_ in csv.DictReader(open(path)) if "stream_spin" not in r_["Kernel"]), key=lambda r_: -float(r_["TotalDurationNs"]))[:4]
     for r_ in rows:
         w("| %s | `%s` | %s | %.1f |" % (wl, r_["Kernel"][:80], r_["Calls"], float(r_["AverageNs"]) / 1e3))
 w("\nCounter passes (six separate `--pmc` passes + FETCH / WRITE per workload): `profiles/%s_{f16x3,f32,f32w,mn8,c5,c1}_pmc.txt` and `_traffic.json`.\n" % TAG)
+
+# ---- counters of the dominant kernels
+w("### 5.5b Counters of the heaviest kernels (`profiles/%s_*_pmc.txt`: separate `--pmc` passes; columns as defined in those files)\n" % TAG)
+w("| workload | kernel | launches | us | matrix pipe busy % | waves parked % | issue-stalled % | waves / SIMD | LDS conflict % | GHz | fetch MB | write MB |")
+w("|---|---|---|---|---|---|---|---|---|---|---|---|")
+for wl in ("f16x3", "f32", "f32w", "mn8", "c5", "c1"):
+    path = P("%s_pmc.txt" % wl)
+    if not os.path.exists(path):
+        continue
+    rows = []
+    for ln in open(path):
+        m = re.match(r"(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        if m and "stream_spin" not in m.group(1):
+            rows.append(m.groups())
+    rows.sort(key=lambda g_: -int(g_[1]) * float(g_[2]))
+    for g_ in rows[:3]:
+        w("| %s | `%s` | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (wl, g_[0].strip()[:70], g_[1], g_[2], g_[3], g_[6], g_[7], g_[8], g_[9], g_[10], g_[11], g_[12]))
+w("")
 
 # ---- code objects
 w("### 5.6 Code objects of the shipped library (`tests/codeobj.py`; budgets held by `tests/test_host.py::test_kernel_register_budgets`)\n")

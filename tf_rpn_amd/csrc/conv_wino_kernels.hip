@@ -9,7 +9,7 @@
 // its own ("f32w"), never a silent replacement of "f32".
 //   y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        (Lavin & Gray; g: 3 x 3 filter, d: 4 x 4 input patch)
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
-// One launch, everything fused: a workgroup (768 threads, one per CU: 150 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16 output
+// One launch, everything fused: a workgroup (768 threads, one per CU: 155 KB of LDS) owns 8 x 8 Winograd tiles = 16 x 16 output
 // pixels x 64 output channels and walks the input channels in slices of 8, ONE workgroup barrier per slice, two wave roles:
 //   STAGING waves 8 .. 11 (one per SIMD), one slice ahead of the MFMAs:
 //   * the slice's 18 x 18 x 8 input patch: buffer loads (out-of-image = out-of-range offset = zeros) -> registers -> LDS `raws`,
@@ -43,7 +43,7 @@ constexpr int kWinoThreads = 768;              // 8 MFMA waves + 4 staging waves
 constexpr int kWinoKS = 8;                  // input channels per slice
 constexpr int kWinoBN = 64;                 // output channels per workgroup
 constexpr int kWinoTT = 8;                  // Winograd tiles per workgroup side (8 x 8 tiles = 16 x 16 output pixels)
-constexpr int kRawPitch = 20, kRawPlane = 18 * kRawPitch;       // raw[channel][18][20] (18 columns used)
+constexpr int kRawPitch = 24, kRawPlane = 18 * kRawPitch;       // raw[channel][18][24] (18 columns used; two patch rows = 48 floats = 16 banks apart: the transform's 8-byte reads of a 16-lane group -- two tile rows -- are conflict-free; at pitch 20: 20 % of LDS cycles were conflicts)
 constexpr int kUFloats = 16 * kWinoKS * kWinoBN;                // 8192 floats = 32 KB per slice and N tile
 constexpr int kVFloats = 16 * kWinoKS * 64;                     // V[xi][k][tile]
 
