@@ -26,7 +26,7 @@ def _conv(x, w, b, act, precision):
 
 WINO_CASES = [
     # B, H, W, Cin, Cout, act
-    (1, 16, 16, 8, 64, "linear"),        # one exact workgroup tile, one slice
+    (1, 16, 16, 8, 64, "linear"),        # one exact workgroup tile, one slice (few workgroups: F(2x2, 3x3))
     (1, 16, 16, 64, 64, "relu"),
     (2, 31, 31, 512, 512, "relu"),       # block5 / rpn_conv: odd size, ragged tiles, 64 slices
     (2, 17, 23, 24, 96, "relu"),         # ragged everywhere, Cout % 64 == 32
@@ -34,6 +34,12 @@ WINO_CASES = [
     (3, 5, 7, 16, 32, "relu6"),          # smaller than a tile
     (1, 33, 1, 8, 32, "linear"),         # one column
     (2, 62, 62, 256, 512, "relu"),       # block4_conv1
+    # grids of >= 256 workgroups of 16 x 32 pixels: the F(4x4, 3x3) kernel (wino_variant's rule)
+    (2, 125, 125, 128, 256, "relu"),     # block3_conv1's shape at batch 2: exactly 256 workgroups
+    (8, 62, 62, 256, 512, "relu"),       # block4_conv1 at batch 8
+    (1, 250, 250, 64, 128, "relu"),      # block2_conv1
+    (5, 130, 70, 32, 96, "linear"),      # ragged in both directions, Cout % 64 == 32, four-channel slices
+    (4, 100, 100, 8, 64, "relu6"),       # two slices
 ]
 
 
@@ -49,12 +55,18 @@ def test_winograd_conv_against_float64(case):
     assert not np.isnan(got).any(), "some outputs were never written"
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(got - ref).max())
-    assert err <= 1e-5 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
+    # F(2x2, 3x3) measures at the direct kernel's level (1-2e-6); F(4x4, 3x3) -- larger transform constants -- a few times that
+    f4 = -(-W // 32) * -(-H // 16) * B * -(-Cout // 64) >= torch.cuda.get_device_properties(0).multi_processor_count and Cin % 4 == 0
+    bound = (3e-5 if f4 else 1e-5) * scale
+    assert err <= bound, "max abs err %.3e (scale %.2f, F(%d))" % (err, scale, 4 if f4 else 2)
     direct = _conv(x, w, b, act, "f32")
-    assert float(np.abs(got - direct).max()) <= 1e-5 * scale
+    assert float(np.abs(got - direct).max()) <= bound
 
 
 def test_winograd_conv_repeats_bit_identically_and_is_batch_invariant():
+    """(rpn_conv2d picks the Winograd form from the call's own grid, so single images of a small map run F(2x2, 3x3) where the batch ran
+    F(4x4, 3x3): the batch-invariance of ONE form is what a model handle guarantees -- checked at the model level -- and here on a map
+    small enough for F(2x2, 3x3) at every batch size.)"""
     rng = np.random.RandomState(3)
     x = rng.uniform(-1, 1, size=(4, 40, 36, 64)).astype(np.float32)
     w = (rng.standard_normal((3, 3, 64, 128)) * 0.06).astype(np.float32)
@@ -91,12 +103,13 @@ def test_vgg16_forward_in_f32w_at_full_size_against_float64():
     assert np.abs(reg[:1] - ref_reg).max() <= 1e-4, np.abs(reg[:1] - ref_reg).max()
     assert np.abs(cls[:1] - ref_cls).max() <= 1e-4, np.abs(cls[:1] - ref_cls).max()
     kinds = {op["name"]: (op["kernel"], op["arith"]) for op in model.ops()}
-    assert kinds["block3_conv2"] == ("conv3x3_wino_f32<16x16x64>", "f32w") and kinds["rpn_conv"][1] == "f32w"
+    assert kinds["block3_conv2"] == ("conv3x3_wino4_f32<16x32x64>", "f32w") and kinds["rpn_conv"] == ("conv3x3_wino_f32<16x16x64>", "f32w")
     assert kinds["block1_conv1"][1] == "f32"
     assert "fused:maxpool_f32" in [k for k, _ in kinds.values()]
     reg1, cls1 = model.predict_on_batch(imgs[1:2])
     assert np.array_equal(reg1, reg[1:2]) and np.array_equal(cls1, cls[1:2])
-    keep = RPNModel("vgg16", hp, precision="f32w", max_batch=1, keep_activations=True)
+    # (the same max_batch: a handle picks each layer's Winograd form from the grid at ITS largest batch)
+    keep = RPNModel("vgg16", hp, precision="f32w", max_batch=2, keep_activations=True)
     keep.set_weights(weights)
     regk, clsk = keep.predict_on_batch(imgs[:1])
     assert np.array_equal(regk, reg[:1]) and np.array_equal(clsk, cls[:1])

@@ -60,7 +60,8 @@ struct Op {
     bool k16 = false;                  // split conv on the 16x16x32-MFMA kernel ("split32" weight packing)
     bool out_f32 = false;              // split conv writing float32 NHWC (feeds the float32 head)
     bool f32_out_split = false;        // float32 implicit-GEMM conv writing SPLIT16 directly (its consumer is a split conv)
-    bool wino = false;                 // precision F32W: 3x3 stride-1 'same' conv as float32 Winograd F(2x2, 3x3) (conv_wino_kernels.hip)
+    bool wino = false;                 // precision F32W: 3x3 stride-1 'same' conv as float32 Winograd (conv_wino_kernels.hip)
+    int wino_f = 2;                    // ... F(2x2, 3x3) or F(4x4, 3x3): wino_variant at the handle's max_batch
     float out_scale = 1.0f;            // 2^-shift of the pre-scaled split weights
     // OP_IRBLOCK (one fused MobileNetV2 block; Cin / Cout = block input / output channels, stride = the depthwise's):
     int cexp = 0;                      // expanded channels
@@ -219,6 +220,7 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     op.out_f32 = split && force_f32_out;
     op.wino = m->wino && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == ti.H && OW == ti.W && residual < 0 &&
               act != ACT_SIGMOID && !op.cin3 && !ti.external && wino_supported(ti.C, Cout);
+    if (op.wino) op.wino_f = wino_variant(m->max_batch, ti.H, ti.W, ti.C, Cout);
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
@@ -522,7 +524,7 @@ static void plan_weights(rpn_model *m)
             off += (size_t)split_cout_pad(op.Cout);
         } else if (op.kind == OP_CONV && op.wino) {
             op.w_off = off;
-            off += (wino_weight_floats(op.Cin, op.Cout) + 63) & ~(size_t)63;
+            off += (wino_weight_floats(op.Cin, op.Cout, op.wino_f) + 63) & ~(size_t)63;
             op.b_off = off;
             off += (size_t)op.ps.cout_pad;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
@@ -854,8 +856,8 @@ extern "C" int rpn_model_set_layer(rpn_model *m, const char *name, const float *
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float),
                                 hipMemcpyHostToDevice));
     } else if (op.wino) {
-        std::vector<float> packed(wino_weight_floats(p.Cin, p.Cout));
-        pack_weights_wino_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, packed.data());
+        std::vector<float> packed(wino_weight_floats(p.Cin, p.Cout, op.wino_f));
+        pack_weights_wino_host(kernel, has_bn ? scale.data() : nullptr, p.Cin, p.Cout, packed.data(), op.wino_f);
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         RPN_HIP_CHECK(hipMemcpy(m->d_weights + op.b_off, shift.data(), (size_t)p.Cout * sizeof(float), hipMemcpyHostToDevice));
     } else if (is_pw_x3(m, op)) {
@@ -997,7 +999,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             const bool pool = f32_pool_fused(m, oi);                    // + block*_pool: a Winograd tile's 2 x 2 outputs are one window
             e = launch_conv3x3_wino(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
                                     tensor_ptr(m, pool ? m->ops[oi + 1].out : op.out, d_imgs), B, op.H, op.W, op.Cin, op.Cout, op.act,
-                                    pool, s);
+                                    pool, s, op.wino_f);
             skip_next = pool;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
@@ -1159,7 +1161,7 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         else if (is_pw_x3(m, op))
             snprintf(kname32, sizeof kname32, "pw_f16x3<%d,%d>", op.Cin, op.Cout);
         else if (op.kind == OP_CONV && op.wino)
-            snprintf(kname32, sizeof kname32, "conv3x3_wino_f32<16x16x64>");      // (fl above: the direct conv's flops; 2.25 x fewer are executed)
+            snprintf(kname32, sizeof kname32, op.wino_f == 4 ? "conv3x3_wino4_f32<16x32x64>" : "conv3x3_wino_f32<16x16x64>");   // (fl above: the direct conv's flops; 4 x / 2.25 x fewer are executed)
         else
         {
             const int bn32 = conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout);
@@ -1289,13 +1291,14 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
               act != ACT_SIGMOID))
             return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the Winograd path needs 3x3 s1 'same', Cin %% 8 == 0, Cout %% 32 == 0");
         const size_t wcount = (size_t)9 * Cin * Cout;
-        std::vector<float> hw(wcount), packed(wino_weight_floats(Cin, Cout));
+        const int wf = wino_variant(B, H, W, Cin, Cout);
+        std::vector<float> hw(wcount), packed(wino_weight_floats(Cin, Cout, wf));
         RPN_HIP_CHECK(hipMemcpy(hw.data(), d_w, wcount * sizeof(float), hipMemcpyDeviceToHost));
-        pack_weights_wino_host(hw.data(), nullptr, Cin, Cout, packed.data());
+        pack_weights_wino_host(hw.data(), nullptr, Cin, Cout, packed.data(), wf);
         float *d_u = nullptr;
         RPN_HIP_CHECK(hipMalloc(&d_u, packed.size() * sizeof(float)));
         hipError_t e = hipMemcpy(d_u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = launch_conv3x3_wino(d_x, d_u, d_bias, d_out, B, H, W, Cin, Cout, act, false, s);
+        if (e == hipSuccess) e = launch_conv3x3_wino(d_x, d_u, d_bias, d_out, B, H, W, Cin, Cout, act, false, s, wf);
         const hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(d_u);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(f32w): launch failed: %s", hipGetErrorString(e));
