@@ -525,6 +525,14 @@ def c3_traffic():
     return {}, None
 
 
+def winograd_reduction(op):
+    """Direct-conv flops / flops the kernel executes: 1 for direct kernels; 2.25 for Winograd F(2x2,3x3) (16 instead of 36
+    multiplications per 2 x 2 outputs and channel pair), 4 for F(4x4,3x3) (36 instead of 144 per 4 x 4 outputs)."""
+    if op["arith"] != "f32w":
+        return 1.0
+    return 4.0 if op["kernel"].startswith("conv3x3_wino4") else 2.25
+
+
 def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmup=2, heads=None, precision="f32", keep_heads=None):
     """The parity-clean arithmetic beside the headline (report both): the same workload with every conv
     on the exact float32 MFMA (v_mfma_f32_32x32x2_f32: float32 products, float32 accumulation in a fixed order per
@@ -534,8 +542,8 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     a per-op event pass.  `heads` = the headline path's (reg, cls) head outputs for the same images: their largest
     absolute difference from this path's is returned as `max_abs_diff_vs_headline` (the bench line's self-check).
     precision="f32w" (the `f32_winograd` leg): the 3x3 convs as float32 Winograd F(2x2, 3x3) on the same float32 MFMA (float32
-    operands and accumulation, 2.25 x fewer multiply-adds, another summation order: a precision of its own, never the
-    parity-clean `exact_f32` row).  Its `roofline.achieved` prices the multiply-adds the kernel EXECUTES (the direct conv's / 2.25)
+    operands and accumulation, 2.25 x -- F(4x4,3x3): 4 x -- fewer multiply-adds, another summation order: a precision of its own, never
+    the parity-clean `exact_f32` row).  Its `roofline.achieved` prices the multiply-adds the kernel EXECUTES (`winograd_reduction`)
     against the 157.3 TFLOP/s peak; `effective_tflops` is the direct conv's flops over the same time.  `keep_heads`: a list that
     receives this path's (reg, cls) head outputs; `heads` may then be the exact-f32 leg's."""
     import torch
@@ -566,7 +574,7 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     for op, t in zip(ops, ms):
         d = tot.setdefault(op["kernel"], [0.0, 0.0, 0, 0.0])
         d[0] += t
-        d[1] += op["flops_per_image"] * B / (2.25 if op["arith"] == "f32w" else 1.0)      # multiply-adds executed
+        d[1] += op["flops_per_image"] * B / winograd_reduction(op)                         # multiply-adds executed
         d[2] += op["launches"]
         d[3] += op["flops_per_image"] * B                                                  # the direct conv's
     dom = max(tot, key=lambda k: tot[k][0])
@@ -590,8 +598,9 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     if precision == "f32w":
         out["max_abs_diff_vs_exact_f32"] = out.pop("max_abs_diff_vs_headline")
         out["roofline"]["effective_tflops"] = round(tot[dom][3] / (tot[dom][0] * 1e-3) / 1e12, 3)
-        out["note"] = ("3x3 convs as float32 Winograd F(2x2,3x3) on the f32 MFMA: float32 operands and accumulation, 1 / 2.25 of the "
-                       "multiply-adds, another summation order -- not the parity-clean `exact_f32` row")
+        out["note"] = ("3x3 convs as float32 Winograd on the f32 MFMA -- F(4x4,3x3) where its 16x32 tiles fill the chip (1/4 of the direct "
+                       "conv's multiply-adds), F(2x2,3x3) on the 31x31 layers (1/2.25): float32 operands and accumulation, another "
+                       "summation order -- not the parity-clean `exact_f32` row")
     return out
 
 
@@ -1002,7 +1011,7 @@ def main():
         for op, ms in zip(ops, last_ms):
             d = by_kernel.setdefault(op["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
             d["ms"] += ms
-            d["flops"] += op["flops_per_image"] * B / (2.25 if op["arith"] == "f32w" else 1.0)   # (Winograd: the multiply-adds executed)
+            d["flops"] += op["flops_per_image"] * B / winograd_reduction(op)   # (Winograd: the multiply-adds executed)
             d["launches"] += op["launches"]
         d = by_kernel[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -1029,7 +1038,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "dtype_note": {"f32": "float32 in, float32 MFMA accumulate (exact)",
-                           "f32w": "float32 in, float32 MFMA accumulate; the 3x3 convs as Winograd F(2x2,3x3): 1 / 2.25 of the multiply-adds, another summation order",
+                           "f32w": "float32 in, float32 MFMA accumulate; the 3x3 convs as Winograd F(4x4,3x3) / F(2x2,3x3): 1/4 / 1/2.25 of the multiply-adds, another summation order",
                            "f16x3": "float32 operands as hi+lo float16 halves, 3 MFMAs per product, float32 accumulate",
                            "bf16x3": "float32 operands as hi+lo bfloat16 halves, 3 MFMAs per product, float32 accumulate"
                            }[args.precision],

@@ -73,7 +73,7 @@ for n, k, ms, tf, _ in L16:
     b = d32w.get(n)
     a_s = "%.3f | %.3f" % (a[1], a[2] / 157.3) if a else " | "
     if b:
-        executed = b[2] / (2.25 if "wino" in b[0] else 1.0)
+        executed = b[2] / (4.0 if "wino4" in b[0] else (2.25 if "wino" in b[0] else 1.0))
         b_s = "%.3f | %.3f" % (b[1], executed / 157.3)
     else:
         b_s = " | "
