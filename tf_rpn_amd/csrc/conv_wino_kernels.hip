@@ -172,7 +172,7 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     do {                                                                                                                    \
         rr[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (CB), 0);                                              \
         rr[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (CB), 0);                                              \
-        if (third) rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);                                   \
+        rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);   /* (no piece: kOob, zeros, no traffic) */   \
     } while (0)
     u32x4_w rr[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     auto raw_to_lds = [&](int buf) {                                 // this thread's pieces -> channel-major planes
@@ -189,13 +189,18 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int t_c = t_c0 + 4 * r;
-            const float *rp = raws[buf] + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
+            // ONE opaque index per patch, constants behind it: hipcc's waitcnt pass lets an LDS read overtake the filter DMAs in
+            // flight only when the read carries the alias scope of its __shared__ array, and the pass that attaches the scopes
+            // follows at most five address computations from the array -- with the index split into hoisted pieces the reads lost
+            // theirs, and the transform waited for the whole memory latency of the slice's loads (s_waitcnt vmcnt(0) in front of it)
+            int ro = buf * (kWinoKS * kRawPlane) + t_c * kRawPlane + (2 * t_ty) * kRawPitch + 2 * t_tx;
+            asm volatile("" : "+v"(ro));
+            const float *rp = &raws[0][0] + ro;
             float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float2 p0 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch);
-                const float2 p1 = *reinterpret_cast<const float2 *>(rp + i * kRawPitch + 2);
-                d[i][0] = p0.x; d[i][1] = p0.y; d[i][2] = p1.x; d[i][3] = p1.y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = rp[i * kRawPitch + j];
             }
             float t[4][4];
 #pragma unroll
@@ -241,12 +246,17 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             __syncthreads();
             continue;
 #endif
-            if (s + 2 < n_slices) RPN_WINO_LOAD_RAW((s + 2) * kWinoKS * 4);
-            if (s + 1 < n_slices) {
+            // (the full iterations and the last two are separate straight-line bodies: with the requests under conditions hipcc's
+            // counted waits assume the DMAs may not have been issued and make raw_to_lds wait for all of them)
+            if (s + 2 < n_slices) {
+                RPN_WINO_LOAD_RAW((s + 2) * kWinoKS * 4);
+                RPN_WINO_DMA_U(s + 1, cur ^ 1);
+                transform(cur ^ 1);
+                raw_to_lds(cur);
+            } else if (s + 1 < n_slices) {
                 RPN_WINO_DMA_U(s + 1, cur ^ 1);
                 transform(cur ^ 1);
             }
-            if (s + 2 < n_slices) raw_to_lds(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slice s + 1's filters have landed
             __syncthreads();
         }
@@ -454,9 +464,9 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4])
     y[3] = __builtin_fmaf(8.0f, s, q) + m[5];
 }
 
-// Output transform of one (tile, channel) pair of an epilogue phase: thread -> (channel = tid & 31, tile = tid >> 5); Ms = the parked
-// accumulators [xi][tile][32]; Y = A^T M A, + bias, activation, 128-byte NHWC stores (or the 2 x 2 max of the pooled form).
-__device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *Ms, int tid, int ph, int img, int oy0, int ox0, int n0)
+// Output transform of one (tile, channel) pair of an epilogue phase: thread -> (channel = tid & 31, tile = tid >> 5); MsA / MsB = the parked
+// accumulators [xi][tile][32] of xi 0 .. 17 / 18 .. 35; Y = A^T M A, + bias, activation, 128-byte NHWC stores (or the 2 x 2 max of the pooled form).
+__device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0)
 {
     const int e_n = tid & 31, e_tile = tid >> 5;
     const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
@@ -473,7 +483,7 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
         for (int j = 0; j < 6; ++j) {
             float m[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = Ms[((6 * i + j) * 32 + e_tile) * 32 + e_n];
+            for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * 32 + e_tile) * 32 + e_n];     // xi = 6 i + j
             const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
             if (hp == 0) {
                 R0[j] = m[0] + pp + rr;
@@ -512,12 +522,17 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    // one block: U x 2 (72 KB) | V x 2 (36 KB) | raw x 2 (20.25 KB); the epilogue parks 36 x 32 x 32 accumulators (144 KB) over all of it
-    constexpr int kW4LdsFloats = kW4Xi * 32 * 32 > 2 * (kW4UFloats + kW4VFloats + kW4KS * kW4Plane) ? kW4Xi * 32 * 32 : 2 * (kW4UFloats + kW4VFloats + kW4KS * kW4Plane);
-    __shared__ __attribute__((aligned(16))) float lds_all[kW4LdsFloats];
-    float (*Us)[kW4UFloats] = reinterpret_cast<float (*)[kW4UFloats]>(lds_all);
-    float (*Vs)[kW4VFloats] = reinterpret_cast<float (*)[kW4VFloats]>(lds_all + 2 * kW4UFloats);
-    float (*raws)[kW4KS * kW4Plane] = reinterpret_cast<float (*)[kW4KS * kW4Plane]>(lds_all + 2 * kW4UFloats + 2 * kW4VFloats);
+    // two arrays of 72 KB: ldsU = U x 2 | ldsVR = V x 2 (36 KB), raw x 2 (20.25 KB), padding.  TWO, because hipcc's waitcnt pass lets an
+    // LDS access overtake an LDS-DMA in flight only when the two carry the alias scopes of DIFFERENT __shared__ arrays: with one block
+    // the staging waves' transform waited for the slice's filter DMA (and, results returning in order, for every load before it).
+    // The epilogue parks the 36 x 32 x 32 accumulators (144 KB) over both: xi 0 .. 17 in ldsU, xi 18 .. 35 in ldsVR.
+    constexpr int kW4Half = 18 * 32 * 32;                                  // floats per array
+    static_assert(2 * kW4UFloats == kW4Half && 2 * (kW4VFloats + kW4KS * kW4Plane) <= kW4Half, "LDS layout");
+    __shared__ __attribute__((aligned(16))) float ldsU[kW4Half];
+    __shared__ __attribute__((aligned(16))) float ldsVR[kW4Half];
+    float (*Us)[kW4UFloats] = reinterpret_cast<float (*)[kW4UFloats]>(ldsU);
+    float (*Vs)[kW4VFloats] = reinterpret_cast<float (*)[kW4VFloats]>(ldsVR);
+    float (*raws)[kW4KS * kW4Plane] = reinterpret_cast<float (*)[kW4KS * kW4Plane]>(ldsVR + 2 * kW4VFloats);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,7 +587,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     do {                                                                                                                    \
         rr[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (CB), 0);                                              \
         rr[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (CB), 0);                                              \
-        if (third) rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);                                   \
+        rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);   /* (no piece: kOob, zeros, no traffic) */   \
     } while (0)
         auto raw_to_lds = [&](int buf) {
             float *raw = raws[buf];
@@ -586,16 +601,18 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         };
         auto transform = [&](int buf) {
             // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
-            const float *rp = raws[buf] + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx;
+            // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
+            int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx;
+            asm volatile("" : "+v"(ro));
+            const float *rp = ldsVR + ro;
             float T[3][6];
 #pragma unroll
             for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
                 float d0[6], d1[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
-                    const float2 p = *reinterpret_cast<const float2 *>(rp + r * kW4Pitch + 2 * jp);
-                    d0[r] = p.x;
-                    d1[r] = p.y;
+                    d0[r] = rp[r * kW4Pitch + 2 * jp];
+                    d1[r] = rp[r * kW4Pitch + 2 * jp + 1];
                 }
                 float t0[3], t1[3];
                 if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
@@ -603,13 +620,15 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
             }
-            float *vp = Vs[buf] + t_c * 32 + t_tile;
+            int vo = buf * kW4VFloats + (18 * t_part) * (kW4KS * 32) + t_c * 32 + t_tile;      // (opaque for the same reason: the writes
+            asm volatile("" : "+v"(vo));                                                         // need not wait for the DMA either)
+            float *vp = ldsVR + vo;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 float v[6];
                 w4_bt6(T[i], v);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) vp[(6 * (3 * t_part + i) + j) * (kW4KS * 32)] = v[j];
+                for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * 32)] = v[j];
             }
         };
         // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
@@ -627,22 +646,28 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             const int cur = s & 1;
             /* timing experiments (wrong results): -DRPN_EXP_W4_NOSTAGE / _NODMA / _NOXF / _NORAW */
 #ifndef RPN_EXP_W4_NOSTAGE
+            // (full iterations and the last two as separate straight-line bodies: see conv3x3_wino_f32_kernel)
+            if (s + 2 < n_slices) {
 #ifndef RPN_EXP_W4_NORAW
-            if (s + 2 < n_slices) RPN_W4_LOAD_RAW((s + 2) * kW4KS * 4);
+                RPN_W4_LOAD_RAW((s + 2) * kW4KS * 4);
 #endif
-            if (s + 1 < n_slices) {
 #ifndef RPN_EXP_W4_NODMA
                 RPN_W4_DMA_U(s + 1, cur ^ 1);
 #endif
-            }
-            if (s + 1 < n_slices) {
+#ifndef RPN_EXP_W4_NOXF
+                transform(cur ^ 1);
+#endif
+#ifndef RPN_EXP_W4_NORAW
+                raw_to_lds(cur);
+#endif
+            } else if (s + 1 < n_slices) {
+#ifndef RPN_EXP_W4_NODMA
+                RPN_W4_DMA_U(s + 1, cur ^ 1);
+#endif
 #ifndef RPN_EXP_W4_NOXF
                 transform(cur ^ 1);
 #endif
             }
-#ifndef RPN_EXP_W4_NORAW
-            if (s + 2 < n_slices) raw_to_lds(cur);
-#endif
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slice s + 1's filters have landed
 #ifdef RPN_EXP_W4_HALFBAR
@@ -654,7 +679,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
             __syncthreads();                                         // the phase's accumulators are in LDS
-            w4_output_pair(a, lds_all, tid, ph, img, oy0, ox0, n0);
+            w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0);
             __syncthreads();                                         // the staging area may be overwritten
         }
         return;
@@ -705,6 +730,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     // loop's buffers are dead), then every thread transforms one (tile, channel) pair; the accumulators of the other N block stay in
     // registers meanwhile (48 + the transform's ~60: inside the 128 a sixteen-wave workgroup may have).  (First version: four rounds
     // of 16 channels transformed by the 256 staging threads alone: 32 k cycles per workgroup, 10 % of a 256-channel layer.)
+    float *park = wave < 6 ? ldsU : ldsVR - kW4Half;                       // xi = 3 wave + j: waves 0 .. 5 own xi 0 .. 17
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
 #pragma unroll
@@ -713,11 +739,11 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;            // tile
-                lds_all[(xi * 32 + row) * 32 + l31] = acc[j][ph][e];
+                park[(xi * 32 + row) * 32 + l31] = acc[j][ph][e];
             }
         }
         __syncthreads();
-        w4_output_pair(a, lds_all, tid, ph, img, oy0, ox0, n0);
+        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0);
         __syncthreads();
     }
 }
