@@ -40,7 +40,23 @@ WINO_CASES = [
     (1, 250, 250, 64, 128, "relu"),      # block2_conv1
     (5, 130, 70, 32, 96, "linear"),      # ragged in both directions, Cout % 64 == 32, four-channel slices
     (4, 100, 100, 8, 64, "relu6"),       # two slices
+    # grids that fill only half of the chip with 16 x 32-pixel tiles: F(4x4, 3x3) with the input channels split over two workgroups
+    # per tile, the last arriver adding the halves (variant 8)
+    (8, 31, 31, 512, 512, "relu"),       # block5 / rpn_conv at batch 8: 128 tiles
+    (8, 32, 32, 576, 512, "relu"),       # MobileNetV2's rpn_conv at batch 8
+    (4, 50, 90, 64, 160, "linear"),      # ragged, a 32-channel last N tile, eight slices per half
 ]
+
+
+def _variant(B, H, W, Cin, Cout):
+    """wino_variant (conv_wino_kernels.hip) restated: 4, 8 (split input channels) or 2."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    wgs4 = -(-W // 32) * -(-H // 16) * B * -(-Cout // 64)
+    if Cin % 4:
+        return 2
+    if wgs4 >= cus:
+        return 4
+    return 8 if 2 * wgs4 >= cus and Cin >= 64 else 2
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c))
@@ -56,11 +72,14 @@ def test_winograd_conv_against_float64(case):
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(got - ref).max())
     # F(2x2, 3x3) measures at the direct kernel's level (1-2e-6); F(4x4, 3x3) -- larger transform constants -- a few times that
-    f4 = -(-W // 32) * -(-H // 16) * B * -(-Cout // 64) >= torch.cuda.get_device_properties(0).multi_processor_count and Cin % 4 == 0
-    bound = (3e-5 if f4 else 1e-5) * scale
-    assert err <= bound, "max abs err %.3e (scale %.2f, F(%d))" % (err, scale, 4 if f4 else 2)
+    form = _variant(B, H, W, Cin, Cout)
+    bound = (3e-5 if form != 2 else 1e-5) * scale
+    assert err <= bound, "max abs err %.3e (scale %.2f, form %d)" % (err, scale, form)
     direct = _conv(x, w, b, act, "f32")
     assert float(np.abs(got - direct).max()) <= bound
+    if form == 8:       # whichever half arrives last adds half 0 + half 1: the same bits every time
+        for _ in range(3):
+            assert np.array_equal(got, _conv(x, w, b, act, "f32w"))
 
 
 def test_winograd_conv_repeats_bit_identically_and_is_batch_invariant():
@@ -113,6 +132,36 @@ def test_vgg16_forward_in_f32w_at_full_size_against_float64():
     keep.set_weights(weights)
     regk, clsk = keep.predict_on_batch(imgs[:1])
     assert np.array_equal(regk, reg[:1]) and np.array_equal(clsk, cls[:1])
+
+
+def test_vgg16_f32w_split_channel_layers_at_batch_8():
+    """A handle with max_batch 8 runs the 31 x 31 layers (block5_conv1-3, rpn_conv; models/rpn_vgg16.py:16-18) on F(4x4, 3x3) with the
+    input channels split over two workgroups per tile.  The tickets return to zero after every launch (the same bits call after call),
+    smaller batches run the same form (an image alone == inside the batch), and the heads agree with the exact float32 graph."""
+    from oracle import bbox_oracle as bo
+    from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+    hp = bo.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    weights = synthetic_weights("vgg16", hp, seed=4)
+    imgs = np.random.RandomState(5).uniform(0, 1, size=(8, 500, 500, 3)).astype(np.float32)
+    model = RPNModel("vgg16", hp, precision="f32w", max_batch=8)
+    model.set_weights(weights)
+    kinds = {op["name"]: op["kernel"] for op in model.ops()}
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        for name in ("block5_conv1", "block5_conv2", "block5_conv3", "rpn_conv"):
+            assert kinds[name] == "conv3x3_wino4_f32<16x32x64,k2>", kinds
+    reg, cls = model.predict_on_batch(imgs)
+    for _ in range(3):
+        reg2, cls2 = model.predict_on_batch(imgs)
+        assert np.array_equal(reg, reg2) and np.array_equal(cls, cls2)
+    for lo, hi in ((0, 1), (5, 6), (2, 5)):
+        r, c = model.predict_on_batch(imgs[lo:hi])
+        assert np.array_equal(r, reg[lo:hi]) and np.array_equal(c, cls[lo:hi])
+    reg2, cls2 = model.predict_on_batch(imgs)          # ... and the full batch again after the smaller ones
+    assert np.array_equal(reg, reg2) and np.array_equal(cls, cls2)
+    exact = RPNModel("vgg16", hp, precision="f32", max_batch=8)
+    exact.set_weights(weights)
+    rege, clse = exact.predict_on_batch(imgs)
+    assert np.abs(reg - rege).max() <= 2e-5 and np.abs(cls - clse).max() <= 2e-5, (np.abs(reg - rege).max(), np.abs(cls - clse).max())
 
 
 def test_mobilenet_v2_rpn_conv_in_f32w():

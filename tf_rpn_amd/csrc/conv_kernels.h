@@ -66,14 +66,18 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
                            const float *conv_bias = nullptr);
 
 // ---- 3x3 stride-1 'same' conv as Winograd F(2x2, 3x3) on the float32 MFMA (conv_wino_kernels.hip; precision "f32w") ----
-// variant: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3) (wino_variant picks per layer from the grid at the handle's largest batch).
+// variant: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3), 8 = F(4x4, 3x3) with the input channels split over two workgroups per tile
+// (wino_variant picks per layer from the grid at the handle's largest batch).
 // u = pack_weights_wino_host(HWIO weights, variant): wino_weight_floats floats; out: (B,H,W,Cout) or, pool, (B,H/2,W/2,Cout).
+// workspace (variant 8 only): wino_workspace_bytes bytes of device memory, zeroed ONCE by the owner (partial tiles + tickets; the
+// kernel leaves the tickets at zero), private to one stream at a time.
 bool wino_supported(int Cin, int Cout);                  // Cin % 8 == 0, Cout % 32 == 0
 int wino_variant(int B, int H, int W, int Cin, int Cout);
 size_t wino_weight_floats(int Cin, int Cout, int variant);
+size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant);
 void pack_weights_wino_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst, int variant);
 hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias, float *out, int B, int H, int W, int Cin,
-                               int Cout, int act, bool pool, hipStream_t s, int variant);
+                               int Cout, int act, bool pool, hipStream_t s, int variant, void *workspace = nullptr);
 
 // MaxPooling2D(2,2) 'valid' (floors odd sizes), NHWC, C % 4 == 0
 hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);

@@ -50,7 +50,7 @@ constexpr int kVFloats = 16 * kWinoKS * 64;                     // V[xi][k][tile
 size_t wino4_weight_floats(int Cin, int Cout);
 size_t wino_weight_floats(int Cin, int Cout, int variant)
 {
-    return variant == 4 ? wino4_weight_floats(Cin, Cout) : (size_t)((Cout + kWinoBN - 1) / kWinoBN) * (Cin / kWinoKS) * kUFloats;
+    return variant == 4 || variant == 8 ? wino4_weight_floats(Cin, Cout) : (size_t)((Cout + kWinoBN - 1) / kWinoBN) * (Cin / kWinoKS) * kUFloats;
 }
 bool wino_supported(int Cin, int Cout) { return Cin >= kWinoKS && Cin % kWinoKS == 0 && Cout >= 32 && Cout % 32 == 0; }
 
@@ -59,7 +59,7 @@ bool wino_supported(int Cin, int Cout) { return Cin >= kWinoKS && Cin % kWinoKS 
 void pack_weights_wino4_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst);
 void pack_weights_wino_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst, int variant)
 {
-    if (variant == 4) {
+    if (variant == 4 || variant == 8) {
         pack_weights_wino4_host(hwio, scale, Cin, Cout, dst);
         return;
     }
@@ -92,6 +92,12 @@ struct WinoArgs {
     float *out;              // (B,H,W,Cout), or pooled (B,H/2,W/2,Cout)
     int B, H, W, Cin, Cout;
     int act, pool;
+    // F(4x4, 3x3) with the input channels split over TWO workgroups per tile (variant 8: layers whose 16 x 32-pixel tiles fill only
+    // half of the chip): each writes its raw partial outputs [512 pixels][64 channels] to part[(2 * tile + half)], the LAST arriver of
+    // a tile (ticket) adds the two in fixed order (half 0 + half 1), + bias, activation, and writes the layer's output.
+    int ksplit;              // 1 | 2
+    float *part;             // ksplit 2: 2 x tiles x 32768 floats
+    unsigned *tickets;       // ksplit 2: one per tile, zero between launches (the last arriver resets its ticket)
 };
 
 __device__ __forceinline__ float wino_act(float v, int act)
@@ -394,6 +400,7 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 constexpr int kW4Threads = 1024;            // 12 MFMA waves + 4 staging waves
 constexpr int kW4KS = 4;                    // input channels per slice
 constexpr int kW4Xi = 36;
+constexpr int kW4Tickets = 16384;            // K split (variant 8): tickets at the front of the workspace
 constexpr int kW4TY = 4, kW4TX = 8;         // Winograd tiles per workgroup: 4 x 8 (16 x 32 output pixels)
 constexpr int kW4PatchH = 4 * kW4TY + 2, kW4PatchW = 4 * kW4TX + 2;      // 18 x 34
 constexpr int kW4Pitch = 36, kW4Plane = kW4PatchH * kW4Pitch;            // raw[channel][18][36]
@@ -466,7 +473,8 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4])
 
 // Output transform of one (tile, channel) pair of an epilogue phase: thread -> (channel = tid & 31, tile = tid >> 5); MsA / MsB = the parked
 // accumulators [xi][tile][32] of xi 0 .. 17 / 18 .. 35; Y = A^T M A, + bias, activation, 128-byte NHWC stores (or the 2 x 2 max of the pooled form).
-__device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0)
+__device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0,
+                                               bool split, __amdgpu_buffer_rsrc_t part_rs)
 {
     const int e_n = tid & 31, e_tile = tid >> 5;
     const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
@@ -474,6 +482,7 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
     const float bias = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
     if (n >= a.Cout) return;
+    constexpr int kSc1 = 16;                                             // cache-policy bit 4 = sc1 (device scope, write-through)
     // two output rows at a time (the 4 x 6 intermediate of all four would not fit beside the other N block's 48 live accumulator
     // registers): R[p][j] = sum_i At[p][i] M[i][j] for p = 2 hp, 2 hp + 1, then the column transform of those two rows
 #pragma unroll 1
@@ -497,7 +506,14 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
         float y0[4], y1[4];
         w4_at(R0, y0);
         w4_at(R1, y1);
-        if (a.pool) {
+        if (split) {                                                     // K split: the raw partial tile [16 x 32 pixels][64 channels]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pix = (4 * e_ty + p) * 32 + 4 * e_tx + q;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0[q]), part_rs, (pix * kWinoBN + ph * 32 + e_n) * 4, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1[q]), part_rs, ((pix + 32) * kWinoBN + ph * 32 + e_n) * 4, 0, kSc1);
+            }
+        } else if (a.pool) {
             const int PH = a.H >> 1, PW = a.W >> 1, py = (oy + p) >> 1;
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
@@ -515,6 +531,70 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
                 if (oy + p + 1 < a.H && ox + q < a.W)
                     a.out[(((size_t)img * a.H + oy + p + 1) * a.W + ox + q) * a.Cout + n] = wino_act(y1[q] + bias, a.act);
             }
+        }
+    }
+}
+
+// K split, after the workgroup's partial tile is written: take the tile's ticket; the LAST of the two arrivers adds the halves in
+// fixed order, + bias, activation, and writes the output tile.  Visibility as in ir_block_x3_kernel (mnv2_block_kernels.hip): every
+// handed-off word is written with a device-scope (sc1) store and read with a device-scope load, a storing wave drains its stores in
+// front of the barrier that precedes the ticket -- no cache-wide fence.  Nobody waits for anybody.  Called by all 1024 threads.
+__device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, int tid, int tile_id, int img, int oy0, int ox0, int n0)
+{
+    constexpr int kSc1 = 16;
+    unsigned *flag = reinterpret_cast<unsigned *>(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(a.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == 1u) __hip_atomic_store(a.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        *flag = ticket;
+    }
+    __syncthreads();
+    if (*flag != 1u) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)tile_id * 2 * (512 * kWinoBN), (short)0,
+                                                                        2 * 512 * kWinoBN * 4, 0x00020000);
+    if (a.pool) {                                        // + block*_pool: 8 x 16 pooled pixels x 16 pieces, two per thread
+        const int PH = a.H >> 1, PW = a.W >> 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = k * kW4Threads + tid;
+            const int ppix = e >> 4, c4 = (e & 15) * 4;
+            const int py = (oy0 >> 1) + (ppix >> 4), px = (ox0 >> 1) + (ppix & 15), n = n0 + c4;
+            f32x4_w m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int pix = (2 * (ppix >> 4) + (w >> 1)) * 32 + 2 * (ppix & 15) + (w & 1);
+                const f32x4_w p0 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, (pix * kWinoBN + c4) * 4, 0, kSc1));
+                const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, 512 * kWinoBN * 4 + (pix * kWinoBN + c4) * 4, 0, kSc1));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = w == 0 ? p0[i] + p1[i] : fmaxf(m[i], p0[i] + p1[i]);
+            }
+            if (py < PH && px < PW && n < a.Cout) {
+                f32x4_w b = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) b = *reinterpret_cast<const f32x4_w *>(a.bias + n);
+                f32x4_w v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = wino_act(m[i] + b[i], a.act);
+                *reinterpret_cast<f32x4_w *>(a.out + (((size_t)img * PH + py) * PW + px) * a.Cout + n) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                        // 8192 pieces of four channels, eight per thread
+        const int e = k * kW4Threads + tid;
+        const int pix = e >> 4, c4 = (e & 15) * 4;
+        const f32x4_w p0 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16, 0, kSc1));
+        const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, 512 * kWinoBN * 4 + e * 16, 0, kSc1));
+        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31), n = n0 + c4;
+        if (oy < a.H && ox < a.W && n < a.Cout) {
+            f32x4_w b = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) b = *reinterpret_cast<const f32x4_w *>(a.bias + n);
+            f32x4_w v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = wino_act((p0[i] + p1[i]) + b[i], a.act);
+            *reinterpret_cast<f32x4_w *>(a.out + (((size_t)img * a.H + oy) * a.W + ox) * a.Cout + n) = v;
         }
     }
 }
@@ -537,7 +617,10 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
+    int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int khalf = a.ksplit == 2 ? (wg & 1) : 0;      // K split: the two halves of a tile are neighbours (same XCD, same time)
+    if (a.ksplit == 2) wg >>= 1;
+    const int tile_id = wg;
     const int nt = wg % n_tiles;
     int mt = wg / n_tiles;
     const int tx = mt % tiles_x;
@@ -546,13 +629,18 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int img = mt / tiles_y;
     const int oy0 = ty * 4 * kW4TY, ox0 = tx * 4 * kW4TX, n0 = nt * kWinoBN;
 
-    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
-    const int n_slices = a.Cin / kW4KS;
+    const int all_slices = a.Cin / kW4KS;
+    const int s_begin = khalf ? all_slices / 2 : 0;      // this workgroup's slices [s_begin, s_begin + n_slices)
+    const int n_slices = a.ksplit == 2 ? (khalf ? all_slices - all_slices / 2 : all_slices / 2) : all_slices;
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin + s_begin * kW4KS;
     constexpr unsigned kOob = 0x80000000u;
-    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
+    const long long xbytes = (long long)a.H * a.W * a.Cin * 4 - (long long)s_begin * kW4KS * 4;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), (short)0, (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
-    const float *ubase = a.u + (size_t)nt * n_slices * kW4UFloats;
+    const float *ubase = a.u + ((size_t)nt * all_slices + s_begin) * kW4UFloats;
     const long long ubytes = (long long)n_slices * kW4UFloats * 4;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        a.ksplit == 2 ? a.part + ((size_t)tile_id * 2 + khalf) * (512 * kWinoBN) : nullptr, (short)0, a.ksplit == 2 ? 512 * kWinoBN * 4 : 0, 0x00020000);
+    const bool split = a.ksplit == 2;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
 
     const bool stager = wave >= 12;
@@ -679,9 +767,10 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
             __syncthreads();                                         // the phase's accumulators are in LDS
-            w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0);
+            w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
             __syncthreads();                                         // the staging area may be overwritten
         }
+        if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
         return;
 #undef RPN_W4_DMA_U
 #undef RPN_W4_LOAD_RAW
@@ -743,9 +832,10 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             }
         }
         __syncthreads();
-        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0);
+        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
         __syncthreads();
     }
+    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
 }
 #undef RPN_WINO_LDS_PTR
 
@@ -761,23 +851,45 @@ int wino_variant(int B, int H, int W, int Cin, int Cout)
         return n;
     }();
     if (Cin % kW4KS != 0) return 2;
-    if (knob == 2 || knob == 4) return knob;
+    if (knob == 2 || knob == 4 || knob == 8) return knob;
     const long long wgs4 = (long long)((W + 4 * kW4TX - 1) / (4 * kW4TX)) * ((H + 4 * kW4TY - 1) / (4 * kW4TY)) * B * ((Cout + kWinoBN - 1) / kWinoBN);
-    return wgs4 >= n_cus ? 4 : 2;
+    if (wgs4 >= n_cus) return 4;
+    return 2 * wgs4 >= n_cus && Cin >= 64 && wgs4 <= kW4Tickets ? 8 : 2;       // 8: F(4x4, 3x3), the input channels split over two workgroups per tile
+}
+
+// device workspace of a variant-8 layer: kW4Tickets tickets (one per tile; zero-initialised ONCE by the owner, the kernel leaves every
+// ticket at zero) at a FIXED place in front -- launches of different batch sizes share the buffer, and a ticket must never lie where
+// another launch writes partial tiles --, then 2 partial tiles of 512 x 64 floats per tile
+static long long wino4_tiles(int B, int H, int W, int Cout)
+{
+    return (long long)((W + 4 * kW4TX - 1) / (4 * kW4TX)) * ((H + 4 * kW4TY - 1) / (4 * kW4TY)) * B * ((Cout + kWinoBN - 1) / kWinoBN);
+}
+size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant)
+{
+    (void)Cin;
+    if (variant != 8) return 0;
+    return (size_t)kW4Tickets * 4 + (size_t)wino4_tiles(B, H, W, Cout) * 2 * 512 * kWinoBN * 4;
 }
 
 hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias, float *out, int B, int H, int W, int Cin,
-                               int Cout, int act, bool pool, hipStream_t s, int variant)
+                               int Cout, int act, bool pool, hipStream_t s, int variant, void *workspace)
 {
-    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4)) return hipErrorInvalidValue;
+    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8)) return hipErrorInvalidValue;
     if ((long long)H * W * Cin * 4 > 0x7fffffffll) return hipErrorInvalidValue;
     WinoArgs a{};
     a.x = x; a.u = u; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act; a.pool = pool ? 1 : 0;
-    if (variant == 4) {
+    a.ksplit = 1;
+    if (variant == 8) {
+        if (!workspace || Cin / kW4KS < 2 || wino4_tiles(B, H, W, Cout) > kW4Tickets) return hipErrorInvalidValue;
+        a.ksplit = 2;
+        a.tickets = static_cast<unsigned *>(workspace);
+        a.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + (size_t)kW4Tickets * 4);
+    }
+    if (variant == 4 || variant == 8) {
         const int tiles_x = (W + 4 * kW4TX - 1) / (4 * kW4TX), tiles_y = (H + 4 * kW4TY - 1) / (4 * kW4TY);
         const int n_tiles = (Cout + kWinoBN - 1) / kWinoBN;
-        const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles;
+        const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles * a.ksplit;
         if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
         hipLaunchKernelGGL(conv3x3_wino4_f32_kernel, dim3((unsigned)nblocks), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
         return hipGetLastError();

@@ -97,6 +97,9 @@ struct rpn_model {
     // only while the forwards of a handle run in stream order.  Two concurrent rpn_model_forward calls on the SAME handle
     // from different streams are not supported (rpn_hip.h says so); use one handle per stream.
     float *d_ksplit = nullptr;
+    // f32w layers on F(4x4, 3x3) with split input channels (wino_variant 8): partial tiles + tickets (conv_kernels.h), one buffer for
+    // all such layers of the handle, under the same one-stream-at-a-time rule
+    void *d_wino_ws = nullptr;
     const float *last_input = nullptr;
     double flops = 0.0;
     // optional per-op timing: one hipEvent before the first op and one after every op
@@ -581,6 +584,15 @@ static int ensure_device(rpn_model *m)
         RPN_HIP_CHECK(hipMalloc(&m->d_status, 64));
         RPN_HIP_CHECK(hipMemset(m->d_status, 0, 64));
     }
+    if (!m->d_wino_ws) {
+        size_t need = 0;
+        for (const Op &op : m->ops)
+            if (op.kind == OP_CONV && op.wino) need = std::max(need, wino_workspace_bytes(m->max_batch, op.H, op.W, op.Cin, op.Cout, op.wino_f));
+        if (need) {
+            RPN_HIP_CHECK(hipMalloc(&m->d_wino_ws, need));
+            RPN_HIP_CHECK(hipMemset(m->d_wino_ws, 0, need));
+        }
+    }
     if (!m->d_ksplit) {
         bool any = false;
         for (const Op &op : m->ops) any = any || (op.kind == OP_IRBLOCK && op.ir_x3);
@@ -635,6 +647,7 @@ extern "C" void rpn_model_destroy(rpn_model *m)
     if (m->d_arena) (void)hipFree(m->d_arena);
     if (m->d_status) (void)hipFree(m->d_status);
     if (m->d_ksplit) (void)hipFree(m->d_ksplit);
+    if (m->d_wino_ws) (void)hipFree(m->d_wino_ws);
     for (auto &ev : m->events) (void)hipEventDestroy(ev);
     delete m;
 }
@@ -999,7 +1012,7 @@ extern "C" int rpn_model_forward(rpn_model *m, const float *d_imgs, int B, float
             const bool pool = f32_pool_fused(m, oi);                    // + block*_pool: a Winograd tile's 2 x 2 outputs are one window
             e = launch_conv3x3_wino(x, m->d_weights + op.w_off, m->d_weights + op.b_off,
                                     tensor_ptr(m, pool ? m->ops[oi + 1].out : op.out, d_imgs), B, op.H, op.W, op.Cin, op.Cout, op.act,
-                                    pool, s, op.wino_f);
+                                    pool, s, op.wino_f, m->d_wino_ws);
             skip_next = pool;
         } else if (op.kind == OP_CONV || op.kind == OP_HEAD) {
             ConvArgs a{};
@@ -1161,7 +1174,8 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         else if (is_pw_x3(m, op))
             snprintf(kname32, sizeof kname32, "pw_f16x3<%d,%d>", op.Cin, op.Cout);
         else if (op.kind == OP_CONV && op.wino)
-            snprintf(kname32, sizeof kname32, op.wino_f == 4 ? "conv3x3_wino4_f32<16x32x64>" : "conv3x3_wino_f32<16x16x64>");   // (fl above: the direct conv's flops; 4 x / 2.25 x fewer are executed)
+            snprintf(kname32, sizeof kname32, op.wino_f == 4 ? "conv3x3_wino4_f32<16x32x64>"
+                                              : (op.wino_f == 8 ? "conv3x3_wino4_f32<16x32x64,k2>" : "conv3x3_wino_f32<16x16x64>"));   // (fl above: the direct conv's flops; 4 x / 2.25 x fewer are executed)
         else
         {
             const int bn32 = conv_f32_tile_n(m->max_batch, op.OH, op.OW, op.Cout);
@@ -1296,11 +1310,16 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
         RPN_HIP_CHECK(hipMemcpy(hw.data(), d_w, wcount * sizeof(float), hipMemcpyDeviceToHost));
         pack_weights_wino_host(hw.data(), nullptr, Cin, Cout, packed.data(), wf);
         float *d_u = nullptr;
+        void *d_ws = nullptr;
         RPN_HIP_CHECK(hipMalloc(&d_u, packed.size() * sizeof(float)));
         hipError_t e = hipMemcpy(d_u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = launch_conv3x3_wino(d_x, d_u, d_bias, d_out, B, H, W, Cin, Cout, act, false, s, wf);
+        const size_t ws_bytes = wino_workspace_bytes(B, H, W, Cin, Cout, wf);
+        if (e == hipSuccess && ws_bytes) e = hipMalloc(&d_ws, ws_bytes);
+        if (e == hipSuccess && ws_bytes) e = hipMemset(d_ws, 0, ws_bytes);
+        if (e == hipSuccess) e = launch_conv3x3_wino(d_x, d_u, d_bias, d_out, B, H, W, Cin, Cout, act, false, s, wf, d_ws);
         const hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(d_u);
+        if (d_ws) (void)hipFree(d_ws);
         if (e != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(f32w): launch failed: %s", hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(RPN_ERR_NO_DEVICE, "rpn_conv2d(f32w): kernel failed: %s", hipGetErrorString(e2));
         return RPN_OK;
