@@ -37,6 +37,7 @@ namespace rpn {
 
 using f32x16_w = __attribute__((ext_vector_type(16))) float;
 using f32x4_w = __attribute__((ext_vector_type(4))) float;
+using f32x2_w = __attribute__((ext_vector_type(2))) float;
 using u32x4_w = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kWinoThreads = 768;              // 8 MFMA waves + 4 staging waves
@@ -429,7 +430,7 @@ void pack_weights_wino4_host(const float *hwio, const float *scale, int Cin, int
                     for (int i = 0; i < 6; ++i)
                         for (int j = 0; j < 6; ++j) {
                             const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                            dst[(((size_t)nt * n_slices + s) * kW4Xi + (6 * i + j)) * (kW4KS * kWinoBN) + k * kWinoBN + nn] = (float)u;
+                            dst[(((size_t)nt * n_slices + s) * kW4Xi + (6 * i + j)) * (kW4KS * kWinoBN) + k * kWinoBN + (nn & 31) * 2 + (nn >> 5)] = (float)u;
                         }
                 }
 }
@@ -610,7 +611,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     static_assert(2 * kW4UFloats == kW4Half && 2 * (kW4VFloats + kW4KS * kW4Plane) <= kW4Half, "LDS layout");
     __shared__ __attribute__((aligned(16))) float ldsU[kW4Half];
     __shared__ __attribute__((aligned(16))) float ldsVR[kW4Half];
-    float (*Us)[kW4UFloats] = reinterpret_cast<float (*)[kW4UFloats]>(ldsU);
     float (*Vs)[kW4VFloats] = reinterpret_cast<float (*)[kW4VFloats]>(ldsVR);
     float (*raws)[kW4KS * kW4Plane] = reinterpret_cast<float (*)[kW4KS * kW4Plane]>(ldsVR + 2 * kW4VFloats);
 
@@ -645,7 +645,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 
     const bool stager = wave >= 12;
     const int hid = tid - 768;             // staging thread 0 .. 255
-    const int sw = wave - 12;              // staging wave 0 .. 3
     const int kh = lane >> 5, l31 = lane & 31;
 
     if (stager) {
@@ -667,10 +666,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         const int t_tile = t_pair & 31, t_c = t_pair >> 5;
         const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
         u32x4_w rr[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-#define RPN_W4_DMA_U(SLICE, BUF)                                                                                            \
-    _Pragma("unroll") for (int q = 0; q < 9; ++q)                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, RPN_WINO_LDS_PTR(&Us[BUF][(sw * 9 + q) * 256]), 16,                   \
-                                                 (unsigned)(((sw * 9 + q) * 256 + lane * 4) * 4), (SLICE) * kW4UFloats * 4, 0, 0)
 #define RPN_W4_LOAD_RAW(CB)                                                                                                 \
     do {                                                                                                                    \
         rr[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (CB), 0);                                              \
@@ -722,7 +717,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
         // wait -- to turn the LDS-DMA's Infinity-Cache / HBM misses into L2 hits measured SLOWER: 1 717 -> 1 639 images/s.)
         RPN_W4_LOAD_RAW(0);
-        RPN_W4_DMA_U(0, 0);
         raw_to_lds(0);
         if (n_slices > 1) RPN_W4_LOAD_RAW(kW4KS * 4);
         __syncthreads();
@@ -739,9 +733,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #ifndef RPN_EXP_W4_NORAW
                 RPN_W4_LOAD_RAW((s + 2) * kW4KS * 4);
 #endif
-#ifndef RPN_EXP_W4_NODMA
-                RPN_W4_DMA_U(s + 1, cur ^ 1);
-#endif
 #ifndef RPN_EXP_W4_NOXF
                 transform(cur ^ 1);
 #endif
@@ -749,9 +740,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
                 raw_to_lds(cur);
 #endif
             } else if (s + 1 < n_slices) {
-#ifndef RPN_EXP_W4_NODMA
-                RPN_W4_DMA_U(s + 1, cur ^ 1);
-#endif
 #ifndef RPN_EXP_W4_NOXF
                 transform(cur ^ 1);
 #endif
@@ -772,7 +760,6 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         }
         if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
         return;
-#undef RPN_W4_DMA_U
 #undef RPN_W4_LOAD_RAW
     }
 
@@ -784,36 +771,47 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.0f;
-    __syncthreads();
-    __syncthreads();
-    for (int s = 0; s < n_slices; ++s) {
-        const int cur = s & 1;
-        const float *U = Us[cur];
-        const float *V = Vs[cur];
-        float av[2], bv[2][2];
-        auto ld = [&](int g, int buf) {                  // group g = (k pair g / 3, xi j = g % 3): an accumulator is reused after six MFMAs
-            const int xi = 3 * wave + (g % 3), k = 2 * (g / 3) + kh;
-            av[buf] = V[(xi * kW4KS + k) * 32 + l31];
-            const float *ub = U + (xi * kW4KS + k) * kWinoBN + l31;
-            bv[buf][0] = ub[0];
-            bv[buf][1] = ub[32];
-        };
-        constexpr int kCross = 0x2 | 0x4 | 0x10 | 0x200;
-        ld(0, 0);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            if (g + 1 < 6) ld(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(kCross);
-            const int j = g % 3, bf = g & 1;
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf], bv[bf][0], acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bf], bv[bf][1], acc[j][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(kCross);
-        }
-#ifdef RPN_EXP_W4_HALFBAR       /* timing experiment (with NOSTAGE): a barrier only every second slice */
-        if (s & 1)
-#endif
-        __syncthreads();
+    // The filters go STRAIGHT from L2 into this wave's registers: a wave owns its three xi, so no other wave ever reads its filter
+    // fragments, and (pack_weights_wino4_host) lane l31 finds channels l31 and l31 + 32 of (xi, k) as one 8-byte word -- six 8-byte
+    // loads per slice and wave, requested a whole slice ahead into the other register set.  (Through LDS -- DMA in, fragment reads
+    // out -- they were 72 of the 137 KB of LDS traffic per slice, and LDS-pipe time is added to the slice like vector-ALU time.)
+    f32x2_w ureg[2][6];
+    const unsigned u_voff = (unsigned)((((3 * wave) * kW4KS + kh) * kWinoBN + l31 * 2) * 4);
+#define RPN_W4_LOAD_U(SLICE, SET)                                                                                           \
+    _Pragma("unroll") for (int g = 0; g < 6; ++g)                                                                           \
+        ureg[SET][g] = __builtin_bit_cast(f32x2_w, __builtin_amdgcn_raw_buffer_load_b64(                                    \
+            urs, u_voff + (unsigned)((((g % 3) * kW4KS + 2 * (g / 3)) * kWinoBN) * 4), (SLICE) * kW4UFloats * 4, 0))
+#define RPN_W4_SLICE(S, SET)                                                                                                \
+    {                                                                                                                       \
+        const int nxt_ = (S) + 1 < n_slices ? (S) + 1 : (S);          /* (past the end: the last slice again, unused) */    \
+        RPN_W4_LOAD_U(nxt_, (SET) ^ 1);                                                                                     \
+        const float *V = Vs[(S) & 1];                                                                                       \
+        float av[2];                                                                                                        \
+        av[0] = V[((3 * wave) * kW4KS + kh) * 32 + l31];                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 6; ++g) {              /* group g = (k pair g / 3, xi j = g % 3) */           \
+            if (g + 1 < 6) av[(g + 1) & 1] = V[((3 * wave + ((g + 1) % 3)) * kW4KS + 2 * ((g + 1) / 3) + kh) * 32 + l31];   \
+            __builtin_amdgcn_sched_barrier(kCross);                                                                         \
+            const int j = g % 3;                                                                                            \
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[SET][g][0], acc[j][0], 0, 0, 0);               \
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[SET][g][1], acc[j][1], 0, 0, 0);               \
+            __builtin_amdgcn_sched_barrier(kCross);                                                                         \
+        }                                                                                                                   \
+        __syncthreads();                                                                                                    \
     }
+    constexpr int kCross = 0x2 | 0x4 | 0x10 | 0x200;
+    RPN_W4_LOAD_U(0, 0);
+    __syncthreads();
+    __syncthreads();
+    {
+        int s = 0;
+        for (; s + 1 < n_slices; s += 2) {
+            RPN_W4_SLICE(s, 0);
+            RPN_W4_SLICE(s + 1, 1);
+        }
+        if (s < n_slices) RPN_W4_SLICE(s, 0);
+    }
+#undef RPN_W4_SLICE
+#undef RPN_W4_LOAD_U
 
     // ---- epilogue: park the 32 channels of N block ph ([xi 36][tile 32][32 channels] = 144 KB over the whole LDS block: the slice
     // loop's buffers are dead), then every thread transforms one (tile, channel) pair; the accumulators of the other N block stay in
