@@ -658,7 +658,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
             const bool v = pix < kW4PatchH * kW4PatchW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
-            r_lds[j] = py * kW4Pitch + px;
+            r_lds[j] = py * kW4Pitch + px + ((py >> 2) & 1) * 2;      // rows of odd tile rows skewed by two floats (see transform)
         }
         const bool third = hid + 512 < kW4PatchH * kW4PatchW;
         // transform role: pair = (tile, channel), two threads per pair (output rows 3 part .. 3 part + 2)
@@ -685,17 +685,22 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         auto transform = [&](int buf) {
             // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
             // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
-            int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx;
-            asm volatile("" : "+v"(ro));
+            // Bank skew: tile columns are 4 floats apart and four tile rows 144 = 16 (mod 32) floats, so the 32 tiles of a wave's
+            // 8-byte read would fall on 16 of the 32 banks; patch rows 4 .. 7, 12 .. 15 are stored two floats to the right
+            // (raw_to_lds), which puts odd tile rows on the other 16.  A tile's rows 4, 5 belong to the next tile row: second base.
+            int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
+            int ro45 = ro + 2 - (t_ty & 1) * 4;
+            asm volatile("" : "+v"(ro), "+v"(ro45));
             const float *rp = ldsVR + ro;
+            const float *rp45 = ldsVR + ro45;
             float T[3][6];
 #pragma unroll
             for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
                 float d0[6], d1[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
-                    d0[r] = rp[r * kW4Pitch + 2 * jp];
-                    d1[r] = rp[r * kW4Pitch + 2 * jp + 1];
+                    d0[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp];
+                    d1[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp + 1];
                 }
                 float t0[3], t1[3];
                 if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
