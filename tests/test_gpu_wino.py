@@ -44,7 +44,10 @@ WINO_CASES = [
     # per tile, the last arriver adding the halves (variant 8)
     (8, 31, 31, 512, 512, "relu"),       # block5 / rpn_conv at batch 8: 128 tiles
     (8, 32, 32, 576, 512, "relu"),       # MobileNetV2's rpn_conv at batch 8
-    (4, 50, 90, 64, 160, "linear"),      # ragged, a 32-channel last N tile, eight slices per half
+    (4, 50, 90, 64, 160, "linear"),      # ragged, a 32-channel last N tile, eight slices per half (the 64-channel form: variant 8)
+    # Cout % 128 == 0 and >= 256 workgroups of 16 x 16 pixels x 128 channels: the wide F(4x4, 3x3) form (several cases above too)
+    (3, 70, 90, 16, 384, "relu6"),       # ragged tiles, three N tiles, four slices
+    (16, 50, 50, 8, 128, "linear"),      # two slices
 ]
 
 
@@ -54,6 +57,8 @@ def _variant(B, H, W, Cin, Cout):
     wgs4 = -(-W // 32) * -(-H // 16) * B * -(-Cout // 64)
     if Cin % 4:
         return 2
+    if Cout % 128 == 0 and -(-W // 16) * -(-H // 16) * B * (Cout // 128) >= cus:
+        return 16       # the wide form: 16 x 16 pixels x 128 channels per workgroup
     if wgs4 >= cus:
         return 4
     return 8 if 2 * wgs4 >= cus and Cin >= 64 else 2
@@ -122,7 +127,7 @@ def test_vgg16_forward_in_f32w_at_full_size_against_float64():
     assert np.abs(reg[:1] - ref_reg).max() <= 1e-4, np.abs(reg[:1] - ref_reg).max()
     assert np.abs(cls[:1] - ref_cls).max() <= 1e-4, np.abs(cls[:1] - ref_cls).max()
     kinds = {op["name"]: (op["kernel"], op["arith"]) for op in model.ops()}
-    assert kinds["block3_conv2"] == ("conv3x3_wino4_f32<16x32x64>", "f32w") and kinds["rpn_conv"] == ("conv3x3_wino_f32<16x16x64>", "f32w")
+    assert kinds["block3_conv2"][0].startswith("conv3x3_wino4_f32<") and kinds["rpn_conv"] == ("conv3x3_wino_f32<16x16x64>", "f32w")
     assert kinds["block1_conv1"][1] == "f32"
     assert "fused:maxpool_f32" in [k for k, _ in kinds.values()]
     reg1, cls1 = model.predict_on_batch(imgs[1:2])

@@ -66,8 +66,9 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
                            const float *conv_bias = nullptr);
 
 // ---- 3x3 stride-1 'same' conv as Winograd F(2x2, 3x3) on the float32 MFMA (conv_wino_kernels.hip; precision "f32w") ----
-// variant: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3), 8 = F(4x4, 3x3) with the input channels split over two workgroups per tile
-// (wino_variant picks per layer from the grid at the handle's largest batch).
+// variant: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3) on 16 x 32-pixel x 64-channel tiles, 16 = F(4x4, 3x3) on 16 x 16-pixel x 128-channel tiles
+// (Cout % 128 == 0), 8 = the 64-channel form with the input channels split over two workgroups per tile (wino_variant picks per
+// layer from the grid at the handle's largest batch).
 // u = pack_weights_wino_host(HWIO weights, variant): wino_weight_floats floats; out: (B,H,W,Cout) or, pool, (B,H/2,W/2,Cout).
 // workspace (variant 8 only): wino_workspace_bytes bytes of device memory, zeroed ONCE by the owner (partial tiles + tickets; the
 // kernel leaves the tickets at zero), private to one stream at a time.

@@ -49,8 +49,10 @@ constexpr int kUFloats = 16 * kWinoKS * kWinoBN;                // 8192 floats =
 constexpr int kVFloats = 16 * kWinoKS * 64;                     // V[xi][k][tile]
 
 size_t wino4_weight_floats(int Cin, int Cout);
+size_t wino4n_weight_floats(int Cin, int Cout);
 size_t wino_weight_floats(int Cin, int Cout, int variant)
 {
+    if (variant == 16) return wino4n_weight_floats(Cin, Cout);
     return variant == 4 || variant == 8 ? wino4_weight_floats(Cin, Cout) : (size_t)((Cout + kWinoBN - 1) / kWinoBN) * (Cin / kWinoKS) * kUFloats;
 }
 bool wino_supported(int Cin, int Cout) { return Cin >= kWinoKS && Cin % kWinoKS == 0 && Cout >= 32 && Cout % 32 == 0; }
@@ -58,8 +60,13 @@ bool wino_supported(int Cin, int Cout) { return Cin >= kWinoKS && Cin % kWinoKS 
 // HWIO (3,3,Cin,Cout) -> U = G g G^T per (c, n), laid out [n_tile][slice][xi = 4 i + j][k][64]; scale[n] (BatchNorm fold) or null.
 // Computed in double and rounded once (the halves are exact, the sums of three weights are not).
 void pack_weights_wino4_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst);
+void pack_weights_wino4n_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst);
 void pack_weights_wino_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst, int variant)
 {
+    if (variant == 16) {
+        pack_weights_wino4n_host(hwio, scale, Cin, Cout, dst);
+        return;
+    }
     if (variant == 4 || variant == 8) {
         pack_weights_wino4_host(hwio, scale, Cin, Cout, dst);
         return;
@@ -395,9 +402,10 @@ conv3x3_wino_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // Same structure as the F(2x2, 3x3) kernel above: a 1024-thread workgroup per CU owns 4 x 8 tiles = 16 x 32 output pixels x 64 output
 // channels and walks the input channels in slices of 4, one barrier per slice; four STAGING waves (18 x 34 x 4 patch -> LDS, the 6 x 6
-// transforms -- a (tile, channel) pair by two threads, three output rows each --, the slice's 36 filter matrices by LDS-DMA: 36 KB),
-// twelve MFMA waves (xi = 3 w .. 3 w + 2 each: 96 accumulator registers; 12 MFMAs per slice and wave).  Used where its 16 x 32-pixel
-// tiles fill the chip (wino_variant); the 31 x 31 layers stay on F(2x2, 3x3).
+// transforms -- a (tile, channel) pair by two threads, three output rows each), twelve MFMA waves (xi = 3 w .. 3 w + 2 each: 96
+// accumulator registers; 12 MFMAs per slice and wave; the wave's filter fragments straight from L2 into its registers, a slice
+// ahead).  Used where its 16 x 32-pixel tiles fill the chip; where they fill half of it (the 31 x 31 layers at batch 8) the input
+// channels are split over two workgroups per tile (wino_variant 8, w4_ksplit_finish); smaller grids stay on F(2x2, 3x3).
 constexpr int kW4Threads = 1024;            // 12 MFMA waves + 4 staging waves
 constexpr int kW4KS = 4;                    // input channels per slice
 constexpr int kW4Xi = 36;
@@ -543,6 +551,9 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
 __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, int tid, int tile_id, int img, int oy0, int ox0, int n0)
 {
     constexpr int kSc1 = 16;
+    constexpr int BN = kWinoBN, TW = 32;
+    constexpr int kPartF = 512 * kWinoBN;                // floats per partial tile: 512 pixels x 64 channels
+    constexpr int kC4 = BN / 4;                          // 16-byte pieces per pixel
     unsigned *flag = reinterpret_cast<unsigned *>(lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -553,21 +564,20 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
     }
     __syncthreads();
     if (*flag != 1u) return;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)tile_id * 2 * (512 * kWinoBN), (short)0,
-                                                                        2 * 512 * kWinoBN * 4, 0x00020000);
-    if (a.pool) {                                        // + block*_pool: 8 x 16 pooled pixels x 16 pieces, two per thread
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)tile_id * 2 * kPartF, (short)0, 2 * kPartF * 4, 0x00020000);
+    if (a.pool) {                                        // + block*_pool: 8 x TW / 2 pooled pixels x kC4 pieces, two per thread
         const int PH = a.H >> 1, PW = a.W >> 1;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = k * kW4Threads + tid;
-            const int ppix = e >> 4, c4 = (e & 15) * 4;
-            const int py = (oy0 >> 1) + (ppix >> 4), px = (ox0 >> 1) + (ppix & 15), n = n0 + c4;
+            const int ppix = e / kC4, c4 = (e % kC4) * 4;
+            const int py = (oy0 >> 1) + ppix / (TW / 2), px = (ox0 >> 1) + ppix % (TW / 2), n = n0 + c4;
             f32x4_w m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const int pix = (2 * (ppix >> 4) + (w >> 1)) * 32 + 2 * (ppix & 15) + (w & 1);
-                const f32x4_w p0 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, (pix * kWinoBN + c4) * 4, 0, kSc1));
-                const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, 512 * kWinoBN * 4 + (pix * kWinoBN + c4) * 4, 0, kSc1));
+                const int pix = (2 * (ppix / (TW / 2)) + (w >> 1)) * TW + 2 * (ppix % (TW / 2)) + (w & 1);
+                const f32x4_w p0 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, (pix * BN + c4) * 4, 0, kSc1));
+                const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, kPartF * 4 + (pix * BN + c4) * 4, 0, kSc1));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m[i] = w == 0 ? p0[i] + p1[i] : fmaxf(m[i], p0[i] + p1[i]);
             }
@@ -585,10 +595,10 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                        // 8192 pieces of four channels, eight per thread
         const int e = k * kW4Threads + tid;
-        const int pix = e >> 4, c4 = (e & 15) * 4;
+        const int pix = e / kC4, c4 = (e % kC4) * 4;
         const f32x4_w p0 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16, 0, kSc1));
-        const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, 512 * kWinoBN * 4 + e * 16, 0, kSc1));
-        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31), n = n0 + c4;
+        const f32x4_w p1 = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(rs, kPartF * 4 + e * 16, 0, kSc1));
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW, n = n0 + c4;
         if (oy < a.H && ox < a.W && n < a.Cout) {
             f32x4_w b = {0.f, 0.f, 0.f, 0.f};
             if (a.bias) b = *reinterpret_cast<const f32x4_w *>(a.bias + n);
@@ -603,10 +613,10 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    // two arrays of 72 KB: ldsU = U x 2 | ldsVR = V x 2 (36 KB), raw x 2 (20.25 KB), padding.  TWO, because hipcc's waitcnt pass lets an
-    // LDS access overtake an LDS-DMA in flight only when the two carry the alias scopes of DIFFERENT __shared__ arrays: with one block
-    // the staging waves' transform waited for the slice's filter DMA (and, results returning in order, for every load before it).
-    // The epilogue parks the 36 x 32 x 32 accumulators (144 KB) over both: xi 0 .. 17 in ldsU, xi 18 .. 35 in ldsVR.
+    // two arrays of 72 KB.  The slice loop uses ldsVR only: V x 2 (36 KB), raw x 2 (20.25 KB); the epilogue parks the 36 x 32 x 32
+    // accumulators of a phase (144 KB) over both: xi 0 .. 17 in ldsU, xi 18 .. 35 in ldsVR.  (Two arrays since the filters still came
+    // by LDS-DMA into ldsU: hipcc's waitcnt pass lets an LDS access overtake an LDS-DMA in flight only when the two carry the alias
+    // scopes of DIFFERENT __shared__ arrays.)
     constexpr int kW4Half = 18 * 32 * 32;                                  // floats per array
     static_assert(2 * kW4UFloats == kW4Half && 2 * (kW4VFloats + kW4KS * kW4Plane) <= kW4Half, "LDS layout");
     __shared__ __attribute__((aligned(16))) float ldsU[kW4Half];
@@ -648,6 +658,10 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int kh = lane >> 5, l31 = lane & 31;
 
     if (stager) {
+        // issue priority over the MFMA waves: the three MFMA waves of a SIMD always have a matrix instruction pending, and at equal
+        // priority the staging wave's vector instructions were starved behind them -- the MFMA waves then waited for it at the
+        // slice barrier (wide form 1 873 -> 1 976 images/s; no change for the 32-tile form, kept for symmetry)
+        __builtin_amdgcn_s_setprio(3);
         // a staging thread's pixels of a slice's raw patch (18 x 34 = 612 pixels, one 16-byte load = 4 channels each)
         unsigned r_off[3];
         int r_lds[3];
@@ -665,23 +679,27 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         const int t_part = hid & 1, t_pair = hid >> 1;
         const int t_tile = t_pair & 31, t_c = t_pair >> 5;
         const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-        u32x4_w rr[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-#define RPN_W4_LOAD_RAW(CB)                                                                                                 \
+        // TWO register sets for the raw patch: slice t travels in set t & 1, requested TWO iterations before the transform that reads
+        // it and written to LDS one iteration after the request -- a request consumed in the iteration that issues it makes every
+        // iteration at least one memory latency long, and the MFMA waves wait for the staging waves at the slice barrier (the matrix
+        // pipe was 48 % busy).  (The same idea measured slower while the filter DMAs shared the stream: their conservative
+        // vmcnt(0) waited for everything in flight.)
+        u32x4_w rr[2][3] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
+#define RPN_W4_LOAD_RAW(SLICE, SET)                                                                                         \
     do {                                                                                                                    \
-        rr[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (CB), 0);                                              \
-        rr[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (CB), 0);                                              \
-        rr[2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (CB), 0);   /* (no piece: kOob, zeros, no traffic) */   \
+        rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
+        rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);                          \
+        rr[SET][2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros, no traffic) */ \
     } while (0)
-        auto raw_to_lds = [&](int buf) {
-            float *raw = raws[buf];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < 2 || third) {
-                    const f32x4_w v = __builtin_bit_cast(f32x4_w, rr[j]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) raw[r_lds[j] + i * kW4Plane] = v[i];
-                }
-        };
+#define RPN_W4_RAW_TO_LDS(BUF, SET)                                                                                         \
+    {                                                                                                                       \
+        float *raw_ = raws[BUF];                                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                                    \
+            if (j_ < 2 || third) {                                                                                          \
+                const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kW4Plane] = v_[i_];                  \
+            }                                                                                                               \
+    }
         auto transform = [&](int buf) {
             // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
             // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
@@ -721,41 +739,37 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         };
         // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
         // wait -- to turn the LDS-DMA's Infinity-Cache / HBM misses into L2 hits measured SLOWER: 1 717 -> 1 639 images/s.)
-        RPN_W4_LOAD_RAW(0);
-        raw_to_lds(0);
-        if (n_slices > 1) RPN_W4_LOAD_RAW(kW4KS * 4);
+        const int last = n_slices - 1;
+        RPN_W4_LOAD_RAW(0, 0);
+        RPN_W4_RAW_TO_LDS(0, 0);
+        RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
+        RPN_W4_LOAD_RAW(2 < last ? 2 : last, 0);
         __syncthreads();
         transform(0);
-        if (n_slices > 1) raw_to_lds(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RPN_W4_RAW_TO_LDS(1, 1);
         __syncthreads();
-        for (int s = 0; s < n_slices; ++s) {
-            const int cur = s & 1;
-            /* timing experiments (wrong results): -DRPN_EXP_W4_NOSTAGE / _NODMA / _NOXF / _NORAW */
-#ifndef RPN_EXP_W4_NOSTAGE
-            // (full iterations and the last two as separate straight-line bodies: see conv3x3_wino_f32_kernel)
-            if (s + 2 < n_slices) {
-#ifndef RPN_EXP_W4_NORAW
-                RPN_W4_LOAD_RAW((s + 2) * kW4KS * 4);
-#endif
-#ifndef RPN_EXP_W4_NOXF
-                transform(cur ^ 1);
-#endif
-#ifndef RPN_EXP_W4_NORAW
-                raw_to_lds(cur);
-#endif
-            } else if (s + 1 < n_slices) {
-#ifndef RPN_EXP_W4_NOXF
-                transform(cur ^ 1);
-#endif
+        // iteration s (between its barriers the MFMA waves run slice s): request slice s + 3 into the set slice s + 1 has left,
+        // transform slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1]), write slice s + 2 (requested an iteration ago) to raws[s & 1]
+#define RPN_W4_STAGE(S, SET)                                                                                                \
+    {                                                                                                                       \
+        if ((S) + 2 < n_slices) {                                                                                           \
+            RPN_W4_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
+            transform((SET) ^ 1);                                                                                           \
+            RPN_W4_RAW_TO_LDS(SET, SET);                                                                                    \
+        } else if ((S) + 1 < n_slices) {                                                                                    \
+            transform((SET) ^ 1);                                                                                           \
+        }                                                                                                                   \
+        __syncthreads();                                                                                                    \
+    }
+        {
+            int s = 0;
+            for (; s + 1 < n_slices; s += 2) {
+                RPN_W4_STAGE(s, 0);
+                RPN_W4_STAGE(s + 1, 1);
             }
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // slice s + 1's filters have landed
-#ifdef RPN_EXP_W4_HALFBAR
-            if (s & 1)
-#endif
-            __syncthreads();
+            if (s < n_slices) RPN_W4_STAGE(s, 0);
         }
+#undef RPN_W4_STAGE
         // ---- epilogue: two phases of 32 output channels; every thread of the workgroup transforms one (tile, channel) pair per phase
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
@@ -766,6 +780,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
         return;
 #undef RPN_W4_LOAD_RAW
+#undef RPN_W4_RAW_TO_LDS
     }
 
     // ---- MFMA waves: xi = 3 wave + j, 32 tiles x 64 channels
@@ -840,6 +855,313 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
     if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
 }
+
+// =================================================================================================================================
+// F(4x4, 3x3), WIDE form: 4 x 4 tiles = 16 x 16 output pixels x 128 output channels per workgroup, on v_mfma_f32_16x16x4_f32 (M = 16
+// tiles, N = 16 channels, K = the slice's 4 input channels; the same 64 flops per cycle as 32x32x2).  The same accumulator footprint
+// as the 32-tile x 64-channel form (36 xi x 16 x 128 floats = 288 KB of registers) but HALF the staging per MFMA: the input transform
+// of a tile serves 128 output channels instead of 64 -- the patch (18 x 18 x 4 instead of 18 x 34 x 4), the transform's vector and
+// LDS work and V (9 KB per slice) all halve, and only the filter fragments double (straight from L2 into the owning wave's
+// registers: 24 per slice and wave, two 16-byte loads per xi).  LDS-pipe and vector-ALU time are ADDED to the float32 MFMA time on
+// this chip, so this is the lever.  Layers with Cout % 128 == 0 whose 16 x 16-pixel tiles fill the chip (wino_variant 16).
+//   U packing: [n_tile][slice][xi][k 4][c 16][nb 8]: lane (k = lane >> 4, c = lane & 15) holds channel nb * 16 + c of its k for the
+//   eight N blocks as 32 contiguous bytes.   V: [xi][k][16 tiles].   raw: [channel][18][20] + padding (plane = 18 (mod 32) floats: a
+//   transform wave's 32 (tile, channel) pairs cover all 32 banks with their 8-byte reads).
+constexpr int kWnBN = 128, kWnNT = 16, kWnPatch = 18, kWnPitch = 20, kWnPlane = kWnPatch * kWnPitch + 10;
+constexpr int kWnUFloats = kW4Xi * kW4KS * kWnBN;                        // 18432 floats = 72 KB per slice and N tile
+constexpr int kWnVFloats = kW4Xi * kW4KS * kWnNT;                        // 2304 floats = 9 KB
+static_assert(kWnPlane % 32 == 18, "raw plane stride");
+
+size_t wino4n_weight_floats(int Cin, int Cout) { return (size_t)((Cout + kWnBN - 1) / kWnBN) * (Cin / kW4KS) * kWnUFloats; }
+
+void pack_weights_wino4n_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst)
+{
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int n_tiles = (Cout + kWnBN - 1) / kWnBN, n_slices = Cin / kW4KS;
+    for (int nt = 0; nt < n_tiles; ++nt)
+        for (int s = 0; s < n_slices; ++s)
+            for (int k = 0; k < kW4KS; ++k)
+                for (int nn = 0; nn < kWnBN; ++nn) {
+                    const int c = s * kW4KS + k, n = nt * kWnBN + nn;
+                    double g[3][3];
+                    for (int r = 0; r < 3; ++r)
+                        for (int q = 0; q < 3; ++q)
+                            g[r][q] = n < Cout ? (double)hwio[((size_t)(r * 3 + q) * Cin + c) * Cout + n] * (scale ? (double)scale[n] : 1.0) : 0.0;
+                    double t[6][3];
+                    for (int i = 0; i < 6; ++i)
+                        for (int q = 0; q < 3; ++q) t[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = 0; j < 6; ++j) {
+                            const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                            dst[(((size_t)nt * n_slices + s) * kW4Xi + (6 * i + j)) * (kW4KS * kWnBN) + (k * 16 + (nn & 15)) * 8 + (nn >> 4)] = (float)u;
+                        }
+                }
+}
+
+// output transform of one (tile, channel) pair of an epilogue phase of the wide form: thread -> (channel = tid & 63 of the phase's
+// 64, tile = tid >> 6); MsA / MsB = the parked accumulators [xi][16 tiles][64 channels] of xi 0 .. 17 / 18 .. 35
+__device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0)
+{
+    const int e_n = tid & 63, e_tile = tid >> 6;
+    const int e_ty = e_tile >> 2, e_tx = e_tile & 3;
+    const int n = n0 + ph * 64 + e_n;
+    const float bias = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+    const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
+    if (n >= a.Cout) return;
+#pragma unroll 1
+    for (int hp = 0; hp < 2; ++hp) {                      // two output rows at a time (see w4_output_pair)
+        float R0[6], R1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * kWnNT + e_tile) * 64 + e_n];     // xi = 6 i + j
+            const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
+            if (hp == 0) {
+                R0[j] = m[0] + pp + rr;
+                R1[j] = __builtin_fmaf(2.0f, ss, qq);
+            } else {
+                R0[j] = __builtin_fmaf(4.0f, rr, pp);
+                R1[j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
+            }
+        }
+        const int p = 2 * hp;
+        float y0[4], y1[4];
+        w4_at(R0, y0);
+        w4_at(R1, y1);
+        if (a.pool) {
+            const int PH = a.H >> 1, PW = a.W >> 1, py = (oy + p) >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const int px = (ox + q) >> 1;
+                if (py < PH && px < PW) {
+                    const float v = fmaxf(fmaxf(y0[q], y0[q + 1]), fmaxf(y1[q], y1[q + 1]));
+                    a.out[(((size_t)img * PH + py) * PW + px) * a.Cout + n] = wino_act(v + bias, a.act);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (oy + p < a.H && ox + q < a.W)
+                    a.out[(((size_t)img * a.H + oy + p) * a.W + ox + q) * a.Cout + n] = wino_act(y0[q] + bias, a.act);
+                if (oy + p + 1 < a.H && ox + q < a.W)
+                    a.out[(((size_t)img * a.H + oy + p + 1) * a.W + ox + q) * a.Cout + n] = wino_act(y1[q] + bias, a.act);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kW4Threads, 1)
+conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
+{
+    // two arrays of 72 KB: the slice loop uses ldsVR only (V x 2: 18 KB, raw x 2: 11.6 KB); the epilogue parks the 36 x 16 x 64
+    // accumulators of a phase (144 KB) over both: xi 0 .. 17 in ldsA, xi 18 .. 35 in ldsVR
+    constexpr int kHalf = 18 * kWnNT * 64;                                 // floats per array
+    static_assert(2 * (kWnVFloats + kW4KS * kWnPlane) <= kHalf, "LDS layout");
+    __shared__ __attribute__((aligned(16))) float ldsA[kHalf];
+    __shared__ __attribute__((aligned(16))) float ldsVR[kHalf];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = wg % n_tiles;
+    int mt = wg / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    const int img = mt / tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16, n0 = nt * kWnBN;
+
+    const int n_slices = a.Cin / kW4KS;
+    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
+    constexpr unsigned kOob = 0x80000000u;
+    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), (short)0, (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
+    const float *ubase = a.u + (size_t)nt * n_slices * kWnUFloats;
+    const long long ubytes = (long long)n_slices * kWnUFloats * 4;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
+
+    const bool stager = wave >= 12;
+    const int hid = tid - 768;             // staging thread 0 .. 255
+    const int k4 = lane >> 4, l15 = lane & 15;
+
+    if (stager) {
+        __builtin_amdgcn_s_setprio(3);                 // (see conv3x3_wino4_f32_kernel)
+        // a staging thread's pixels of a slice's raw patch (18 x 18 = 324 pixels, one 16-byte load = 4 channels each)
+        unsigned r_off[2];
+        int r_lds[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pix = hid + j * 256;
+            const int py = pix / kWnPatch, px = pix - py * kWnPatch;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool v = pix < kWnPatch * kWnPatch && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+            r_lds[j] = py * kWnPitch + px;
+        }
+        const bool second = hid + 256 < kWnPatch * kWnPatch;
+        // transform role (staging threads 0 .. 127): pair = (tile, channel), two threads per pair (output rows 3 part .. 3 part + 2)
+        const bool xf = hid < 128;
+        const int t_part = hid & 1, t_pair = (hid >> 1) & 63;
+        const int t_tile = t_pair & 15, t_c = t_pair >> 4;
+        const int t_ty = t_tile >> 2, t_tx = t_tile & 3;
+        // (two register sets, a slice's patch requested two iterations before its transform: see conv3x3_wino4_f32_kernel)
+        u32x4_w rr[2][2] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
+#define RPN_WN_LOAD_RAW(SLICE, SET)                                                                                         \
+    do {                                                                                                                    \
+        rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
+        rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros) */ \
+    } while (0)
+#define RPN_WN_RAW_TO_LDS(BUF, SET)                                                                                         \
+    {                                                                                                                       \
+        float *raw_ = ldsVR + 2 * kWnVFloats + (BUF) * (kW4KS * kWnPlane);                                                  \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                    \
+            if (j_ < 1 || second) {                                                                                         \
+                const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kWnPlane] = v_[i_];                  \
+            }                                                                                                               \
+    }
+        auto transform = [&](int buf) {
+            if (!xf) return;
+            int ro = 2 * kWnVFloats + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx;
+            asm volatile("" : "+v"(ro));
+            const float *rp = ldsVR + ro;
+            float T[3][6];
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) {
+                float d0[6], d1[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    d0[r] = rp[r * kWnPitch + 2 * jp];
+                    d1[r] = rp[r * kWnPitch + 2 * jp + 1];
+                }
+                float t0[3], t1[3];
+                if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
+                else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
+            }
+            int vo = buf * kWnVFloats + (18 * t_part) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
+            asm volatile("" : "+v"(vo));
+            float *vp = ldsVR + vo;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float v[6];
+                w4_bt6(T[i], v);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+            }
+        };
+        const int last = n_slices - 1;
+        RPN_WN_LOAD_RAW(0, 0);
+        RPN_WN_RAW_TO_LDS(0, 0);
+        RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
+        RPN_WN_LOAD_RAW(2 < last ? 2 : last, 0);
+        __syncthreads();
+        transform(0);
+        RPN_WN_RAW_TO_LDS(1, 1);
+        __syncthreads();
+#ifdef RPN_EXP_WN_NOSTAGE    /* timing experiment (wrong results): the staging waves only keep the barriers */
+#define RPN_WN_STAGE(S, SET) __syncthreads();
+#else
+#define RPN_WN_STAGE(S, SET)                                                                                                \
+    {                                                                                                                       \
+        if ((S) + 2 < n_slices) {                                                                                           \
+            RPN_WN_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
+            transform((SET) ^ 1);                                                                                           \
+            RPN_WN_RAW_TO_LDS(SET, SET);                                                                                    \
+        } else if ((S) + 1 < n_slices) {                                                                                    \
+            transform((SET) ^ 1);                                                                                           \
+        }                                                                                                                   \
+        __syncthreads();                                                                                                    \
+    }
+#endif
+        {
+            int s = 0;
+            for (; s + 1 < n_slices; s += 2) {
+                RPN_WN_STAGE(s, 0);
+                RPN_WN_STAGE(s + 1, 1);
+            }
+            if (s < n_slices) RPN_WN_STAGE(s, 0);
+        }
+#undef RPN_WN_STAGE
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ++ph) {
+            __syncthreads();                                         // the phase's accumulators are in LDS
+            w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
+            __syncthreads();                                         // the staging area may be overwritten
+        }
+        return;
+#undef RPN_WN_LOAD_RAW
+#undef RPN_WN_RAW_TO_LDS
+    }
+
+    // ---- MFMA waves: xi = 3 wave + j, 16 tiles x 128 channels = eight 16 x 16 blocks per xi
+    f32x4_w acc[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) acc[j][nb] = f32x4_w{0.f, 0.f, 0.f, 0.f};
+    // filter fragments: ONE register set; xi j's fragments of the next slice are requested right behind its MFMAs of this slice (a
+    // whole slice of latency budget; two sets would be 48 registers beside the 96 accumulators)
+    f32x4_w ureg[3][2];
+    const unsigned u_voff = (unsigned)(((3 * wave) * (kW4KS * kWnBN) + lane * 8) * 4);
+#define RPN_WN_LOAD_U(SLICE, J)                                                                                             \
+    {                                                                                                                       \
+        ureg[J][0] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff + (unsigned)((J) * (kW4KS * kWnBN) * 4), (SLICE) * kWnUFloats * 4, 0));        \
+        ureg[J][1] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff + (unsigned)((J) * (kW4KS * kWnBN) * 4 + 16), (SLICE) * kWnUFloats * 4, 0));   \
+    }
+    RPN_WN_LOAD_U(0, 0);
+    RPN_WN_LOAD_U(0, 1);
+    RPN_WN_LOAD_U(0, 2);
+    __syncthreads();
+    __syncthreads();
+    for (int s = 0; s < n_slices; ++s) {
+        const float *V = ldsVR + (s & 1) * kWnVFloats;
+#ifdef RPN_EXP_WN_U0         /* timing experiment (wrong results): every filter request hits slice 0 */
+        const int nxt = 0;
+#else
+        const int nxt = s + 1 < n_slices ? s + 1 : s;                 // (past the end: the last slice again, unused)
+#endif
+        float av[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) av[j] = V[((3 * wave + j) * kW4KS + k4) * kWnNT + l15];
+        // (hipcc mixes the three xi and sinks the requests to the end of the slice, so the next slice starts with s_waitcnt vmcnt(0);
+        // forcing the order with full scheduling barriers measured 2 % SLOWER, with and without staging)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+#ifdef RPN_EXP_WN_HALFMFMA   /* timing experiment (wrong results) */
+            for (int nb = 0; nb < 4; ++nb)
+#else
+            for (int nb = 0; nb < 8; ++nb)
+#endif
+                acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ureg[j][nb >> 2][nb & 3], acc[j][nb], 0, 0, 0);
+            if (j == 0) { RPN_WN_LOAD_U(nxt, 0); } else if (j == 1) { RPN_WN_LOAD_U(nxt, 1); } else { RPN_WN_LOAD_U(nxt, 2); }
+        }
+        __syncthreads();
+    }
+#undef RPN_WN_LOAD_U
+
+    // ---- epilogue: two phases of 64 channels: park [xi 36][tile 16][64 channels] = 144 KB over both arrays, every thread transforms
+    // one (tile, channel) pair; C / D of the 16x16 MFMA: column (channel) = lane & 15, row (tile) = 4 * (lane >> 4) + register
+    float *park = wave < 6 ? ldsA : ldsVR - kHalf;                        // xi = 3 wave + j: waves 0 .. 5 own xi 0 .. 17
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int xi = 3 * wave + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) park[(xi * kWnNT + 4 * k4 + r) * 64 + q * 16 + l15] = acc[j][4 * ph + q][r];
+        }
+        __syncthreads();
+        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
+        __syncthreads();
+    }
+}
 #undef RPN_WINO_LDS_PTR
 
 // Which Winograd form a layer runs on (per model handle, from the grid at its largest batch -- never per call: the forms sum in
@@ -854,7 +1176,12 @@ int wino_variant(int B, int H, int W, int Cin, int Cout)
         return n;
     }();
     if (Cin % kW4KS != 0) return 2;
-    if (knob == 2 || knob == 4 || knob == 8) return knob;
+    if (knob == 2 || knob == 4 || knob == 8 || (knob == 16 && Cout % kWnBN == 0)) return knob;
+#ifndef RPN_EXP_W4_NOWIDE
+    if (Cout % kWnBN == 0 && knob != 1 &&
+        (long long)((W + 15) / 16) * ((H + 15) / 16) * B * (Cout / kWnBN) >= n_cus)
+        return 16;                                       // the wide form: 16 x 16 pixels x 128 channels per workgroup
+#endif
     const long long wgs4 = (long long)((W + 4 * kW4TX - 1) / (4 * kW4TX)) * ((H + 4 * kW4TY - 1) / (4 * kW4TY)) * B * ((Cout + kWinoBN - 1) / kWinoBN);
     if (wgs4 >= n_cus) return 4;
     return 2 * wgs4 >= n_cus && Cin >= 64 && wgs4 <= kW4Tickets ? 8 : 2;       // 8: F(4x4, 3x3), the input channels split over two workgroups per tile
@@ -877,7 +1204,7 @@ size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant)
 hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias, float *out, int B, int H, int W, int Cin,
                                int Cout, int act, bool pool, hipStream_t s, int variant, void *workspace)
 {
-    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8)) return hipErrorInvalidValue;
+    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8 && variant != 16)) return hipErrorInvalidValue;
     if ((long long)H * W * Cin * 4 > 0x7fffffffll) return hipErrorInvalidValue;
     WinoArgs a{};
     a.x = x; a.u = u; a.bias = bias; a.out = out;
@@ -888,6 +1215,14 @@ hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias
         a.ksplit = 2;
         a.tickets = static_cast<unsigned *>(workspace);
         a.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + (size_t)kW4Tickets * 4);
+    }
+    if (variant == 16) {
+        if (Cout % kWnBN != 0) return hipErrorInvalidValue;
+        const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, n_tiles = Cout / kWnBN;
+        const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles;
+        if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(conv3x3_wino4n_f32_kernel, dim3((unsigned)nblocks), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
+        return hipGetLastError();
     }
     if (variant == 4 || variant == 8) {
         const int tiles_x = (W + 4 * kW4TX - 1) / (4 * kW4TX), tiles_y = (H + 4 * kW4TY - 1) / (4 * kW4TY);

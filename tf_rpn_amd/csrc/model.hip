@@ -1174,7 +1174,7 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
         else if (is_pw_x3(m, op))
             snprintf(kname32, sizeof kname32, "pw_f16x3<%d,%d>", op.Cin, op.Cout);
         else if (op.kind == OP_CONV && op.wino)
-            snprintf(kname32, sizeof kname32, op.wino_f == 4 ? "conv3x3_wino4_f32<16x32x64>"
+            snprintf(kname32, sizeof kname32, op.wino_f == 16 ? "conv3x3_wino4_f32<16x16x128>" : op.wino_f == 4 ? "conv3x3_wino4_f32<16x32x64>"
                                               : (op.wino_f == 8 ? "conv3x3_wino4_f32<16x32x64,k2>" : "conv3x3_wino_f32<16x16x64>"));   // (fl above: the direct conv's flops; 4 x / 2.25 x fewer are executed)
         else
         {
