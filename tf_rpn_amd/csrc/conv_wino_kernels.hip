@@ -1001,10 +1001,13 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             r_lds[j] = py * kWnPitch + px;
         }
         const bool second = hid + 256 < kWnPatch * kWnPatch;
-        // transform role (staging threads 0 .. 127): pair = (tile, channel), two threads per pair (output rows 3 part .. 3 part + 2)
-        const bool xf = hid < 128;
-        const int t_part = hid & 1, t_pair = (hid >> 1) & 63;
-        const int t_tile = t_pair & 15, t_c = t_pair >> 4;
+        // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
+        // QUARTER of every pair's 6 x 6 transform -- output rows 3 part .. 3 part + 2, output columns 3 half .. 3 half + 2, part and half
+        // wave-uniform (no divergent halves) -- so that the transform's vector instructions, which take float32-MFMA time, are spread
+        // evenly over the four SIMDs (two waves doing halves loaded two SIMDs with all of it)
+        const int sw = wave - 12;
+        const int t_part = sw & 1, t_half = sw >> 1;
+        const int t_tile = lane & 15, t_c = lane >> 4;
         const int t_ty = t_tile >> 2, t_tx = t_tile & 3;
         // (two register sets, a slice's patch requested two iterations before its transform: see conv3x3_wino4_f32_kernel)
         u32x4_w rr[2][2] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
@@ -1023,7 +1026,6 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             }                                                                                                               \
     }
         auto transform = [&](int buf) {
-            if (!xf) return;
             int ro = 2 * kWnVFloats + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx;
             asm volatile("" : "+v"(ro));
             const float *rp = ldsVR + ro;
@@ -1042,15 +1044,16 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
             }
-            int vo = buf * kWnVFloats + (18 * t_part) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
+            int vo = buf * kWnVFloats + (18 * t_part + 3 * t_half) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
             asm volatile("" : "+v"(vo));
             float *vp = ldsVR + vo;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float v[6];
-                w4_bt6(T[i], v);
+                float v[3];
+                if (t_half == 0) w4_bt3<0>(T[i], v);
+                else w4_bt3<1>(T[i], v);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+                for (int j = 0; j < 3; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
             }
         };
         const int last = n_slices - 1;
