@@ -57,6 +57,7 @@ def bench_name(k):
     if m: return "conv_igemm_f32_dma<128x%d>" % (32 * int(m.group(2)) * int(m.group(4)))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>", k)
     if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")
+    if "conv3x3_wino4n_f32_kernel" in k: return "conv3x3_wino4_f32<16x16x128>"
     if "conv3x3_wino4_f32_kernel" in k: return "conv3x3_wino4_f32<16x32x64>"
     if "conv3x3_wino_f32_kernel" in k: return "conv3x3_wino_f32<16x16x64>"
     return short(k)

@@ -412,7 +412,7 @@ constexpr int kW4Xi = 36;
 constexpr int kW4Tickets = 16384;            // K split (variant 8): tickets at the front of the workspace
 constexpr int kW4TY = 4, kW4TX = 8;         // Winograd tiles per workgroup: 4 x 8 (16 x 32 output pixels)
 constexpr int kW4PatchH = 4 * kW4TY + 2, kW4PatchW = 4 * kW4TX + 2;      // 18 x 34
-constexpr int kW4Pitch = 36, kW4Plane = kW4PatchH * kW4Pitch;            // raw[channel][18][36]
+constexpr int kW4Pitch = 36, kW4Plane = kW4PatchH * kW4Pitch + 26;       // raw[channel][18][36] + 26: the plane stride is 2 (mod 32) floats, a transform wave's two channels fall on different banks
 constexpr int kW4UFloats = kW4Xi * kW4KS * kWinoBN;                     // 9216 floats = 36 KB per slice and N tile
 constexpr int kW4VFloats = kW4Xi * kW4KS * 32;                          // V[xi][k][32 tiles]: 18 KB
 
@@ -613,7 +613,7 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
-    // two arrays of 72 KB.  The slice loop uses ldsVR only: V x 2 (36 KB), raw x 2 (20.25 KB); the epilogue parks the 36 x 32 x 32
+    // two arrays of 72 KB.  The slice loop uses ldsVR only: V x 2 (36 KB), raw x 2 (21 KB); the epilogue parks the 36 x 32 x 32
     // accumulators of a phase (144 KB) over both: xi 0 .. 17 in ldsU, xi 18 .. 35 in ldsVR.  (Two arrays since the filters still came
     // by LDS-DMA into ldsU: hipcc's waitcnt pass lets an LDS access overtake an LDS-DMA in flight only when the two carry the alias
     // scopes of DIFFERENT __shared__ arrays.)
@@ -675,8 +675,11 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             r_lds[j] = py * kW4Pitch + px + ((py >> 2) & 1) * 2;      // rows of odd tile rows skewed by two floats (see transform)
         }
         const bool third = hid + 512 < kW4PatchH * kW4PatchW;
-        // transform role: pair = (tile, channel), two threads per pair (output rows 3 part .. 3 part + 2)
-        const int t_part = hid & 1, t_pair = hid >> 1;
+        // transform role: a lane = one (tile, channel) pair, two WAVES per pair (output rows 3 part .. 3 part + 2)
+        // (the part is wave-uniform: with a lane-dependent part every wave runs both halves of the row transform under exec masks.
+        // Before the staging waves had issue priority this measured SLOWER -- two waves read a pair's patch instead of two lanes
+        // sharing one broadcast read --, with it +0.7 %.)
+        const int t_part = (wave - 12) & 1, t_pair = ((wave - 12) >> 1) * 64 + lane;
         const int t_tile = t_pair & 31, t_c = t_pair >> 5;
         const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
         // TWO register sets for the raw patch: slice t travels in set t & 1, requested TWO iterations before the transform that reads
