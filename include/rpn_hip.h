@@ -71,8 +71,8 @@ typedef enum rpn_backbone { RPN_BACKBONE_VGG16 = 0, RPN_BACKBONE_MOBILENET_V2 = 
  * relative; measured against the 1e-4 parity bound in tests/, never assumed).  F16X3 requires
  * |activation| < 65504.  All other layers stay on the float32 kernels. */
 typedef enum rpn_precision { RPN_PRECISION_F32 = 0, RPN_PRECISION_BF16X3 = 1, RPN_PRECISION_F16X3 = 2,
-                             RPN_PRECISION_F32W = 3 /* float32 Winograd for the 3x3 stride-1 convs -- F(4x4,3x3) where its 16x32-pixel
-                                                       tiles fill the chip, F(2x2,3x3) otherwise, chosen per model handle: float32
+                             RPN_PRECISION_F32W = 3 /* float32 Winograd for the 3x3 stride-1 convs -- F(4x4,3x3) where its tiles
+                                                       fill the chip, F(2x2,3x3) otherwise, chosen per model handle: float32
                                                        operands and accumulation, 1/4 / 1/2.25 of the multiply-adds, another
                                                        summation order (1e-4 contract; measured 3e-6 ... 6e-6 on the heads) */
 } rpn_precision;

@@ -2010,7 +2010,11 @@ struct __attribute__((packed, aligned(4))) F4u {      // float4 at 4-byte alignm
     float x, y, z, w;
 };
 
-template <bool F16, bool OUT_SPLIT, int STRIDE>
+// WCG (Cout <= 64): the channel group is WAVE-uniform (wave w of the block = group w % CG, a lane = a pixel pair), so the 16 weights of
+// a tap are a scalar load (s_load_dwordx16 from `w`, scalar-cache hits) and feed the FMAs as SGPR operands, two channels per
+// v_pk_fma_f32.  With a lane-dependent group every tap cost four 16-byte LDS reads per lane: 4 KB per wave for 32 FMAs -- the LDS
+// pipe, shared by the CU's four SIMDs, was exactly as busy as the vector ALUs, and the layer ran at half its store rate.
+template <bool F16, bool OUT_SPLIT, int STRIDE, bool WCG = false>
 __global__ void __launch_bounds__(256)
 conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27, Cout) */,
                  const float *__restrict__ bias, void *__restrict__ out, int B, int H, int W, int OH, int OW,
@@ -2018,10 +2022,12 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [27][Cout] + bias[Cout], then the stage
     const int CG = Cout >> 4;
-    uint4 *stage = reinterpret_cast<uint4 *>(wl + 28 * Cout);         // [2 * 256 / CG pixels][4 * CG pieces]
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.0f;
-    __syncthreads();
+    uint4 *stage = reinterpret_cast<uint4 *>(WCG ? wl : wl + 28 * Cout);   // [2 * 256 / CG pixels][4 * CG pieces] (WCG: no weights in LDS)
+    if constexpr (!WCG) {
+        for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = w[i];
+        for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.0f;
+        __syncthreads();
+    }
     // index math in 32 bits with ONE division per block (the host checks npairs < 2^31): 64-bit div/mod per
     // thread and per stored piece used to double this kernel's VALU instruction count
     const int PW = (OW + 1) >> 1;                                     // pixel pairs per output row
@@ -2029,8 +2035,9 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     const unsigned pair0 = blockIdx.x * (unsigned)pairs_per_block;
     const unsigned row0 = pair0 / (unsigned)PW;                       // flattened (img, oy) row of the block's first pair
     const int x0 = (int)(pair0 - row0 * (unsigned)PW);
-    const int cg = threadIdx.x % CG;
-    const int pairl = threadIdx.x / CG;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int cg = WCG ? wv % CG : (int)threadIdx.x % CG;
+    const int pairl = WCG ? ((int)threadIdx.x & 63) + 64 * (wv / CG) : (int)threadIdx.x / CG;
     const bool live = pair0 + (unsigned)pairl < (unsigned)npairs;
     int px2 = x0 + pairl;
     unsigned rowf = row0;
@@ -2043,20 +2050,58 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     const int ox = 2 * px2;
     (void)stride;
 
-    float acc[2][16];
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    f2 acc[2][8];                                                     // channel pairs: one v_pk_fma_f32 = two FMAs (same chains, same bits)
 #pragma unroll
-    for (int n = 0; n < 16; ++n) acc[0][n] = acc[1][n] = wl[27 * Cout + cg * 16 + n];
+    for (int n = 0; n < 8; ++n) {
+        if constexpr (WCG) acc[0][n] = bias ? f2{bias[cg * 16 + 2 * n], bias[cg * 16 + 2 * n + 1]} : f2{0.0f, 0.0f};
+        else acc[0][n] = f2{wl[27 * Cout + cg * 16 + 2 * n], wl[27 * Cout + cg * 16 + 2 * n + 1]};
+        acc[1][n] = acc[0][n];
+    }
     if (live) {
         // per filter row: the 2 output pixels read (STRIDE + 3) consecutive input pixels = 12 or 15 contiguous
         // floats; interior threads fetch them as 4 wide loads, border threads element by element with zero fill
         const float *ximg = x + (size_t)img * H * W * 3;
         const int c0 = ox * STRIDE - pad_l;                              // first input column of the window
-#pragma unroll 1
-        for (int r = 0; r < 3; ++r) {                                    // rolled: keeps registers low
+        // WCG: the three rows' windows are requested together (one memory latency per thread instead of three; the rolled loop's
+        // registers are not what limits residency there -- the staging LDS is)
+        float win3[WCG ? 3 : 1][16];
+        if constexpr (WCG) {
+            const int iy0 = oy * STRIDE - pad_t;
+            if (iy0 >= 0 && iy0 + 2 < H && c0 >= 0 && c0 * 3 + 16 <= W * 3) {      // ONE decision for the three rows: twelve loads in flight
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const F4u *src = reinterpret_cast<const F4u *>(ximg + ((size_t)(iy0 + r) * W + c0) * 3);
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4) {
+                        const F4u v = src[v4];
+                        win3[r][4 * v4] = v.x; win3[r][4 * v4 + 1] = v.y; win3[r][4 * v4 + 2] = v.z; win3[r][4 * v4 + 3] = v.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int iy = iy0 + r;
+                    const bool row_ok = iy >= 0 && iy < H;
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) {
+                        const int col = c0 + j / 3;
+                        const bool v = row_ok && col >= 0 && col < W && j < 3 * (STRIDE + 3);
+                        win3[r][j] = v ? ximg[((size_t)iy * W + col) * 3 + j % 3] : 0.0f;
+                    }
+                    win3[r][15] = 0.0f;
+                }
+            }
+        }
+#pragma unroll(WCG ? 3 : 1)
+        for (int r = 0; r < 3; ++r) {                                    // (!WCG) rolled: keeps registers low
             const int iy = oy * STRIDE + r - pad_t;
             const bool row_ok = iy >= 0 && iy < H;
             float win[16];
-            if (row_ok && c0 >= 0 && c0 * 3 + 16 <= W * 3) {
+            if constexpr (WCG) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) win[j] = win3[r][j];
+            } else if (row_ok && c0 >= 0 && c0 * 3 + 16 <= W * 3) {
                 const F4u *src = reinterpret_cast<const F4u *>(ximg + ((size_t)iy * W + c0) * 3);
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
@@ -2074,15 +2119,17 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
             }
 #pragma unroll
             for (int sc = 0; sc < 9; ++sc) {                             // (tap column s, channel c) = (sc / 3, sc % 3)
-                const float4 *wk = reinterpret_cast<const float4 *>(&wl[(r * 9 + sc) * Cout + cg * 16]);
+                const float4 *wk = WCG ? reinterpret_cast<const float4 *>(w + (r * 9 + sc) * Cout + cg * 16)      // (uniform: scalar loads)
+                                       : reinterpret_cast<const float4 *>(&wl[(r * 9 + sc) * Cout + cg * 16]);
                 const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
-                const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                const f2 ws[8] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w},
+                                  {w2.x, w2.y}, {w2.z, w2.w}, {w3.x, w3.y}, {w3.z, w3.w}};
                 const float in0 = win[sc], in1 = win[sc + 3 * STRIDE];    // pixel p reads column p*STRIDE + s
+                const f2 i0 = {in0, in0}, i1 = {in1, in1};
 #pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    acc[0][n] = fmaf(in0, ws[n], acc[0][n]);
-                    acc[1][n] = fmaf(in1, ws[n], acc[1][n]);
+                for (int n = 0; n < 8; ++n) {
+                    acc[0][n] = __builtin_elementwise_fma(i0, ws[n], acc[0][n]);
+                    acc[1][n] = __builtin_elementwise_fma(i1, ws[n], acc[1][n]);
                 }
             }
         }
@@ -2095,7 +2142,7 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     for (int p = 0; p < 2; ++p) {
         float v[16];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) v[n] = fminf(fmaxf(acc[p][n], act_lo), act_hi);
+        for (int n = 0; n < 16; ++n) v[n] = fminf(fmaxf(acc[p][n >> 1][n & 1], act_lo), act_hi);
         uint4 *dst = stage + ((2 * pairl + p) * CG + cg) * 4;
         if constexpr (OUT_SPLIT) {
             const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
@@ -2143,10 +2190,17 @@ hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, v
     if (threads <= 0) return hipSuccess;
     if (npairs >= 0x7fffffffll || threads / 256 >= 0x7fffffffll) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((threads + 255) / 256);
-    const size_t lds = (size_t)28 * Cout * sizeof(float) + (size_t)2048 * 16;   // weights + bias + staged records
+    const bool wcg = Cout <= 64 && 4 % (Cout / 16) == 0;            // 1, 2 or 4 channel groups: one per wave (conv_cin3_kernel)
+    const size_t lds = (wcg ? 0 : (size_t)28 * Cout * sizeof(float)) + (size_t)2048 * 16;   // (weights + bias) + staged records
 #define RPN_CIN3(F16_, SPLIT_, STRIDE_)                                                                       \
-    hipLaunchKernelGGL((conv_cin3_kernel<F16_, SPLIT_, STRIDE_>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, \
-                       H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs, range_status())
+    do {                                                                                                      \
+        if (wcg)                                                                                              \
+            hipLaunchKernelGGL((conv_cin3_kernel<F16_, SPLIT_, STRIDE_, true>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, \
+                               H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs, range_status());         \
+        else                                                                                                  \
+            hipLaunchKernelGGL((conv_cin3_kernel<F16_, SPLIT_, STRIDE_, false>), dim3(grid), dim3(256), lds, s, x, w, bias, out, B, \
+                               H, W, OH, OW, Cout, stride, pad_t, pad_l, act, npairs, range_status());         \
+    } while (0)
     if (stride != 1 && stride != 2) return hipErrorInvalidValue;
     if (out_fmt == 0) {
         if (stride == 1) RPN_CIN3(false, false, 1); else RPN_CIN3(false, false, 2);
