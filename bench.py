@@ -541,7 +541,7 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     timed over `steps` steps in this same run, with the dominant kernel's fraction of the 157.3 TFLOP/s f32-MFMA peak from
     a per-op event pass.  `heads` = the headline path's (reg, cls) head outputs for the same images: their largest
     absolute difference from this path's is returned as `max_abs_diff_vs_headline` (the bench line's self-check).
-    precision="f32w" (the `f32_winograd` leg): the 3x3 convs as float32 Winograd F(2x2, 3x3) on the same float32 MFMA (float32
+    precision="f32w" (the `f32_winograd` leg): the 3x3 convs as float32 Winograd F(4x4, 3x3) / F(2x2, 3x3) on the same float32 MFMA (float32
     operands and accumulation, 2.25 x -- F(4x4,3x3): 4 x -- fewer multiply-adds, another summation order: a precision of its own, never
     the parity-clean `exact_f32` row).  Its `roofline.achieved` prices the multiply-adds the kernel EXECUTES (`winograd_reduction`)
     against the 157.3 TFLOP/s peak; `effective_tflops` is the direct conv's flops over the same time.  `keep_heads`: a list that
@@ -598,9 +598,10 @@ def exact_f32_leg(backbone, hp, weights, B, iou_threshold, imgs, steps=30, warmu
     if precision == "f32w":
         out["max_abs_diff_vs_exact_f32"] = out.pop("max_abs_diff_vs_headline")
         out["roofline"]["effective_tflops"] = round(tot[dom][3] / (tot[dom][0] * 1e-3) / 1e12, 3)
-        out["note"] = ("3x3 convs as float32 Winograd on the f32 MFMA -- F(4x4,3x3) where its 16x32 tiles fill the chip (1/4 of the direct "
-                       "conv's multiply-adds), F(2x2,3x3) on the 31x31 layers (1/2.25): float32 operands and accumulation, another "
-                       "summation order -- not the parity-clean `exact_f32` row")
+        out["note"] = ("3x3 convs as float32 Winograd on the f32 MFMA -- F(4x4,3x3) (1/4 of the direct conv's multiply-adds; per layer "
+                       "on 16x16-pixel x 128-channel or 16x32 x 64 tiles, the 31x31 layers with their input channels split over two "
+                       "workgroups), F(2x2,3x3) (1/2.25) on small grids: float32 operands and accumulation, another summation "
+                       "order -- not the parity-clean `exact_f32` row")
     return out
 
 
