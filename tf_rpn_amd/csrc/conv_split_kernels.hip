@@ -2143,19 +2143,22 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
         float v[16];
 #pragma unroll
         for (int n = 0; n < 16; ++n) v[n] = fminf(fmaxf(acc[p][n >> 1][n & 1], act_lo), act_hi);
-        uint4 *dst = stage + ((2 * pairl + p) * CG + cg) * 4;
+        // WCG: a wave's lanes are pixel PAIRS, 2 * ppp pieces = a multiple of 512 bytes apart -- every lane of a store on the same
+        // four banks; the piece index inside a pixel is XOR-swizzled by the pair index (undone by the block-linear reader below)
+        uint4 *dst = stage + (2 * pairl + p) * (4 * CG);
+        const int q0 = 4 * cg, sw = WCG ? (pairl & (4 * CG - 1) & 7) : 0;
         if constexpr (OUT_SPLIT) {
             const float lo8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
             const float hi8[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
-            dst[0] = split_piece<F16>(lo8, false, status);
-            dst[1] = split_piece<F16>(lo8, true);
-            dst[2] = split_piece<F16>(hi8, false, status);
-            dst[3] = split_piece<F16>(hi8, true);
+            dst[(q0 + 0) ^ sw] = split_piece<F16>(lo8, false, status);
+            dst[(q0 + 1) ^ sw] = split_piece<F16>(lo8, true);
+            dst[(q0 + 2) ^ sw] = split_piece<F16>(hi8, false, status);
+            dst[(q0 + 3) ^ sw] = split_piece<F16>(hi8, true);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                dst[k] = make_uint4(__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]),
-                                    __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3]));
+                dst[(q0 + k) ^ sw] = make_uint4(__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]),
+                                                __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3]));
         }
     }
     __syncthreads();
@@ -2175,7 +2178,7 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
         }
         const int gox = 2 * gx2 + (pl & 1);
         if (gox >= OW) continue;
-        gout[((size_t)grow * OW + gox) * ppp + q] = stage[e];
+        gout[((size_t)grow * OW + gox) * ppp + q] = stage[WCG ? pl * ppp + (q ^ ((pl >> 1) & (ppp - 1) & 7)) : e];
     }
 }
 
