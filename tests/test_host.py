@@ -77,7 +77,7 @@ KERNEL_BUDGETS = {
     r"conv3x3_split16_dma_kernel<(false|true),(false|true),64,false>": (176, 40, 113664),
     r"conv3x3_split16_dma_kernel<(false|true),false,64,true>": (216, 72, 113664),            # K-tree fold: two more accumulator sets
     r"conv3x3_split16_kernel<8,2,8,": (240, 0, 136448),
-    r"nms_kernel<(false|true)>": (128, 100, 0),                          # 1024 threads = 4 waves per SIMD (dynamic LDS)
+    r"nms_kernel<(false|true)>": (128, 104, 0),                          # 1024 threads = 4 waves per SIMD (dynamic LDS); SGPR spills go to VGPR lanes
     r"stem_block_kernel<8>": (96, 0, 27648),                             # five workgroups per CU
     r"stem_block_kernel<4>": (80, 0, 16128),
     r"ir_block_hrx3_kernel<16,96,32,24,2,false,1,1>": (112, 0, 27136),   # MobileNetV2 block 1 at batch 8: four per CU

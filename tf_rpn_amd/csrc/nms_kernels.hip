@@ -78,7 +78,10 @@ constexpr int kNmsThreads = 1024;
 constexpr int kBandCap = 4096;         // candidates sorted per band (LDS: 32 KB of keys)
 constexpr int kBandTarget = 3072;      // the radix select aims at this many, accepts up to kBandCap
 constexpr int kBins = kRsHistWords;    // radix-select histogram words (radix_select.h)
-constexpr int kChunk = 256;
+#ifndef RPN_NMS_CHUNK
+#define RPN_NMS_CHUNK 256
+#endif
+constexpr int kChunk = RPN_NMS_CHUNK;
 constexpr int kChunkWords = kChunk / 64;
 // Chunk boxes are stored at slot(j) = (j % 16) * 16 + j / 16: the threads that build one suppression row read 16
 // candidates 16 apart (j = 16 * piece + jj, piece = lane % 16) -- consecutive slots, conflict-free; in natural order
@@ -134,6 +137,12 @@ struct NmsArgs {
                              // 97.6 us with 5 x); the cluster path always takes 3 x
     int prune;
     float prune_lo, prune_hi;   // a pair can only pass the IoU test if area_a * prune_lo <= area_b <= area_a * prune_hi
+    // chunk compaction (round 5): step (A) for the WHOLE chunk first, the survivors moved to the front of the chunk, the group
+    // loop (B1 / walk / B2) over the survivors only.  With a low threshold nine candidates in ten die in (A): one group per chunk
+    // instead of four (two barrier intervals each).  configs[2], IoU 0.5: 126 -> 102 us, 0.7: 36.0 -> 34.5; on the bench model's
+    // head outputs 0.5: 393 -> 300 us, 0.7: 76 -> 66 (smooth-score "model-like" inputs at 0.7: 40.1 -> 42.0, the one loss).
+    // 512-candidate chunks with it: slower (0.7: 41 us, 0.5: 112 us).
+    int compact;             // 0: off; n: for chunks that start with at least n boxes selected
 };
 
 // ---- area pruning ------------------------------------------------------------------------------------------------
@@ -752,6 +761,7 @@ nms_kernel(NmsArgs p)
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem + L.mask);
     unsigned long long *deadw = reinterpret_cast<unsigned long long *>(smem + L.dead);
     int *ctl = reinterpret_cast<int *>(smem + L.ctl);
+    int *cidx = reinterpret_cast<int *>(smem + L.picked);                    // compact mode: survivor -> its place in the chunk
     float4 *srt_c4 = reinterpret_cast<float4 *>(smem + L.srt);               // (p.prune only)
     float *srt_a = reinterpret_cast<float *>(smem + L.srt + align16((size_t)16 * (p.max_sel + 32)));
     int *pcnt = reinterpret_cast<int *>(smem + L.pbin), *pstart = pcnt + kPruneBins, *pcur = pstart + kPruneBins + 1;
@@ -1003,6 +1013,101 @@ nms_kernel(NmsArgs p)
             NMS_STAMP(5);
             NMS_STOP_AT(4);
 
+            // ---- compact mode: (A) for the whole chunk, then the survivors to the front -----------------------------------
+            int Tg = T;                                  // candidates the group loop walks (compact: the survivors)
+            const bool compacted = p.compact > 0 && nsel >= p.compact;
+            if (compacted) {
+                {   // thread (candidate = tid / P, part = tid % P), P = threads per candidate (4; 2 with 512-candidate chunks), tests
+                    // selected boxes part, part + P, ... (the list is padded to a multiple of 32 with boxes that suppress nothing);
+                    // the tests are those of the per-group step (A) below
+                    constexpr int P = kNmsThreads / kChunk, CPW = 64 / P;          // candidates per wave
+                    const int tid = fresh_tid(), lane = tid & 63;
+                    const int t = tid / P, part = tid % P;
+                    bool hit = false;
+                    if (t < T) {
+                        const int st = cslot(t);
+                        const float4 c4 = cbox4[st];
+                        const CBox ci{c4.x, c4.y, c4.z, c4.w, carea[st]};
+                        int run0 = 0, run_n = nsel;
+                        if (p.prune) {
+                            run0 = pstart[prune_bin(ci.area * p.prune_lo)];
+                            run_n = pstart[prune_bin(ci.area * p.prune_hi) + 1] - run0;
+                        }
+                        const float4 *sp = (p.prune ? srt_c4 : sel_c4) + run0 + part;
+                        const float *ap = (p.prune ? srt_a : sel_a) + run0 + part;
+                        float ha = -INFINITY, hb = -INFINITY, ma = p.m0, mb = p.m0;
+                        for (int j0 = 0; j0 < run_n; j0 += 2 * P) {
+                            const float4 a4 = sp[j0], b4 = sp[j0 + P];
+                            const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j0]}, sb{b4.x, b4.y, b4.z, b4.w, ap[j0 + P]};
+                            ha = vmax_vv(ha, nms_excess(ci, sa, p.iou_thr, p.iou_eps, ma));
+                            hb = vmax_vv(hb, nms_excess(ci, sb, p.iou_thr, p.iou_eps, mb));
+                        }
+                        hit = vmax_vv(ha, hb) > 0.0f;
+                        if (!(vmin_vv(ma, mb) > 1e-30f)) {
+                            hit = false;
+                            for (int j = 0; j < ((run_n + 2 * P - 1) & ~(2 * P - 1)); j += P) {
+                                const float4 a4 = sp[j];
+                                const CBox sa{a4.x, a4.y, a4.z, a4.w, ap[j]};
+                                hit |= nms_suppresses(ci, sa, p.iou_thr, p.iou_lo, p.iou_hi);
+                            }
+                        }
+                    }
+                    // lanes P q .. P q + P - 1 of a wave belong to candidate CPW * wave + q
+                    const unsigned long long bal = __ballot(hit);
+                    if (lane == 0 && bal) {
+                        unsigned long long bits = 0ull;
+#pragma unroll
+                        for (int q = 0; q < CPW; ++q)
+                            if ((bal >> (P * q)) & ((1ull << P) - 1ull)) bits |= 1ull << q;
+                        const int c0 = (tid >> 6) * CPW;                           // the wave's first candidate
+                        atomicOr(&deadw[c0 >> 6], bits << (c0 & 63));
+                    }
+                }
+                __syncthreads();
+                NMS_STAMP(44);
+                // survivors keep their order: rank = live candidates in front
+                float4 my4 = float4{0.f, 0.f, 0.f, 0.f};
+                float my_a = 0.0f;
+                int my_rank = -1, n_live = 0;
+                {
+                    const int tid = fresh_tid();
+                    unsigned long long live[kChunkWords];
+#pragma unroll
+                    for (int w = 0; w < kChunkWords; ++w) {
+                        live[w] = ~deadw[w];
+                        n_live += __popcll(live[w]);
+                    }
+                    if (tid < kChunk) {
+                        const int w = tid >> 6, bit = tid & 63;
+                        if ((live[w] >> bit) & 1ull) {
+                            int r = __popcll(live[w] & ((1ull << bit) - 1ull));
+#pragma unroll
+                            for (int v = 0; v < kChunkWords; ++v)
+                                if (v < w) r += __popcll(live[v]);
+                            my_rank = r;
+                            my4 = cbox4[cslot(tid)];
+                            my_a = carea[cslot(tid)];
+                        }
+                    }
+                }
+                __syncthreads();                         // every survivor holds its box: the slots may be rewritten
+                {
+                    const int tid = fresh_tid();
+                    if (my_rank >= 0) {
+                        cbox4[cslot(my_rank)] = my4;
+                        carea[cslot(my_rank)] = my_a;
+                        cidx[my_rank] = tid;
+                    }
+                    if (tid < kChunkWords) {             // the group loop's dead words: only the slots past the survivors
+                        const int lo = tid * 64;
+                        deadw[tid] = n_live <= lo ? ~0ull : (n_live >= lo + 64 ? 0ull : (~0ull << (n_live - lo)));
+                    }
+                }
+                Tg = n_live;
+                __syncthreads();
+                NMS_STAMP(45);
+            }
+
             // The chunk is walked in 4 groups of 64 candidates (one 64-bit word of the live mask).  Per group:
             // (B) all 16 waves build the suppression rows of the group's LIVE candidates against the live candidates after
             //     them: thread (i = tid / 16, piece = tid % 16) produces 16 bits of row i.  Rows of later groups are only
@@ -1013,14 +1118,14 @@ nms_kernel(NmsArgs p)
             //     Selected lanes then OR the rest of their rows into the dead words of the later groups and append
             //     themselves to the selected list at position nsel + (rank among the group's selected).
             int cur = nsel;                                          // uniform: re-read from LDS after every group
-            for (int gw = 0; gw < kChunkWords && gw * 64 < T && cur < max_sel; ++gw) {
+            for (int gw = 0; gw < kChunkWords && gw * 64 < Tg && cur < max_sel; ++gw) {
                 // (A) the group's candidates against the boxes selected in EARLIER chunks (this chunk's selections reach
                 //     later groups through the row ORs below): thread (candidate = tid / 16, part = tid % 16) tests selected
                 //     boxes part, part + 16, ... (LDS broadcast within a part).  Done per group, so a chunk that completes
                 //     the output after one group tests 64 x nsel pairs, not 256 x nsel.  (Round 5: batches of several groups per
                 //     interval measured SLOWER -- 124 -> 132 us at configs[2], IoU 0.5 -- although thread 0's own step (A) took
                 //     6.8 k cycles for four groups against 4 x 3.5 k: the interval [B2, A, B1] overlaps its pieces well as it is.)
-                if (nsel > 0) {
+                if (nsel > 0 && !compacted) {
                     const int tid = fresh_tid(), lane = tid & 63;
                     const int il = tid >> 4, part = tid & 15;
                     const int t = gw * 64 + il;
@@ -1159,7 +1264,7 @@ nms_kernel(NmsArgs p)
                         const float4 b4 = cbox4[cslot(i)];
                         sel_c4[slot] = b4;
                         sel_a[slot] = carea[cslot(i)];
-                        sel_idx[slot] = (int)order[pos + i];
+                        sel_idx[slot] = (int)order[pos + (compacted ? cidx[i] : i)];
                     }
                     if (lane == 0) ctl[CTL_NSEL] = c2;
                     NMS_STAMP(8);
@@ -1183,7 +1288,7 @@ nms_kernel(NmsArgs p)
                         const int pi = item % npl, rest = item / npl;       // the piece varies fastest: conflict-free reads
                         const int part = rest & ((1 << fsh) - 1), sl = cur + (rest >> fsh);
                         const int piece = 4 * (gw + 1) + pi, jj0 = part * per;
-                        if (piece * 16 + jj0 >= T) continue;                // past the band end: dead already
+                        if (piece * 16 + jj0 >= Tg) continue;               // past the band end / the survivors: dead already
                         const float4 s4 = sel_c4[sl];
                         const CBox si{s4.x, s4.y, s4.z, s4.w, sel_a[sl]};
                         unsigned bits = 0u;
@@ -1410,6 +1515,10 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
     // area pruning: a threshold in [0.3, 1) (a candidate's run of area bins is then at most 18 of the 64) on the fast test path
     static const int prune = RPN_KNOB("RPN_NMS_PRUNE", 1);
     p.prune = prune && fast && p.iou_thr >= 0.3f && p.iou_thr < 1.0f && lds_layout(p.max_sel, 0, 1).total <= kLdsLimit;
+    {
+        static const int compact = RPN_LAB_KNOB("RPN_NMS_COMPACT", 1);     // (A/B timing: 0 = never, n = chunks that start with >= n selected)
+        p.compact = compact;
+    }
     if (p.prune) {
         p.prune_lo = p.iou_thr * (1.0f - 0x1p-19f);
         p.prune_hi = 1.0f / p.prune_lo * (1.0f + 0x1p-22f);        // (the quotient's own rounding is 2^-24)
