@@ -1508,8 +1508,12 @@ static int launch_nms(NmsArgs &p, void *d_workspace, size_t workspace_bytes, hip
         p.cluster = 1;
     // first band: 5 x the boxes wanted, 3 x on a saturated head (NmsArgs::band1_mult / band1_sat)
     {
-        static const int b1 = RPN_LAB_KNOB("RPN_NMS_BAND1", 5), bs = RPN_LAB_KNOB("RPN_NMS_BAND1SAT", 3);    // (A/B timing)
-        p.band1_mult = b1 > 0 ? b1 : 5;
+        static const int b1 = RPN_LAB_KNOB("RPN_NMS_BAND1", 0), bs = RPN_LAB_KNOB("RPN_NMS_BAND1SAT", 3);    // (A/B timing; 0 = automatic)
+        // automatic: 6 x below a threshold of 0.6 -- a low threshold visits more candidates per selected box, and with the chunk
+        // compaction (cheap later chunks) a first band that ends the walk is worth its larger ordering pass: configs[2] at IoU 0.5
+        // 102.5 -> 92.8 us (the band is capped at 1 792 candidates: 8 x is the same; a cap of 2 048: 89.4 but the bench model's head
+        // outputs 305 -> 347), the bench model's head outputs 298.8 -> 305.7, smooth-score inputs 126.6 -> 131.1; at 0.7 no gain: left at 5 x
+        p.band1_mult = b1 > 0 ? b1 : (p.iou_thr < 0.6f ? 6 : 5);
         p.band1_sat = bs;
     }
     // area pruning: a threshold in [0.3, 1) (a candidate's run of area bins is then at most 18 of the 64) on the fast test path
