@@ -150,6 +150,8 @@ def parse_args():
                          "second HIP stream; every step's work still completes inside the timed region)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise a world-size-1 RCCL group and run the N > 1 code path (record packing + all-gather)")
+    ap.add_argument("--no-dist-legs", action="store_true",
+                    help="N > 1 (or --force-dist) line: skip the `multi_gpu_configs` legs (configs[3] / configs[4] sharded + all-gathered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the configs[2] box-path leg (`c3`) and the exact-float32 leg (`exact_f32`) of the N = 1 line")
@@ -483,10 +485,14 @@ def cpu_baseline(backbone, hyper_params, weights, iou_threshold, target_seconds,
     for w in workers.values():
         w.close()
     blob.close()
-    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images of the same workload, %d per call (torch-CPU f32 conv stack with %d threads + plain-C "
-                      "decode/NMS(300), single thread; %s), %.1f s" % (n, nb, cores, where, dt),
-            "cpu": _cpu_model_name(), "logical_cpus": logical, "usable_cpus": usable, "cgroup_cpu_quota": _cpu_quota(),
+    # `cores`: the CPUs this process can actually use = min(threads, cgroup quota) -- the GPU boxes grant 16 CPUs of time while 256
+    # logical CPUs are visible, and the fastest configuration found runs MORE threads than that (`threads`)
+    quota = _cpu_quota()
+    granted = cores if not quota else max(1, min(cores, int(round(quota))))
+    return {"value": n / dt, "unit": "images/s", "cores": granted, "threads": cores, "kind": "port",
+            "sample": "%d images of the same workload, %d per call (torch-CPU f32 conv stack with %d threads on %d granted CPUs + "
+                      "plain-C decode/NMS(300), single thread; %s), %.1f s" % (n, nb, cores, granted, where, dt),
+            "cpu": _cpu_model_name(), "logical_cpus": logical, "usable_cpus": usable, "cgroup_cpu_quota": quota,
             "variants": variants, "leg_seconds": round(time.perf_counter() - t_leg, 1)}
 
 
@@ -690,6 +696,87 @@ def config_leg(label, backbone, hp, B, precision, iou_threshold, steps=10, warmu
     return out
 
 
+def dist_config_leg(label, backbone, hp, B, precision, iou_threshold, world, rank, steps=30, warmup=3):
+    """One of BASELINE.json's 8-GPU configs (configs[3]: VGG16, 32 images per GPU; configs[4]: MobileNetV2 1024x1024, 15
+    anchors per cell, ONE image per GPU) through the sharded path the N > 1 line is about: every rank proposes for its own
+    images (`Proposer.propose_distributed_pipelined`: convs on the current stream; decode + NMS, record packing and the ONE
+    RCCL all-gather of 6 KB records on the side stream, beside the convs of the next step), `steps` timed steps bracketed by
+    barrier + synchronize on both sides, MAX over ranks.  Called by EVERY rank (collectives inside); rank 0 gets the dict.
+    With `--force-dist` on one GPU the group has one rank: the same code path, the all-gather included.
+    (The reference has no counterpart: one process, /root/reference/utils/io_utils.py:52-59.)"""
+    import torch
+    import torch.distributed as dist
+
+    from tf_rpn_amd.models._rpn_model import synthetic_weights
+    from tf_rpn_amd.predictor import Proposer
+    weights = synthetic_weights(backbone, hp, seed=1)
+    prop = Proposer(backbone, hyper_params=hp, weights=weights, precision=precision, max_batch=B,
+                    iou_threshold=iou_threshold, overlap_nms=True)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1000 + rank)
+    imgs = torch.rand((B, hp["img_size"], hp["img_size"], 3), generator=gen, device="cuda", dtype=torch.float32)
+    M = prop.topn
+    gather_bufs = [torch.empty((world * B, M * 5 + 1), dtype=torch.float32, device="cuda") for _ in range(2)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 2)):
+        prop.propose_distributed_pipelined(imgs, gather_bufs)
+    prop.flush_distributed(gather_bufs)
+    torch.cuda.synchronize()
+    side_ok = prop.ensure_side_stream()           # the communicator's streams exist: still beside the conv stream?
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prop.propose_distributed_pipelined(imgs, gather_bufs)
+    gathered = prop.flush_distributed(gather_bufs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # the gathered records of the last step: every rank's valid counts, boxes and scores, as every rank received them
+    g_boxes, g_scores, g_valid = Proposer.unpack_records(gathered[:world * B], M)
+    valid_min = int(g_valid.min().item())
+    finite = bool(torch.isfinite(g_boxes).all().item() and torch.isfinite(g_scores).all().item())
+    # rank r's rows must be rank r's own proposals: compare this rank's slice with its local outputs
+    own = gathered[rank * B:(rank + 1) * B]
+    mine = prop.pack_records(prop._last["boxes"][:B], prop._last["scores"][:B], prop._last["valid"][:B])
+    own_rows_match = bool(torch.equal(own.view(torch.int32), mine.view(torch.int32)))
+    f16_range = bool(prop.rpn_model.status(reset=False)["f16_range"]) if precision == "f16x3" else False
+    # the all-gather alone, after the region
+    rec = prop.pack_records(prop._last["boxes"][:B], prop._last["scores"][:B], prop._last["valid"][:B])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dist.all_gather_into_tensor(gather_bufs[0], rec)
+    e1.record()
+    torch.cuda.synchronize()
+    gather_ms = e0.elapsed_time(e1) / 10
+    mine_t = torch.tensor([elapsed, gather_ms, 1.0 if (f16_range or valid_min < 1 or not finite or not own_rows_match) else 0.0],
+                          dtype=torch.float64, device="cuda")
+    allr = [torch.zeros_like(mine_t) for _ in range(world)]
+    dist.all_gather(allr, mine_t)
+    t_max = max(float(v[0].item()) for v in allr)
+    n_launches = sum(op["launches"] for op in prop.rpn_model.ops())
+    del prop, gather_bufs, imgs
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {"workload": "%s: %s, %dx%d, %d anchors/cell, batch %d per GPU x %d GPU(s), image-sharded + one RCCL all-gather of "
+                        "proposal records" % (label, backbone, hp["img_size"], hp["img_size"], hp["anchor_count"], B, world),
+            "value": round(world * B * steps / t_max, 2), "unit": "images/s", "images_per_s": round(world * B * steps / t_max, 2),
+            "ms_per_step": round(1e3 * t_max / steps, 4), "steps": steps, "n_gpus": world, "global_batch": world * B,
+            "dtype": precision, "allgather_ms": round(gather_ms, 4), "record_bytes_per_rank": B * (M * 5 + 1) * 4,
+            "rccl_ranks": dist.get_world_size(), "nms_stream_concurrent": side_ok, "conv_launches_per_step": n_launches,
+            "per_rank": {"images_per_s": [round(B * steps / float(v[0].item()), 2) for v in allr],
+                         "allgather_ms": [round(float(v[1].item()), 4) for v in allr]},
+            "checks": {"f16_range": f16_range, "valid_min": valid_min, "proposals_finite": finite,
+                       "own_rows_match": own_rows_match, "any_rank_failed": any(float(v[2].item()) > 0 for v in allr)}}
+
+
 def c3_leg(hp, n=30):
     """BASELINE.json configs[2]: batch 64, box path only (no backbone) -- the metric's "NMS boxes/sec".  Inputs as
     SURVEY.md 8(d): deltas ~ N(0,1) (x variances inside the kernel), scores = a seeded permutation of (i + 0.5) / A per
@@ -739,7 +826,33 @@ def c3_leg(hp, n=30):
     t = timed(lambda: L.check(lib.rpn_decode(L.ptr(anchors), 0, L.ptr(deltas), vptr, B, A, L.ptr(boxes), L.stream_ptr()),
                               "rpn_decode"), n)
     by = 32.0 * B * A + 16.0 * A
-    out["decode"] = {"us": round(t * 1e6, 2), "GBps": round(by / t / 1e9, 1), "frac": round(by / t / 8e12, 4), "bytes": by}
+    # (`us` is launch-to-launch time over back-to-back launches on ONE stream: for this 18 MB kernel that is the ~2-3 us boundary
+    # between dependent launches + the kernel (rocprofv3 reads 4.8 us of kernel, profiles/r05_c3_kernel_stats.csv); `kernel_us`
+    # below times the same launches spread over four streams, where the boundaries overlap)
+    out["decode"] = {"us": round(t * 1e6, 2), "GBps": round(by / t / 1e9, 1), "frac": round(by / t / 8e12, 4), "bytes": by,
+                     "timing": "launch-bound: events around n back-to-back launches on one stream (kernel + launch boundary)"}
+    # kernel-only duration: n launches spread round-robin over 4 streams (no dependence between consecutive launches, so the
+    # boundaries overlap and the device is bounded by the kernels themselves)
+    streams4 = [torch.cuda.Stream() for _ in range(4)]
+    outs4 = [torch.empty_like(boxes) for _ in range(4)]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cur = torch.cuda.current_stream()
+    e0.record(cur)
+    for st in streams4:
+        st.wait_event(e0)
+    reps4 = 4 * max(8, n // 2)
+    for i in range(reps4):
+        with torch.cuda.stream(streams4[i % 4]):
+            L.check(lib.rpn_decode(L.ptr(anchors), 0, L.ptr(deltas), vptr, B, A, L.ptr(outs4[i % 4]), L.stream_ptr()), "rpn_decode")
+    for st in streams4:
+        cur.wait_stream(st)
+    e1.record(cur)
+    torch.cuda.synchronize()
+    tk = e0.elapsed_time(e1) / reps4 * 1e-3
+    out["decode"].update({"kernel_us": round(tk * 1e6, 2), "kernel_GBps": round(by / tk / 1e9, 1), "kernel_frac": round(by / tk / 8e12, 4),
+                          "kernel_timing": "%d launches round-robin over 4 streams (independent launches: boundaries overlap), events around all" % reps4})
+    del streams4, outs4
     t = timed(lambda: L.check(lib.rpn_iou_map(L.ptr(anchors), 0, A, L.ptr(gt), B, G, L.ptr(iou), L.stream_ptr()),
                               "rpn_iou_map"), n)
     by = 4.0 * B * A * G + 16.0 * (A + B * G)
@@ -1005,6 +1118,18 @@ def main():
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         checks["any_rank_failed"] = bool(bad.item() > 0)
 
+    # ---- BASELINE.json's own 8-GPU configs through the sharded + all-gathered path (every rank takes part) ----------------
+    dist_legs = None
+    if use_dist and not args.no_dist_legs and args.config == "c2" and args.backbone == "vgg16" and B == 8:
+        hp_c5 = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                                  anchor_ratios=[1., 2., 1. / 2., 3., 1. / 3.]))
+        dist_legs = {
+            "c4": dist_config_leg("configs[3] (batch %d on %d GPUs; 256 on 8)" % (32 * world, world), "vgg16", hp, 32, args.precision,
+                                  args.iou_threshold, world, rank, steps=30, warmup=3),
+            "c5": dist_config_leg("configs[4] (batch %d on %d GPUs; 8 on 8)" % (world, world), "mobilenet_v2", hp_c5, 1,
+                                  args.precision, args.iou_threshold, world, rank, steps=400, warmup=10),
+        }
+
     exit_code = 0
     if rank == 0:
         # dominant kernel: the conv instantiation with the largest total time
@@ -1063,6 +1188,8 @@ def main():
             "checks": checks,
             "roofline": roofline,
         }
+        if dist_legs is not None:
+            out["multi_gpu_configs"] = dist_legs
         cpu_workers = None
         if world == 1 and not args.no_cpu_baseline:
             # (start-up of the CPU workers overlaps the GPU legs below; they never touch the GPU)
@@ -1124,6 +1251,8 @@ def main():
         legs_bad = [k for k, v in out.get("other_configs", {}).items()
                     for c in [v["checks"]] + [w["checks"] for n, w in v.items() if n.startswith("pipelines_in_flight_")]
                     if c["f16_range"] or c["valid_min"] < 1]
+        legs_bad += [k + "_dist" for k, v in (dist_legs or {}).items()
+                     if v["checks"]["any_rank_failed"] or v["checks"]["valid_min"] < 1 or not v["checks"]["own_rows_match"]]
         legs_bad = sorted(set(legs_bad))
         checks["other_configs_failed"] = legs_bad
         checks["ok"] = not (bool(legs_bad) or checks["f16_range"] or checks["valid_min"] < 1 or not checks["proposals_finite"]

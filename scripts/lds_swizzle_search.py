@@ -37,3 +37,10 @@ for P in (8,16):
                 best=(t,w,tab); print(best)
             if t==0: break
 print("best",best)
+# formula search (round 6): g(h) = (a h ^ b (h >> 1) ^ c (h >> 2) ^ d) & 7 or the same with +; the simplest hit is a = 2: f(hx) = hx & 6
+found = []
+for a, b, c, d in itertools.product(range(8), repeat=4):
+    for name, fn in (("xor", lambda h: ((h * a) ^ ((h >> 1) * b) ^ ((h >> 2) * c) ^ d) & 7), ("add", lambda h: ((h * a) + ((h >> 1) * b) + ((h >> 2) * c) + d) & 7)):
+        if conflicts(lambda hx: fn(hx >> 1))[0] == 0:
+            found.append((name, a, b, c, d))
+print(len(found), "conflict-free formulas; first:", found[:6], " hx & 6:", conflicts(lambda hx: hx & 6))

@@ -6,7 +6,10 @@ is RCCL on a real multi-GPU node; this machine has one GPU, and RCCL does not ru
 With a third argument "nccl" (tests/test_gpu_distributed.py::test_two_ranks_rccl, only where >= 2 devices are visible) each rank
 takes the device LOCAL_RANK and the records travel by RCCL, device to device, exactly as in the product.
 
-argv: total out_dir [nccl]      env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
+With a fourth argument "c5" the ranks run BASELINE.json configs[4]'s per-GPU shape (MobileNetV2, 1024 x 1024, 15 anchors per
+cell, ONE image per rank when total = world) instead of the small VGG16 graph.
+
+argv: total out_dir [gloo|nccl] [vgg160|c5]      env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT
 Writes out_dir/rank<r>.npz with the gathered records of the three code paths; exit code 0 when it ran to the end.
 """
 import os
@@ -24,8 +27,21 @@ from tf_rpn_amd.predictor import Proposer, compact_gathered, shard_bounds
 from tf_rpn_amd.utils import train_utils
 
 
+def config(name):
+    """(backbone, hyper_params, image size, weight seed) of the worker's two graphs; the test builds the same."""
+    if name == "c5":
+        hp = dict(train_utils.get_hyper_params("mobilenet_v2", img_size=1024, feature_map_shape=64,
+                                               anchor_ratios=[1., 2., 1. / 2., 3., 1. / 3.]))
+        train_utils.get_hyper_params("mobilenet_v2", img_size=500, feature_map_shape=32, anchor_ratios=[1., 2., 1. / 2.])   # (mutated global: put it back)
+        return "mobilenet_v2", hp, 1024, 5
+    hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
+    train_utils.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    return "vgg16", hp, 160, 5
+
+
 def main():
     total, out_dir = int(sys.argv[1]), sys.argv[2]
+    backbone, hp, size, seed = config(sys.argv[4] if len(sys.argv) > 4 else "vgg160")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rccl = len(sys.argv) > 3 and sys.argv[3] == "nccl"
     device = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
@@ -46,21 +62,20 @@ def main():
         dist.all_gather_into_tensor = staged_all_gather
     try:
         torch.cuda.set_device(device)
-        hp = dict(train_utils.get_hyper_params("vgg16", img_size=160, feature_map_shape=10))
-        weights = synthetic_weights("vgg16", hp, seed=5)
-        imgs = torch.rand((total, 160, 160, 3), generator=torch.Generator().manual_seed(11))     # same on every rank
+        weights = synthetic_weights(backbone, hp, seed=seed)
+        imgs = torch.rand((total, size, size, 3), generator=torch.Generator().manual_seed(11))     # same on every rank
         lo, hi = shard_bounds(total, world, rank)
         local = imgs[lo:hi].cuda().contiguous()
         rows = -(-total // world)
         res = {}
         # (1) the serial distributed step with uneven shards: propose_distributed(total=...)
-        prop = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7)
+        prop = Proposer(backbone, hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7)
         res["serial"] = prop.propose_distributed(local, total=total).cpu().numpy()
         # (2) the same with a caller-provided gather buffer
         gbuf = torch.full((world * rows, prop.topn * 5 + 1), 7.0, device="cuda")
         res["serial_buf"] = prop.propose_distributed(local, gather_out=gbuf, total=total).cpu().numpy()
         # (3) the pipelined step (NMS + packing + gather on the side stream), rows > B on the short rank: two steps + flush
-        prop2 = Proposer("vgg16", hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7,
+        prop2 = Proposer(backbone, hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=rows, iou_threshold=0.7,
                          overlap_nms=True)
         gather_bufs = [torch.full((world * rows, prop2.topn * 5 + 1), 9.0, device="cuda") for _ in range(2)]
         first = prop2.propose_distributed_pipelined(local, gather_bufs)

@@ -44,6 +44,35 @@ def test_two_ranks_on_one_gpu_match_single_process(total, tmp_path):
             assert np.array_equal(got[key].view(np.uint32), want.view(np.uint32)), (rank, key)
 
 
+def test_two_ranks_on_one_gpu_c5_shape(tmp_path):
+    """The same two-rank run at BASELINE.json configs[4]'s per-GPU shape -- MobileNetV2, 1024 x 1024, 15 anchors per cell
+    (61 440 anchors), ONE image per rank: what `bench.py --gpus N`'s `multi_gpu_configs.c5` leg runs on every rank.  Each rank's
+    gathered records must equal, bit for bit, what a one-image handle proposes for the two images in one process."""
+    sys.path.insert(0, ROOT)
+    from bench import spawn_ranks
+    from tests.dist_gpu_worker import config
+    rc, _out = spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "2", str(tmp_path), "gloo", "c5"],
+                           timeout=900)
+    assert rc == 0
+    backbone, hp, size, seed = config("c5")
+    assert hp["anchor_count"] == 15 and size == 1024
+    weights = synthetic_weights(backbone, hp, seed=seed)
+    imgs = torch.rand((2, size, size, 3), generator=torch.Generator().manual_seed(11)).cuda()
+    prop = Proposer(backbone, hyper_params=dict(hp), weights=weights, precision="f16x3", max_batch=1, iou_threshold=0.7)
+    assert prop.total_anchors == 61440
+    rows = []
+    for i in range(2):
+        boxes, scores, valid, _ = prop.propose(imgs[i:i + 1])
+        assert int(valid[0]) > 0
+        rows.append(prop.pack_records(boxes, scores, valid).cpu().numpy())
+    want = np.concatenate(rows)
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        for key in ("serial", "serial_buf", "pipe_step1", "pipe_step2"):
+            assert got[key].shape == want.shape, (rank, key, got[key].shape)
+            assert np.array_equal(got[key].view(np.uint32), want.view(np.uint32)), (rank, key)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible devices (the 1-GPU pool skips it; the 8-GPU node runs it)")
 def test_two_ranks_rccl(tmp_path):
     """The same two-rank run with each rank on a device of its own and the proposal records gathered by RCCL (backend "nccl"),

@@ -305,6 +305,18 @@ def test_bench_prints_one_json_line(extra):
     assert d["rccl_ranks"] == 1 and "traffic_source" in rf
     if "--force-dist" in extra:
         assert d["allgather_ms"] is not None and d["allgather_ms"] < 5.0
+        # BASELINE.json's two 8-GPU configs at their per-GPU shapes, through record packing + the all-gather (world-size-1 RCCL here)
+        mg = d["multi_gpu_configs"]
+        assert set(mg) == {"c4", "c5"}
+        assert "vgg16" in mg["c4"]["workload"] and "batch 32 per GPU" in mg["c4"]["workload"] and mg["c4"]["global_batch"] == 32
+        assert "mobilenet_v2, 1024x1024, 15 anchors" in mg["c5"]["workload"] and "batch 1 per GPU" in mg["c5"]["workload"]
+        for leg in mg.values():
+            assert leg["rccl_ranks"] == 1 and leg["images_per_s"] > 100 and 0 < leg["allgather_ms"] < 5.0
+            assert len(leg["per_rank"]["images_per_s"]) == 1 and leg["record_bytes_per_rank"] % 6004 == 0
+            ck = leg["checks"]
+            assert ck["valid_min"] >= 1 and ck["proposals_finite"] and ck["own_rows_match"] and not ck["any_rank_failed"] and not ck["f16_range"]
+    else:
+        assert "multi_gpu_configs" not in d
     if "--no-extra-legs" in extra:
         assert "c3" not in d and d["nms_boxes_per_sec"] > 1e7
         return

@@ -181,3 +181,60 @@ def test_mobilenet_v2_rpn_conv_in_f32w():
     reg, cls = model.predict_on_batch(imgs)
     assert np.abs(reg - ref[0]).max() <= 1e-4 and np.abs(cls - ref[1]).max() <= 1e-4
     assert {op["name"]: op["arith"] for op in model.ops()}["rpn_conv"] == "f32w"
+
+
+def test_vgg16_f32w_batch_8_against_float64():
+    """The WHOLE f32w graph at batch 8 -- the forms the bench line runs: wide F(4x4, 3x3) for blocks 2-4, the 64-channel form for
+    block1_conv2, split input channels for the 31 x 31 layers (models/rpn_vgg16.py:16-20) -- against the float64 torch graph of
+    ONE image of the batch (image 5; the oracle is too slow for all eight), at the path's 1e-4 bound on deltas and objectness."""
+    from oracle import bbox_oracle as bo
+    from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+    hp = bo.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    imgs = np.random.RandomState(7).uniform(0, 1, size=(8, 500, 500, 3)).astype(np.float32)
+    model = RPNModel("vgg16", hp, precision="f32w", max_batch=8)
+    model.set_weights(weights)
+    reg, cls = model.predict_on_batch(imgs)
+    ref_reg, ref_cls = cv.rpn_forward("vgg16", imgs[5:6], weights, dtype=torch.float64)
+    d_reg, d_cls = np.abs(reg[5:6] - ref_reg).max(), np.abs(cls[5:6] - ref_cls).max()
+    assert d_reg <= 1e-4 and d_cls <= 1e-4, (d_reg, d_cls)
+    assert np.isfinite(reg).all() and np.isfinite(cls).all()
+
+
+def test_f32w_soak_two_handles_two_streams_and_a_busy_chip():
+    """Round-5's scripts/f32w_soak.py as a test.  The split-channel layers (wino_variant 8) hand partial tiles between two
+    workgroups through device-scope (sc1) stores / loads and a ticket that the last arriver resets; the workspace is shared by all
+    batch sizes of a handle.  Here: two f32w handles on two HIP streams AT ONCE, mixed batch sizes, while a third stream keeps the
+    chip busy with the persistent f16x3 conv stack (all 256 CUs owned by another kernel: uneven arrival of the two halves) --
+    every one of the 72 forwards must reproduce the quiet reference bit for bit (tickets back at zero, no stale partial tile)."""
+    from oracle import bbox_oracle as bo
+    from tf_rpn_amd.models._rpn_model import RPNModel, synthetic_weights
+    hp = bo.get_hyper_params("vgg16", img_size=500, feature_map_shape=31)
+    weights = synthetic_weights("vgg16", hp, seed=1)
+    imgs = torch.from_numpy(np.random.RandomState(0).uniform(0, 1, size=(8, 500, 500, 3)).astype(np.float32)).cuda()
+    F, K = 31, 9
+    handles = [RPNModel("vgg16", hp, precision="f32w", max_batch=8) for _ in range(2)]
+    noise = RPNModel("vgg16", hp, precision="f16x3", max_batch=8)
+    for m in handles + [noise]:
+        m.set_weights(weights)
+    reg0, cls0 = torch.empty((8, F, F, 4 * K), device="cuda"), torch.empty((8, F, F, K), device="cuda")
+    handles[0].forward_into(imgs, reg0, cls0)
+    torch.cuda.synchronize()
+    rounds = 36
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [[None] * rounds for _ in range(2)]
+    nreg, ncls = torch.empty_like(reg0), torch.empty_like(cls0)
+    for i in range(rounds):
+        for h in range(2):
+            b = 8 if (i + h) % 3 else 1 + (i * 5 + h * 3) % 7        # full batches and smaller ones in between, different per handle
+            r, c = torch.empty((b, F, F, 4 * K), device="cuda"), torch.empty((b, F, F, K), device="cuda")
+            with torch.cuda.stream(streams[h]):
+                handles[h].forward_into(imgs[:b], r, c)
+            outs[h][i] = (b, r, c)
+        with torch.cuda.stream(streams[2]):
+            noise.forward_into(imgs, nreg, ncls)
+    torch.cuda.synchronize()
+    bad = [(h, i, b) for h in range(2) for i, (b, r, c) in enumerate(outs[h])
+           if not (torch.equal(r, reg0[:b]) and torch.equal(c, cls0[:b]))]
+    assert not bad, bad[:8]
+    assert not noise.status()["f16_range"]

@@ -299,10 +299,10 @@ __host__ __device__ inline int iou_rows_wave_floats(int G, int rows = 64) { retu
 // down to a multiple of 4; the two halves read their operands at two LDS addresses per wave, still a broadcast per 16-lane
 // read group).  Half the wave-private LDS tile (6.3 KB at G = 42: 24 instead of 12 resident waves per CU by LDS) and half the
 // per-wave latency: the kernel was bound by per-wave latency x occupancy (rocprofv3, round 2), not by its stores.
-// RUN > 1 (round 5): a wave owns RUN CONSECUTIVE tiles -- the same image's gt boxes, staged once -- and requests the next tile's
-// anchor before it works on the current one, so that only the first tile of a run pays the load latency; the stores of tile t
-// drain while tile t + 1 is computed (they are asynchronous; the wave-private LDS tile is reused in order).
-template <bool NT, int WAVES, bool FAST, int ROWS = 64, int RUN = 1>
+// (Round 5 built runs of 2 / 4 CONSECUTIVE tiles per wave -- the image's gt staged once, the next tile's anchor requested under the
+// current tile's arithmetic -- parity-green and slower, 22.7 -> 26.3 / 30.7 us: the kernel lives from many short independent waves.
+// Removed in round 6; NOTES.md.)
+template <bool NT, int WAVES, bool FAST, int ROWS = 64>
 __global__ void __launch_bounds__(64 * WAVES)
 iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A, const float *__restrict__ gt, int G,
                     float *__restrict__ out, int tiles_per_img, int n_tiles)
@@ -317,41 +317,20 @@ iou_map_rows_kernel(const float *__restrict__ bboxes, int bboxes_batched, int A,
     const int al = ROWS == 64 ? lane : (lane & 31);           // this lane's anchor inside the tile
     const int Gh = ROWS == 64 ? G : ((G >> 1) & ~3);          // the gt run of this lane: [g_lo, g_hi)
     const int g_lo = (ROWS == 64 || lane < 32) ? 0 : Gh, g_hi = (ROWS == 64 || lane >= 32) ? G : Gh;
-    // RUN == 1: one tile per trip, tiles gridDim.x * WAVES apart (one trip unless RPN_IOU_PERSIST); RUN > 1: this wave's run
-    const int tile_first = RUN == 1 ? blockIdx.x * WAVES + wave : (blockIdx.x * WAVES + wave) * RUN;
-    const int tile_end = RUN == 1 ? n_tiles : min(n_tiles, tile_first + RUN);
-    const int tile_step = RUN == 1 ? gridDim.x * WAVES : 1;
-    int b_staged = -1;
-    Box bb_next = Box{0.f, 0.f, 0.f, 0.f};
-    if (RUN > 1 && tile_first < n_tiles) {
-        const int b0 = tile_first / tiles_per_img;
-        const int a0 = min((tile_first - b0 * tiles_per_img) * ROWS + al, A - 1);
-        bb_next = load_box(bboxes + (bboxes_batched ? 4 * (size_t)b0 * A : 0) + 4 * (size_t)a0);
-    }
-    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
+    // one tile per trip, tiles gridDim.x * WAVES apart (one trip unless RPN_IOU_PERSIST)
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
     const int b = tile / tiles_per_img;
     const int a_base = (tile - b * tiles_per_img) * ROWS;
     const int rows = min(ROWS, A - a_base);
     const int a = min(a_base + al, A - 1);                    // idle lanes recompute the last anchor, results unused
     const float *__restrict__ gtb = gt + 4 * (size_t)b * G;
-    Box bb;
-    if constexpr (RUN > 1) {
-        bb = bb_next;
-        if (tile + 1 < tile_end) {                            // the next tile's anchor: in flight under this tile's arithmetic
-            const int bn = (tile + 1) / tiles_per_img;
-            const int an = min((tile + 1 - bn * tiles_per_img) * ROWS + al, A - 1);
-            bb_next = load_box(bboxes + (bboxes_batched ? 4 * (size_t)bn * A : 0) + 4 * (size_t)an);
-        }
-    } else {
-        bb = load_box(bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a);
-    }
+    const Box bb = load_box(bboxes + (bboxes_batched ? 4 * (size_t)b * A : 0) + 4 * (size_t)a);
     if constexpr (FAST) {                                     // lane g stages gt box g and its area (G <= 64)
-        if ((RUN == 1 || b != b_staged) && lane < GP) {
+        if (lane < GP) {
             const Box gl = load_box(gtb + 4 * min(lane, G - 1));
             gbox_t[lane] = f32x4_t{gl.y1, gl.x1, gl.y2, gl.x2};
             garea_t[lane] = box_area_plain(gl);
         }
-        b_staged = b;
     }
     const float barea = box_area_plain(bb);                   // :139
     const long long s = ((long long)b * A + a_base) * G;      // first float of this wave's run
@@ -623,10 +602,8 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
         static const int persist = RPN_LAB_KNOB("RPN_IOU_PERSIST", 0);
         static const int fast = RPN_LAB_KNOB("RPN_IOU_FAST", 1);
         static const int wv = RPN_LAB_KNOB("RPN_IOU_WAVES", 4);     // waves per workgroup: 4 | 2
-        static const int runk = RPN_LAB_KNOB("RPN_IOU_RUN", 1);     // consecutive tiles per wave: 1 | 2 | 4
         const int W = wv == 2 ? 2 : 4;
-        const int run = (runk == 2 || runk == 4) && !half && nt_rows() && fast && W == 4 && !persist ? runk : 1;
-        long long wgs = ((n_tiles + run - 1) / run + W - 1) / W;
+        long long wgs = (n_tiles + W - 1) / W;
         if (persist) {
             const long long resident = 256ll * (long long)((160 * 1024) / (W * wave_lds));
             if (wgs > resident) {
@@ -639,9 +616,7 @@ extern "C" int rpn_iou_map(const float *d_bboxes, int bboxes_batched, int A, con
 #define RPN_IOU_ROWS(NT_, W_, FAST_, ...)                                                                             \
     hipLaunchKernelGGL((iou_map_rows_kernel<NT_, W_, FAST_, ##__VA_ARGS__>), grid, dim3(64 * W_), W_ * wave_lds, as_stream(stream), d_bboxes, \
                        bboxes_batched, A, d_gt, G, d_iou, tiles_per_img, nt_i)
-        if (run == 2) RPN_IOU_ROWS(true, 4, true, 64, 2);
-        else if (run == 4) RPN_IOU_ROWS(true, 4, true, 64, 4);
-        else if (half && nt_rows() && fast && W == 4) RPN_IOU_ROWS(true, 4, true, 32);
+        if (half && nt_rows() && fast && W == 4) RPN_IOU_ROWS(true, 4, true, 32);
         else if (half) return rpn::fail(RPN_ERR_INVALID, "rpn_iou_map: RPN_IOU_HALF needs the default row-kernel settings");
         else if (!nt_rows()) RPN_IOU_ROWS(false, 4, true);
         else if (!fast) RPN_IOU_ROWS(true, 4, false);

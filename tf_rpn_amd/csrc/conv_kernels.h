@@ -73,7 +73,8 @@ hipError_t launch_rpn_head(const float *x, long long P, const float *w_packed, c
 // workspace (variant 8 only): wino_workspace_bytes bytes of device memory, zeroed ONCE by the owner (partial tiles + tickets; the
 // kernel leaves the tickets at zero), private to one stream at a time.
 bool wino_supported(int Cin, int Cout);                  // Cin % 8 == 0, Cout % 32 == 0
-int wino_variant(int B, int H, int W, int Cin, int Cout);
+int wino_variant(int B, int H, int W, int Cin, int Cout);   // 16 | 4 | 8 | 2, from the grid and the CURRENT device's CU count
+bool wino_launchable(int B, int H, int W, int Cin, int Cout, int variant);   // launch_conv3x3_wino's limits as a predicate
 size_t wino_weight_floats(int Cin, int Cout, int variant);
 size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant);
 void pack_weights_wino_host(const float *hwio, const float *scale, int Cin, int Cout, float *dst, int variant);

@@ -545,9 +545,23 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
 }
 
 // K split, after the workgroup's partial tile is written: take the tile's ticket; the LAST of the two arrivers adds the halves in
-// fixed order, + bias, activation, and writes the output tile.  Visibility as in ir_block_x3_kernel (mnv2_block_kernels.hip): every
-// handed-off word is written with a device-scope (sc1) store and read with a device-scope load, a storing wave drains its stores in
-// front of the barrier that precedes the ticket -- no cache-wide fence.  Nobody waits for anybody.  Called by all 1024 threads.
+// fixed order, + bias, activation, and writes the output tile.  Nobody waits for anybody.  Called by all 1024 threads.
+// Visibility (as in ir_block_x3_kernel, mnv2_block_kernels.hip) without a cache-wide release / acquire pair -- this is, cell by cell,
+// the first row of MI355X_MICROARCH.md's table "Hand-offs measured with sc1 loads in place of the acquire" (gfx950, ROCm 7.2):
+//   stores   EVERY handed-off word leaves by a buffer store with sc1 (w4_output_pair: 4-byte stores; write-through to memory, the
+//            line is dropped from the XCD's L2);
+//   drain    every storing wave runs `s_waitcnt vmcnt(0)` after its stores, THEN the workgroup barrier, THEN one lane's agent-scope
+//            atomic add on the tile's ticket -- the signal comes after the wait of every wave it signals for;
+//   consumer the workgroup whose add returned 1 came last: the adding lane uses the returned value, publishes it through LDS, and the
+//            other waves load only after the workgroup barrier that lane then joins;
+//   loads    EVERY load of the handed-off words is a buffer load with sc1 to registers (never flat, never plain): served by L2 /
+//            memory, the CU's L1 -- which no other CU's store ever refreshes -- is bypassed, so no `buffer_inv` is needed;
+//   memory   hipMalloc, one workgroup per CU (1024 threads, 144 KB of LDS).
+// A relaxed atomic is enough under those conditions: ordering comes from the drained write-through stores in front of it, not from
+// the atomic's own semantics; an agent-scope release + acquire instead writes back / invalidates whole caches per workgroup (measured
+// in round 3 on the same seam shape: configs[4] 0.384 -> 0.455 ms).  The last arriver resets the ticket for the next launch (the
+// kernel boundary publishes it).  tests/test_gpu_wino.py::test_f32w_soak_two_handles_two_streams_and_a_busy_chip runs the seam
+// under uneven load (another stream's persistent kernels own the CUs) and checks every output word.
 __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, int tid, int tile_id, int img, int oy0, int ox0, int n0)
 {
     constexpr int kSc1 = 16;
@@ -1171,16 +1185,25 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #undef RPN_WINO_LDS_PTR
 
 // Which Winograd form a layer runs on (per model handle, from the grid at its largest batch -- never per call: the forms sum in
-// different orders): F(4x4, 3x3) where its 16 x 32-pixel tiles give every CU at least one workgroup, F(2x2, 3x3) otherwise (the
-// 31 x 31 layers at batch 8: 128 workgroups of 16 x 32 pixels against 256 of 16 x 16).  Returns 4 or 2.
+// different orders).  Returns 16 (wide F(4x4, 3x3): 16 x 16 pixels x 128 channels per workgroup, where Cout % 128 == 0 and those tiles
+// give every CU a workgroup), 4 (F(4x4, 3x3), 16 x 32 pixels x 64 channels, where THOSE tiles fill the chip), 8 (the same with the
+// input channels split over two workgroups per tile, where they fill half of it: the 31 x 31 layers at batch 8) or 2 (F(2x2, 3x3),
+// 16 x 16 pixels x 64 channels: small grids).  The CU count is that of the device CURRENT at the call (rpn_model_create /
+// rpn_conv2d run on the caller's device), cached per device id.
+static int wino_cus_of_current_device()
+{
+    static int cache[64] = {0};                          // (0: not asked yet; benign race: every thread stores the same value)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < 64 && cache[dev] > 0) return cache[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    if (dev < 64) cache[dev] = n;
+    return n;
+}
 int wino_variant(int B, int H, int W, int Cin, int Cout)
 {
-    static const int knob = RPN_LAB_KNOB("RPN_WINO_F", 0);          // (laboratory: 2 | 4 forces a form)
-    static const int n_cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
+    static const int knob = RPN_LAB_KNOB("RPN_WINO_F", 0);          // (laboratory: 2 | 4 | 8 | 16 forces a form)
+    const int n_cus = wino_cus_of_current_device();
     if (Cin % kW4KS != 0) return 2;
     if (knob == 2 || knob == 4 || knob == 8 || (knob == 16 && Cout % kWnBN == 0)) return knob;
 #ifndef RPN_EXP_W4_NOWIDE
@@ -1207,17 +1230,28 @@ size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant)
     return (size_t)kW4Tickets * 4 + (size_t)wino4_tiles(B, H, W, Cout) * 2 * 512 * kWinoBN * 4;
 }
 
+// Everything launch_conv3x3_wino checks besides the pointers, as a predicate: a model handle asks it when the graph is BUILT (add_conv),
+// so that a layer the launcher would refuse (an image beyond the kernels' 32-bit buffer offsets, a tile count beyond the ticket block)
+// stays on the direct float32 kernel instead of failing at every forward.
+bool wino_launchable(int B, int H, int W, int Cin, int Cout, int variant)
+{
+    if (!wino_supported(Cin, Cout) || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8 && variant != 16)) return false;
+    if ((long long)H * W * Cin * 4 > 0x7fffffffll) return false;
+    if (variant == 8 && (Cin / kW4KS < 2 || wino4_tiles(B, H, W, Cout) > kW4Tickets)) return false;
+    if (variant == 16 && Cout % kWnBN != 0) return false;
+    return true;
+}
+
 hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias, float *out, int B, int H, int W, int Cin,
                                int Cout, int act, bool pool, hipStream_t s, int variant, void *workspace)
 {
-    if (!wino_supported(Cin, Cout) || act == ACT_SIGMOID || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8 && variant != 16)) return hipErrorInvalidValue;
-    if ((long long)H * W * Cin * 4 > 0x7fffffffll) return hipErrorInvalidValue;
+    if (act == ACT_SIGMOID || !wino_launchable(B, H, W, Cin, Cout, variant)) return hipErrorInvalidValue;
     WinoArgs a{};
     a.x = x; a.u = u; a.bias = bias; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act; a.pool = pool ? 1 : 0;
     a.ksplit = 1;
     if (variant == 8) {
-        if (!workspace || Cin / kW4KS < 2 || wino4_tiles(B, H, W, Cout) > kW4Tickets) return hipErrorInvalidValue;
+        if (!workspace) return hipErrorInvalidValue;
         a.ksplit = 2;
         a.tickets = static_cast<unsigned *>(workspace);
         a.part = reinterpret_cast<float *>(static_cast<char *>(workspace) + (size_t)kW4Tickets * 4);

@@ -223,7 +223,11 @@ static int add_conv(rpn_model *m, const std::string &name, const std::string &bn
     op.out_f32 = split && force_f32_out;
     op.wino = m->wino && R == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == ti.H && OW == ti.W && residual < 0 &&
               act != ACT_SIGMOID && !op.cin3 && !ti.external && wino_supported(ti.C, Cout);
-    if (op.wino) op.wino_f = wino_variant(m->max_batch, ti.H, ti.W, ti.C, Cout);
+    if (op.wino) {
+        op.wino_f = wino_variant(m->max_batch, ti.H, ti.W, ti.C, Cout);
+        // a layer the Winograd launcher would refuse (32-bit buffer offsets, ticket block) stays on the direct float32 kernel
+        op.wino = wino_launchable(m->max_batch, ti.H, ti.W, ti.C, Cout, op.wino_f);
+    }
     op.kind = OP_CONV; op.name = name; op.in = in; op.residual = residual;
     op.Cin = ti.C; op.Cout = Cout; op.R = R; op.S = R; op.stride = stride; op.pad_t = pad_t; op.pad_l = pad_l;
     op.H = ti.H; op.W = ti.W; op.OH = OH; op.OW = OW; op.act = act;
@@ -590,7 +594,10 @@ static int ensure_device(rpn_model *m)
             if (op.kind == OP_CONV && op.wino) need = std::max(need, wino_workspace_bytes(m->max_batch, op.H, op.W, op.Cin, op.Cout, op.wino_f));
         if (need) {
             RPN_HIP_CHECK(hipMalloc(&m->d_wino_ws, need));
+            // the tickets must read zero before the first forward, which runs on the CALLER's stream: a non-blocking stream is not
+            // ordered behind the null stream's memset, so drain it here (allocation path, once per handle)
             RPN_HIP_CHECK(hipMemset(m->d_wino_ws, 0, need));
+            RPN_HIP_CHECK(hipStreamSynchronize(nullptr));
         }
     }
     if (!m->d_ksplit) {
@@ -1300,12 +1307,15 @@ extern "C" int rpn_conv2d(const float *d_x, int B, int H, int W, int Cin, const 
     RPN_REQUIRE_DEVICE();
     hipStream_t s = as_stream(stream);
     if (precision == RPN_PRECISION_F32W) {
-        // float32 Winograd F(2x2, 3x3): 3x3 / stride 1 / pad 1 only; transforms and packs the weights on the host
+        // float32 Winograd (the form wino_variant picks for this grid: F(4x4, 3x3) wide / 64-channel / split-channel, or F(2x2, 3x3)):
+        // 3x3 / stride 1 / pad 1 only; transforms and packs the weights on the host
         if (!(R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && wino_supported(Cin, Cout) &&
               act != ACT_SIGMOID))
             return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the Winograd path needs 3x3 s1 'same', Cin %% 8 == 0, Cout %% 32 == 0");
         const size_t wcount = (size_t)9 * Cin * Cout;
         const int wf = wino_variant(B, H, W, Cin, Cout);
+        if (!wino_launchable(B, H, W, Cin, Cout, wf))
+            return fail(RPN_ERR_UNSUPPORTED, "rpn_conv2d: the Winograd path needs H * W * Cin * 4 bytes per image below 2 GiB");
         std::vector<float> hw(wcount), packed(wino_weight_floats(Cin, Cout, wf));
         RPN_HIP_CHECK(hipMemcpy(hw.data(), d_w, wcount * sizeof(float), hipMemcpyDeviceToHost));
         pack_weights_wino_host(hw.data(), nullptr, Cin, Cout, packed.data(), wf);

@@ -12,6 +12,8 @@ each rank takes a contiguous slice of the batch, runs the whole path locally, an
 all-gather of fixed-size proposal records collects the result.  There is no
 other collective on the data path.
 """
+import warnings
+
 import torch
 
 from . import _lib as L
@@ -257,6 +259,12 @@ class Proposer(object):
         outside the graph (``rpn_model.raise_on_range_error()``)."""
         if self.check_range and self.rpn_model.precision in ("f16x3", "fp16x3"):
             if torch.cuda.is_current_stream_capturing():
+                if not getattr(self, "_warned_capture_poll", False):
+                    self._warned_capture_poll = True
+                    warnings.warn("Proposer(check_range=True): the float16 range word cannot be polled inside a stream capture; "
+                                  "a captured step never raises FloatingPointError -- call rpn_model.raise_on_range_error() "
+                                  "after replaying the graph, or pass check_range=False to take that on knowingly",
+                                  RuntimeWarning, stacklevel=3)
                 return
             self.rpn_model.raise_on_range_error()
 
