@@ -1,0 +1,45 @@
+"""Per-wave slice timing of the wide F(4x4,3x3) Winograd kernel (needs the -DRPN_STAMP build: scripts/build_wn_stamp.sh, then
+RPN_HIP_LIB=tf_rpn_amd/csrc/librpn_hip_wnstamp.so python scripts/wn_stamp_probe.py [B,H,Cin,Cout ...]).
+For every wave of the first 64 workgroups: work = arrival at slice s's barrier - release from slice s-1's; wait = release - arrival."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tf_rpn_amd import _lib as L
+lib = L.lib()
+raw = ctypes.CDLL(L.LIB_PATH)
+raw.rpn_debug_read_wn_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+def run(B, H, Cin, Cout):
+    x = torch.rand((B, H, H, Cin), device="cuda"); w = torch.randn((3, 3, Cin, Cout), device="cuda") * 0.05
+    b = torch.zeros((Cout,), device="cuda"); out = torch.empty((B, H, H, Cout), device="cuda")
+    for _ in range(3):
+        L.check(lib.rpn_conv2d(L.ptr(x), B, H, H, Cin, L.ptr(w), L.ptr(b), 3, 3, Cout, 1, 1, 1, H, H, 1, L.PRECISIONS["f32w"], L.ptr(out), None), "conv")
+    torch.cuda.synchronize()
+    n = 64 * 16 * 64
+    st = np.zeros(n, dtype=np.uint64)
+    assert raw.rpn_debug_read_wn_stamps(st.ctypes.data, n) == 0
+    s = st.reshape(64, 16, 64).astype(np.int64)
+    ns = min(28, Cin // 4)
+    arr, rel = s[:, :, 0:2 * ns:2], s[:, :, 1:2 * ns:2]
+    work = arr[:, :, 1:] - rel[:, :, :-1]          # slice s's work (s >= 1)
+    wait = rel - arr
+    period = rel[:, :, 1:] - rel[:, :, :-1]
+    sl = slice(3, ns - 1)
+    print("layer B%d %dx%d %d->%d  slices stamped %d" % (B, H, H, Cin, Cout, ns))
+    print("  slice period (release to release), median over workgroups/waves: %d cycles" % np.median(period[:, :, sl]))
+    print("  MFMA waves 0..11: work median %d [p10 %d p90 %d]  wait at the barrier median %d [p10 %d p90 %d]" % (
+        np.median(work[:, :12, sl]), *np.percentile(work[:, :12, sl], [10, 90]), np.median(wait[:, :12, 4:ns - 1]), *np.percentile(wait[:, :12, 4:ns - 1], [10, 90])))
+    print("  staging waves 12..15: work median %d [p10 %d p90 %d]  wait median %d [p10 %d p90 %d]" % (
+        np.median(work[:, 12:, sl]), *np.percentile(work[:, 12:, sl], [10, 90]), np.median(wait[:, 12:, 4:ns - 1]), *np.percentile(wait[:, 12:, 4:ns - 1], [10, 90])))
+    # who arrives last at a barrier?  index of the latest arrival per (workgroup, slice)
+    last = arr[:, :, 4:ns - 1].argmax(axis=1)
+    print("  last arriver is a staging wave in %.0f %% of the barriers" % (100.0 * (last >= 12).mean()))
+    lag = arr[:, 12:, 4:ns - 1].max(axis=1) - arr[:, :12, 4:ns - 1].max(axis=1)
+    print("  (latest staging arrival) - (latest MFMA arrival): median %d [p10 %d p90 %d]" % (np.median(lag), *np.percentile(lag, [10, 90])))
+    spread = arr[:, :12, 4:ns - 1].max(axis=1) - arr[:, :12, 4:ns - 1].min(axis=1)
+    print("  MFMA waves' arrival spread: median %d [p90 %d]" % (np.median(spread), np.percentile(spread, 90)))
+    w0 = s[0]
+    print("  workgroup 0: entry->loop %d, loop %d (%d slices), per-wave first work:" % (np.median(w0[:12, 61] - w0[:12, 60]), np.median(w0[:12, 62] - w0[:12, 61]), Cin // 4),
+          (arr[0, :, 5] - rel[0, :, 4]).tolist())
+cfgs = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 125, 256, 256), (8, 250, 128, 128)]
+for cfg in cfgs:
+    run(*cfg)

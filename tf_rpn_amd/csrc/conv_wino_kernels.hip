@@ -33,6 +33,23 @@
 
 #include <vector>
 
+// Debug build only (-DRPN_STAMP, scripts/wn_stamp_probe.py): per-WAVE cycle stamps of the F(4x4, 3x3) kernels' slice loop -- slot 2 s =
+// arrival at slice s's barrier, 2 s + 1 = release from it (s < 28), 60 = kernel entry, 61 = loop entry, 62 = loop exit, 63 = end.
+#ifdef RPN_STAMP
+__device__ unsigned long long g_wn_stamps[64 * 16 * 64];
+#define RPN_WN_STAMP(k)                                                                                    \
+    do {                                                                                                   \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && (k) < 64)                                        \
+            g_wn_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int rpn_debug_read_wn_stamps(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wn_stamps), (size_t)n * 8);
+}
+#else
+#define RPN_WN_STAMP(k) ((void)0)
+#endif
+
 namespace rpn {
 
 using f32x16_w = __attribute__((ext_vector_type(16))) float;
@@ -492,9 +509,8 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
     const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
     if (n >= a.Cout) return;
     constexpr int kSc1 = 16;                                             // cache-policy bit 4 = sc1 (device scope, write-through)
-    // two output rows at a time (the 4 x 6 intermediate of all four would not fit beside the other N block's 48 live accumulator
-    // registers): R[p][j] = sum_i At[p][i] M[i][j] for p = 2 hp, 2 hp + 1, then the column transform of those two rows
-#pragma unroll 1
+    // two output rows at a time, as two STRAIGHT-LINE passes over the 36 parked values (see w4n_output_pair)
+#pragma unroll
     for (int hp = 0; hp < 2; ++hp) {
         float R0[6], R1[6];
 #pragma unroll
@@ -511,6 +527,7 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
                 R1[j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         const int p = 2 * hp;
         float y0[4], y1[4];
         w4_at(R0, y0);
@@ -624,6 +641,145 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
     }
 }
 
+// The staging role of the 64-channel F(4x4, 3x3) form (waves 12 .. 15), one instantiation per PART (output rows 3 PART .. 3 PART + 2
+// of every pair's transform; pair_half: which 64 of the slice's 128 (tile, channel) pairs): straight-line code, see w4n_staging_role.
+template <int PART>
+__device__ __forceinline__ void w4_staging_role(const WinoArgs &a, float *ldsU, float *ldsVR, float (*raws)[kW4KS * kW4Plane],
+                                                __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t prs, bool split, int pair_half, int tid,
+                                                int lane, int tile_id, int img, int oy0, int ox0, int n0, int n_slices)
+{
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr int kW4Half = 18 * 32 * 32;
+    (void)kW4Half;
+    const int hid = tid - 768;             // staging thread 0 .. 255
+    // issue priority over the MFMA waves: the three MFMA waves of a SIMD always have a matrix instruction pending, and at equal
+    // priority the staging wave's vector instructions were starved behind them -- the MFMA waves then waited for it at the
+    // slice barrier (wide form 1 873 -> 1 976 images/s; no change for the 32-tile form, kept for symmetry)
+    __builtin_amdgcn_s_setprio(3);
+    // a staging thread's pixels of a slice's raw patch (18 x 34 = 612 pixels, one 16-byte load = 4 channels each)
+    unsigned r_off[3];
+    int r_lds[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pix = hid + j * 256;
+        const int py = pix / kW4PatchW, px = pix - py * kW4PatchW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = pix < kW4PatchH * kW4PatchW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        r_lds[j] = py * kW4Pitch + px + ((py >> 2) & 1) * 2;      // rows of odd tile rows skewed by two floats (see transform)
+    }
+    const bool third = hid + 512 < kW4PatchH * kW4PatchW;
+    // transform role: a lane = one (tile, channel) pair, two WAVES per pair (output rows 3 part .. 3 part + 2)
+    // (the part is wave-uniform: with a lane-dependent part every wave runs both halves of the row transform under exec masks.
+    // Before the staging waves had issue priority this measured SLOWER -- two waves read a pair's patch instead of two lanes
+    // sharing one broadcast read --, with it +0.7 %.)
+    constexpr int t_part = PART;                     // (template parameter: straight-line code, see w4n_staging_role)
+    const int t_pair = pair_half * 64 + lane;
+    const int t_tile = t_pair & 31, t_c = t_pair >> 5;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    // TWO register sets for the raw patch: slice t travels in set t & 1, requested TWO iterations before the transform that reads
+    // it and written to LDS one iteration after the request -- a request consumed in the iteration that issues it makes every
+    // iteration at least one memory latency long, and the MFMA waves wait for the staging waves at the slice barrier (the matrix
+    // pipe was 48 % busy).  (The same idea measured slower while the filter DMAs shared the stream: their conservative
+    // vmcnt(0) waited for everything in flight.)
+    u32x4_w rr[2][3] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
+#define RPN_W4_LOAD_RAW(SLICE, SET)                                                                                         \
+do {                                                                                                                    \
+    rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
+    rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);                          \
+    rr[SET][2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros, no traffic) */ \
+} while (0)
+#define RPN_W4_RAW_TO_LDS(BUF, SET)                                                                                         \
+{                                                                                                                       \
+    float *raw_ = raws[BUF];                                                                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                                    \
+        if (j_ < 2 || third) {                                                                                          \
+            const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kW4Plane] = v_[i_];                  \
+        }                                                                                                               \
+}
+    auto transform = [&](int buf) {
+        // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
+        // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
+        // Bank skew: tile columns are 4 floats apart and four tile rows 144 = 16 (mod 32) floats, so the 32 tiles of a wave's
+        // 8-byte read would fall on 16 of the 32 banks; patch rows 4 .. 7, 12 .. 15 are stored two floats to the right
+        // (raw_to_lds), which puts odd tile rows on the other 16.  A tile's rows 4, 5 belong to the next tile row: second base.
+        int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
+        int ro45 = ro + 2 - (t_ty & 1) * 4;
+        asm volatile("" : "+v"(ro), "+v"(ro45));
+        const float *rp = ldsVR + ro;
+        const float *rp45 = ldsVR + ro45;
+        float T[3][6];
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
+            float d0[6], d1[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                d0[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp];
+                d1[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp + 1];
+            }
+            float t0[3], t1[3];
+            if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
+            else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
+        }
+        int vo = buf * kW4VFloats + (18 * t_part) * (kW4KS * 32) + t_c * 32 + t_tile;      // (opaque for the same reason: the writes
+        asm volatile("" : "+v"(vo));                                                         // need not wait for the DMA either)
+        float *vp = ldsVR + vo;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float v[6];
+            w4_bt6(T[i], v);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * 32)] = v[j];
+        }
+    };
+    // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
+    // wait -- to turn the LDS-DMA's Infinity-Cache / HBM misses into L2 hits measured SLOWER: 1 717 -> 1 639 images/s.)
+    const int last = n_slices - 1;
+    RPN_W4_LOAD_RAW(0, 0);
+    RPN_W4_RAW_TO_LDS(0, 0);
+    RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
+    RPN_W4_LOAD_RAW(2 < last ? 2 : last, 0);
+    __syncthreads();
+    transform(0);
+    RPN_W4_RAW_TO_LDS(1, 1);
+    __syncthreads();
+    // iteration s (between its barriers the MFMA waves run slice s): request slice s + 3 into the set slice s + 1 has left,
+    // transform slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1]), write slice s + 2 (requested an iteration ago) to raws[s & 1]
+#define RPN_W4_STAGE(S, SET)                                                                                                \
+{                                                                                                                       \
+    if ((S) + 2 < n_slices) {                                                                                           \
+        RPN_W4_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
+        transform((SET) ^ 1);                                                                                           \
+        RPN_W4_RAW_TO_LDS(SET, SET);                                                                                    \
+    } else if ((S) + 1 < n_slices) {                                                                                    \
+        transform((SET) ^ 1);                                                                                           \
+    }                                                                                                                   \
+    __syncthreads();                                                                                                    \
+}
+    {
+        int s = 0;
+        for (; s + 1 < n_slices; s += 2) {
+            RPN_W4_STAGE(s, 0);
+            RPN_W4_STAGE(s + 1, 1);
+        }
+        if (s < n_slices) RPN_W4_STAGE(s, 0);
+    }
+#undef RPN_W4_STAGE
+    // ---- epilogue: two phases of 32 output channels; every thread of the workgroup transforms one (tile, channel) pair per phase
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        __syncthreads();                                         // the phase's accumulators are in LDS
+        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
+        __syncthreads();                                         // the staging area may be overwritten
+    }
+    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
+#undef RPN_W4_LOAD_RAW
+#undef RPN_W4_RAW_TO_LDS
+}
+
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -672,132 +828,10 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int kh = lane >> 5, l31 = lane & 31;
 
     if (stager) {
-        // issue priority over the MFMA waves: the three MFMA waves of a SIMD always have a matrix instruction pending, and at equal
-        // priority the staging wave's vector instructions were starved behind them -- the MFMA waves then waited for it at the
-        // slice barrier (wide form 1 873 -> 1 976 images/s; no change for the 32-tile form, kept for symmetry)
-        __builtin_amdgcn_s_setprio(3);
-        // a staging thread's pixels of a slice's raw patch (18 x 34 = 612 pixels, one 16-byte load = 4 channels each)
-        unsigned r_off[3];
-        int r_lds[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int pix = hid + j * 256;
-            const int py = pix / kW4PatchW, px = pix - py * kW4PatchW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            const bool v = pix < kW4PatchH * kW4PatchW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
-            r_lds[j] = py * kW4Pitch + px + ((py >> 2) & 1) * 2;      // rows of odd tile rows skewed by two floats (see transform)
-        }
-        const bool third = hid + 512 < kW4PatchH * kW4PatchW;
-        // transform role: a lane = one (tile, channel) pair, two WAVES per pair (output rows 3 part .. 3 part + 2)
-        // (the part is wave-uniform: with a lane-dependent part every wave runs both halves of the row transform under exec masks.
-        // Before the staging waves had issue priority this measured SLOWER -- two waves read a pair's patch instead of two lanes
-        // sharing one broadcast read --, with it +0.7 %.)
-        const int t_part = (wave - 12) & 1, t_pair = ((wave - 12) >> 1) * 64 + lane;
-        const int t_tile = t_pair & 31, t_c = t_pair >> 5;
-        const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-        // TWO register sets for the raw patch: slice t travels in set t & 1, requested TWO iterations before the transform that reads
-        // it and written to LDS one iteration after the request -- a request consumed in the iteration that issues it makes every
-        // iteration at least one memory latency long, and the MFMA waves wait for the staging waves at the slice barrier (the matrix
-        // pipe was 48 % busy).  (The same idea measured slower while the filter DMAs shared the stream: their conservative
-        // vmcnt(0) waited for everything in flight.)
-        u32x4_w rr[2][3] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
-#define RPN_W4_LOAD_RAW(SLICE, SET)                                                                                         \
-    do {                                                                                                                    \
-        rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
-        rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);                          \
-        rr[SET][2] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[2], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros, no traffic) */ \
-    } while (0)
-#define RPN_W4_RAW_TO_LDS(BUF, SET)                                                                                         \
-    {                                                                                                                       \
-        float *raw_ = raws[BUF];                                                                                            \
-        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                                    \
-            if (j_ < 2 || third) {                                                                                          \
-                const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kW4Plane] = v_[i_];                  \
-            }                                                                                                               \
-    }
-        auto transform = [&](int buf) {
-            // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
-            // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
-            // Bank skew: tile columns are 4 floats apart and four tile rows 144 = 16 (mod 32) floats, so the 32 tiles of a wave's
-            // 8-byte read would fall on 16 of the 32 banks; patch rows 4 .. 7, 12 .. 15 are stored two floats to the right
-            // (raw_to_lds), which puts odd tile rows on the other 16.  A tile's rows 4, 5 belong to the next tile row: second base.
-            int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
-            int ro45 = ro + 2 - (t_ty & 1) * 4;
-            asm volatile("" : "+v"(ro), "+v"(ro45));
-            const float *rp = ldsVR + ro;
-            const float *rp45 = ldsVR + ro45;
-            float T[3][6];
-#pragma unroll
-            for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
-                float d0[6], d1[6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    d0[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp];
-                    d1[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp + 1];
-                }
-                float t0[3], t1[3];
-                if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
-                else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
-            }
-            int vo = buf * kW4VFloats + (18 * t_part) * (kW4KS * 32) + t_c * 32 + t_tile;      // (opaque for the same reason: the writes
-            asm volatile("" : "+v"(vo));                                                         // need not wait for the DMA either)
-            float *vp = ldsVR + vo;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float v[6];
-                w4_bt6(T[i], v);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * 32)] = v[j];
-            }
-        };
-        // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
-        // wait -- to turn the LDS-DMA's Infinity-Cache / HBM misses into L2 hits measured SLOWER: 1 717 -> 1 639 images/s.)
-        const int last = n_slices - 1;
-        RPN_W4_LOAD_RAW(0, 0);
-        RPN_W4_RAW_TO_LDS(0, 0);
-        RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
-        RPN_W4_LOAD_RAW(2 < last ? 2 : last, 0);
-        __syncthreads();
-        transform(0);
-        RPN_W4_RAW_TO_LDS(1, 1);
-        __syncthreads();
-        // iteration s (between its barriers the MFMA waves run slice s): request slice s + 3 into the set slice s + 1 has left,
-        // transform slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1]), write slice s + 2 (requested an iteration ago) to raws[s & 1]
-#define RPN_W4_STAGE(S, SET)                                                                                                \
-    {                                                                                                                       \
-        if ((S) + 2 < n_slices) {                                                                                           \
-            RPN_W4_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
-            transform((SET) ^ 1);                                                                                           \
-            RPN_W4_RAW_TO_LDS(SET, SET);                                                                                    \
-        } else if ((S) + 1 < n_slices) {                                                                                    \
-            transform((SET) ^ 1);                                                                                           \
-        }                                                                                                                   \
-        __syncthreads();                                                                                                    \
-    }
-        {
-            int s = 0;
-            for (; s + 1 < n_slices; s += 2) {
-                RPN_W4_STAGE(s, 0);
-                RPN_W4_STAGE(s + 1, 1);
-            }
-            if (s < n_slices) RPN_W4_STAGE(s, 0);
-        }
-#undef RPN_W4_STAGE
-        // ---- epilogue: two phases of 32 output channels; every thread of the workgroup transforms one (tile, channel) pair per phase
-#pragma unroll 1
-        for (int ph = 0; ph < 2; ++ph) {
-            __syncthreads();                                         // the phase's accumulators are in LDS
-            w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
-            __syncthreads();                                         // the staging area may be overwritten
-        }
-        if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
+        const int sw = wave - 12;          // t_part = sw & 1, pairs (sw >> 1) * 64 .. + 63
+        if (sw & 1) w4_staging_role<1>(a, ldsU, ldsVR, raws, xrs, prs, split, sw >> 1, tid, lane, tile_id, img, oy0, ox0, n0, n_slices);
+        else w4_staging_role<0>(a, ldsU, ldsVR, raws, xrs, prs, split, sw >> 1, tid, lane, tile_id, img, oy0, ox0, n0, n_slices);
         return;
-#undef RPN_W4_LOAD_RAW
-#undef RPN_W4_RAW_TO_LDS
     }
 
     // ---- MFMA waves: xi = 3 wave + j, 32 tiles x 64 channels
@@ -810,45 +844,54 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.0f;
     // The filters go STRAIGHT from L2 into this wave's registers: a wave owns its three xi, so no other wave ever reads its filter
     // fragments, and (pack_weights_wino4_host) lane l31 finds channels l31 and l31 + 32 of (xi, k) as one 8-byte word -- six 8-byte
-    // loads per slice and wave, requested a whole slice ahead into the other register set.  (Through LDS -- DMA in, fragment reads
-    // out -- they were 72 of the 137 KB of LDS traffic per slice, and LDS-pipe time is added to the slice like vector-ALU time.)
-    f32x2_w ureg[2][6];
+    // loads per slice and wave.  (Through LDS -- DMA in, fragment reads out -- they were 72 of the 137 KB of LDS traffic per slice,
+    // and LDS-pipe time is added to the slice like vector-ALU time.)
+    // ONE register set (round 6): group g's fragment of the NEXT slice is requested right behind the two MFMAs that consumed it, into
+    // the same registers -- a whole slice of MFMAs before its next use.  (Round 5 declared two sets, "a slice ahead into the other
+    // set"; at 128 registers hipcc folded them into one and sank all six requests to the END of the slice, in front of the barrier:
+    // the next slice's first MFMA then waited for an L2 round trip (`s_waitcnt vmcnt(5)` right behind the barrier), on all three
+    // waves of a SIMD at once.  The order is pinned with sched_group_barrier below.)
+    f32x2_w ureg[6];
     const unsigned u_voff = (unsigned)((((3 * wave) * kW4KS + kh) * kWinoBN + l31 * 2) * 4);
-#define RPN_W4_LOAD_U(SLICE, SET)                                                                                           \
-    _Pragma("unroll") for (int g = 0; g < 6; ++g)                                                                           \
-        ureg[SET][g] = __builtin_bit_cast(f32x2_w, __builtin_amdgcn_raw_buffer_load_b64(                                    \
-            urs, u_voff + (unsigned)((((g % 3) * kW4KS + 2 * (g / 3)) * kWinoBN) * 4), (SLICE) * kW4UFloats * 4, 0))
-#define RPN_W4_SLICE(S, SET)                                                                                                \
+#define RPN_W4_LOAD_U1(SLICE, G)                                                                                            \
+    ureg[G] = __builtin_bit_cast(f32x2_w, __builtin_amdgcn_raw_buffer_load_b64(                                             \
+        urs, u_voff + (unsigned)(((((G) % 3) * kW4KS + 2 * ((G) / 3)) * kWinoBN) * 4), (SLICE) * kW4UFloats * 4, 0))
+#define RPN_W4_SLICE(S)                                                                                                     \
     {                                                                                                                       \
         const int nxt_ = (S) + 1 < n_slices ? (S) + 1 : (S);          /* (past the end: the last slice again, unused) */    \
-        RPN_W4_LOAD_U(nxt_, (SET) ^ 1);                                                                                     \
         const float *V = Vs[(S) & 1];                                                                                       \
         float av[2];                                                                                                        \
         av[0] = V[((3 * wave) * kW4KS + kh) * 32 + l31];                                                                    \
         _Pragma("unroll") for (int g = 0; g < 6; ++g) {              /* group g = (k pair g / 3, xi j = g % 3) */           \
             if (g + 1 < 6) av[(g + 1) & 1] = V[((3 * wave + ((g + 1) % 3)) * kW4KS + 2 * ((g + 1) / 3) + kh) * 32 + l31];   \
-            __builtin_amdgcn_sched_barrier(kCross);                                                                         \
             const int j = g % 3;                                                                                            \
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[SET][g][0], acc[j][0], 0, 0, 0);               \
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[SET][g][1], acc[j][1], 0, 0, 0);               \
-            __builtin_amdgcn_sched_barrier(kCross);                                                                         \
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[g][0], acc[j][0], 0, 0, 0);                    \
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[g][1], acc[j][1], 0, 0, 0);                    \
+            RPN_W4_LOAD_U1(nxt_, g);                                                                                        \
+        }                                                                                                                   \
+        /* pipeline: two operand reads up front, then per group [2 MFMA, its filter request, the operand read of group g + 2] */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+            if (g + 2 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
         }                                                                                                                   \
         __syncthreads();                                                                                                    \
     }
-    constexpr int kCross = 0x2 | 0x4 | 0x10 | 0x200;
-    RPN_W4_LOAD_U(0, 0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) RPN_W4_LOAD_U1(0, g);
     __syncthreads();
     __syncthreads();
     {
         int s = 0;
         for (; s + 1 < n_slices; s += 2) {
-            RPN_W4_SLICE(s, 0);
-            RPN_W4_SLICE(s + 1, 1);
+            RPN_W4_SLICE(s);
+            RPN_W4_SLICE(s + 1);
         }
-        if (s < n_slices) RPN_W4_SLICE(s, 0);
+        if (s < n_slices) RPN_W4_SLICE(s);
     }
 #undef RPN_W4_SLICE
-#undef RPN_W4_LOAD_U
+#undef RPN_W4_LOAD_U1
 
     // ---- epilogue: park the 32 channels of N block ph ([xi 36][tile 32][32 channels] = 144 KB over the whole LDS block: the slice
     // loop's buffers are dead), then every thread transforms one (tile, channel) pair; the accumulators of the other N block stay in
@@ -888,6 +931,7 @@ constexpr int kWnBN = 128, kWnNT = 16, kWnPatch = 18, kWnPitch = 20, kWnPlane = 
 constexpr int kWnUFloats = kW4Xi * kW4KS * kWnBN;                        // 18432 floats = 72 KB per slice and N tile
 constexpr int kWnVFloats = kW4Xi * kW4KS * kWnNT;                        // 2304 floats = 9 KB
 static_assert(kWnPlane % 32 == 18, "raw plane stride");
+constexpr int kWnRawAt = 3 * kWnVFloats;                                 // LDS (ldsVR): three V buffers, then two raw-patch buffers
 
 size_t wino4n_weight_floats(int Cin, int Cout) { return (size_t)((Cout + kWnBN - 1) / kWnBN) * (Cin / kW4KS) * kWnUFloats; }
 
@@ -926,8 +970,11 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
     const float bias = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
     if (n >= a.Cout) return;
-#pragma unroll 1
-    for (int hp = 0; hp < 2; ++hp) {                      // two output rows at a time (see w4_output_pair)
+    // two output rows at a time (all four at once: 24 intermediates + 16 outputs + their store addresses beside the other N block's
+    // 48 live accumulators spill), as two STRAIGHT-LINE passes over the 36 parked values (round 5: `hp` a run-time loop, whose
+    // branch on hp inside the unrolled column loop cut the reads into twelve groups of six, each waited for at once)
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
         float R0[6], R1[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -943,6 +990,7 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
                 R1[j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                   // (the second pass's reads stay behind the first pass's stores)
         const int p = 2 * hp;
         float y0[4], y1[4];
         w4_at(R0, y0);
@@ -969,13 +1017,146 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
     }
 }
 
+// The staging role of the wide form (waves 12 .. 15, one per SIMD), one instantiation per wave: PART / HALF select the wave's QUARTER of
+// every (tile, channel) pair's 6 x 6 input transform (output rows 3 PART .. 3 PART + 2, output columns 3 HALF .. 3 HALF + 2).  As
+// run-time (wave-uniform) values they compiled into a branch around every 1-D transform with the patch reads issued two at a time
+// and waited for at once (`s_waitcnt lgkmcnt(1)`, `lgkmcnt(0)` eighteen times per slice): a staging wave's slice was a chain of
+// ~18 exposed LDS round trips.  As template parameters the slice is straight-line: 18 reads in flight, one wait.
+template <int PART, int HALF>
+__device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA, float *ldsVR, __amdgpu_buffer_rsrc_t xrs, int tid, int lane,
+                                                 int img, int oy0, int ox0, int n0, int n_slices)
+{
+    constexpr unsigned kOob = 0x80000000u;
+    const int hid = tid - 768;             // staging thread 0 .. 255
+    __builtin_amdgcn_s_setprio(3);                 // (see conv3x3_wino4_f32_kernel)
+    // a staging thread's pixels of a slice's raw patch (18 x 18 = 324 pixels, one 16-byte load = 4 channels each)
+    unsigned r_off[2];
+    int r_lds[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = hid + j * 256;
+        const int py = pix / kWnPatch, px = pix - py * kWnPatch;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = pix < kWnPatch * kWnPatch && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        r_lds[j] = py * kWnPitch + px;
+    }
+    const bool second = hid + 256 < kWnPatch * kWnPatch;
+    // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
+    // QUARTER of every pair's 6 x 6 transform -- output rows 3 part .. 3 part + 2, output columns 3 half .. 3 half + 2, part and half
+    // wave-uniform (no divergent halves) -- so that the transform's vector instructions, which take float32-MFMA time, are spread
+    // evenly over the four SIMDs (two waves doing halves loaded two SIMDs with all of it)
+    constexpr int t_part = PART, t_half = HALF;     // (template parameters: the staging waves' four streams are straight-line code)
+    const int t_tile = lane & 15, t_c = lane >> 4;
+    const int t_ty = t_tile >> 2, t_tx = t_tile & 3;
+    // (two register sets, a slice's patch requested two iterations before its transform: see conv3x3_wino4_f32_kernel)
+    u32x4_w rr[2][2] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
+#define RPN_WN_LOAD_RAW(SLICE, SET)                                                                                         \
+do {                                                                                                                    \
+    rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
+    rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros) */ \
+} while (0)
+#define RPN_WN_RAW_TO_LDS(BUF, SET)                                                                                         \
+{                                                                                                                       \
+    float *raw_ = ldsVR + kWnRawAt + (BUF) * (kW4KS * kWnPlane);                                                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                    \
+        if (j_ < 1 || second) {                                                                                         \
+            const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kWnPlane] = v_[i_];                  \
+        }                                                                                                               \
+}
+    auto transform = [&](int buf, int vofs) {            // raws[buf] -> V at float offset vofs (one of the three V buffers)
+        int ro = kWnRawAt + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx;
+        asm volatile("" : "+v"(ro));
+        const float *rp = ldsVR + ro;
+        float T[3][6];
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {
+            float d0[6], d1[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                d0[r] = rp[r * kWnPitch + 2 * jp];
+                d1[r] = rp[r * kWnPitch + 2 * jp + 1];
+            }
+            float t0[3], t1[3];
+            if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
+            else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
+        }
+        int vo = vofs + (18 * t_part + 3 * t_half) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
+        asm volatile("" : "+v"(vo));
+        float *vp = ldsVR + vo;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float v[3];
+            if (t_half == 0) w4_bt3<0>(T[i], v);
+            else w4_bt3<1>(T[i], v);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+        }
+    };
+    // Pipeline (round 6: one slice deeper, V triple-buffered, so that the MFMA waves can read slice s + 1's operands BEFORE the
+    // barrier that ends slice s and issue their first MFMA right behind it): slice t is requested in iteration t - 4 into register
+    // set t & 1, written to raws[t & 1] in iteration t - 3, transformed into V[t % 3] in iteration t - 2, read by the MFMA waves
+    // during iteration t - 1 and multiplied in iteration t.  Requests past the end are clamped to the last slice and the last
+    // iterations' transforms / writes work on stale data that nobody reads: the loop body has no conditions, so hipcc's counted
+    // waits stay exact.
+    const int last = n_slices - 1;
+    RPN_WN_LOAD_RAW(0, 0);
+    RPN_WN_RAW_TO_LDS(0, 0);
+    RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);
+    RPN_WN_LOAD_RAW(2 < last ? 2 : last, 0);
+    __syncthreads();                                                       // (A)
+    transform(0, 0);
+    RPN_WN_RAW_TO_LDS(1, 1);
+    RPN_WN_LOAD_RAW(3 < last ? 3 : last, 1);
+    __syncthreads();                                                       // (B)
+    transform(1, kWnVFloats);
+    RPN_WN_RAW_TO_LDS(0, 0);
+    __syncthreads();                                                       // (C): V[0], V[1] complete, slice 2 in raws[0], slice 3 requested
+#ifdef RPN_EXP_WN_NOSTAGE    /* timing experiment (wrong results): the staging waves only keep the barriers */
+#define RPN_WN_STAGE(S, SET) __syncthreads();
+#else
+#define RPN_WN_STAGE(S, SET)                                                                                                \
+{                                                                                                                       \
+    RPN_WN_LOAD_RAW((S) + 4 < last ? (S) + 4 : last, SET);                                                              \
+    transform(SET, vnext);                                           /* slice S + 2: raws[S & 1] -> V[(S + 2) % 3] */   \
+    RPN_WN_RAW_TO_LDS((SET) ^ 1, (SET) ^ 1);                         /* slice S + 3 */                                  \
+    vnext = vnext + kWnVFloats == 3 * kWnVFloats ? 0 : vnext + kWnVFloats;                                              \
+    RPN_WN_STAMP((S) < 28 ? 2 * (S) : 99);                                                                              \
+    __syncthreads();                                                                                                    \
+    RPN_WN_STAMP((S) < 28 ? 2 * (S) + 1 : 99);                                                                          \
+}
+#endif
+    {
+        int vnext = 2 * kWnVFloats;                                  // V buffer of slice s + 2
+        (void)vnext;
+        int s = 0;
+        for (; s + 1 < n_slices; s += 2) {
+            RPN_WN_STAGE(s, 0);
+            RPN_WN_STAGE(s + 1, 1);
+        }
+        if (s < n_slices) RPN_WN_STAGE(s, 0);
+    }
+#undef RPN_WN_STAGE
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        __syncthreads();                                         // the phase's accumulators are in LDS
+        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
+        __syncthreads();                                         // the staging area may be overwritten
+    }
+#undef RPN_WN_LOAD_RAW
+#undef RPN_WN_RAW_TO_LDS
+}
+
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
     // two arrays of 72 KB: the slice loop uses ldsVR only (V x 2: 18 KB, raw x 2: 11.6 KB); the epilogue parks the 36 x 16 x 64
     // accumulators of a phase (144 KB) over both: xi 0 .. 17 in ldsA, xi 18 .. 35 in ldsVR
     constexpr int kHalf = 18 * kWnNT * 64;                                 // floats per array
-    static_assert(2 * (kWnVFloats + kW4KS * kWnPlane) <= kHalf, "LDS layout");
+    static_assert(kWnRawAt + 2 * kW4KS * kWnPlane <= kHalf, "LDS layout");
     __shared__ __attribute__((aligned(16))) float ldsA[kHalf];
     __shared__ __attribute__((aligned(16))) float ldsVR[kHalf];
 
@@ -1004,117 +1185,12 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int k4 = lane >> 4, l15 = lane & 15;
 
     if (stager) {
-        __builtin_amdgcn_s_setprio(3);                 // (see conv3x3_wino4_f32_kernel)
-        // a staging thread's pixels of a slice's raw patch (18 x 18 = 324 pixels, one 16-byte load = 4 channels each)
-        unsigned r_off[2];
-        int r_lds[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pix = hid + j * 256;
-            const int py = pix / kWnPatch, px = pix - py * kWnPatch;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            const bool v = pix < kWnPatch * kWnPatch && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
-            r_lds[j] = py * kWnPitch + px;
-        }
-        const bool second = hid + 256 < kWnPatch * kWnPatch;
-        // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
-        // QUARTER of every pair's 6 x 6 transform -- output rows 3 part .. 3 part + 2, output columns 3 half .. 3 half + 2, part and half
-        // wave-uniform (no divergent halves) -- so that the transform's vector instructions, which take float32-MFMA time, are spread
-        // evenly over the four SIMDs (two waves doing halves loaded two SIMDs with all of it)
-        const int sw = wave - 12;
-        const int t_part = sw & 1, t_half = sw >> 1;
-        const int t_tile = lane & 15, t_c = lane >> 4;
-        const int t_ty = t_tile >> 2, t_tx = t_tile & 3;
-        // (two register sets, a slice's patch requested two iterations before its transform: see conv3x3_wino4_f32_kernel)
-        u32x4_w rr[2][2] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
-#define RPN_WN_LOAD_RAW(SLICE, SET)                                                                                         \
-    do {                                                                                                                    \
-        rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
-        rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros) */ \
-    } while (0)
-#define RPN_WN_RAW_TO_LDS(BUF, SET)                                                                                         \
-    {                                                                                                                       \
-        float *raw_ = ldsVR + 2 * kWnVFloats + (BUF) * (kW4KS * kWnPlane);                                                  \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                    \
-            if (j_ < 1 || second) {                                                                                         \
-                const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kWnPlane] = v_[i_];                  \
-            }                                                                                                               \
-    }
-        auto transform = [&](int buf) {
-            int ro = 2 * kWnVFloats + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx;
-            asm volatile("" : "+v"(ro));
-            const float *rp = ldsVR + ro;
-            float T[3][6];
-#pragma unroll
-            for (int jp = 0; jp < 3; ++jp) {
-                float d0[6], d1[6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    d0[r] = rp[r * kWnPitch + 2 * jp];
-                    d1[r] = rp[r * kWnPitch + 2 * jp + 1];
-                }
-                float t0[3], t1[3];
-                if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
-                else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
-            }
-            int vo = buf * kWnVFloats + (18 * t_part + 3 * t_half) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
-            asm volatile("" : "+v"(vo));
-            float *vp = ldsVR + vo;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float v[3];
-                if (t_half == 0) w4_bt3<0>(T[i], v);
-                else w4_bt3<1>(T[i], v);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
-            }
-        };
-        const int last = n_slices - 1;
-        RPN_WN_LOAD_RAW(0, 0);
-        RPN_WN_RAW_TO_LDS(0, 0);
-        RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
-        RPN_WN_LOAD_RAW(2 < last ? 2 : last, 0);
-        __syncthreads();
-        transform(0);
-        RPN_WN_RAW_TO_LDS(1, 1);
-        __syncthreads();
-#ifdef RPN_EXP_WN_NOSTAGE    /* timing experiment (wrong results): the staging waves only keep the barriers */
-#define RPN_WN_STAGE(S, SET) __syncthreads();
-#else
-#define RPN_WN_STAGE(S, SET)                                                                                                \
-    {                                                                                                                       \
-        if ((S) + 2 < n_slices) {                                                                                           \
-            RPN_WN_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
-            transform((SET) ^ 1);                                                                                           \
-            RPN_WN_RAW_TO_LDS(SET, SET);                                                                                    \
-        } else if ((S) + 1 < n_slices) {                                                                                    \
-            transform((SET) ^ 1);                                                                                           \
-        }                                                                                                                   \
-        __syncthreads();                                                                                                    \
-    }
-#endif
-        {
-            int s = 0;
-            for (; s + 1 < n_slices; s += 2) {
-                RPN_WN_STAGE(s, 0);
-                RPN_WN_STAGE(s + 1, 1);
-            }
-            if (s < n_slices) RPN_WN_STAGE(s, 0);
-        }
-#undef RPN_WN_STAGE
-#pragma unroll 1
-        for (int ph = 0; ph < 2; ++ph) {
-            __syncthreads();                                         // the phase's accumulators are in LDS
-            w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
-            __syncthreads();                                         // the staging area may be overwritten
-        }
+        const int sw = wave - 12;          // t_part = sw & 1, t_half = sw >> 1
+        if (sw == 0) w4n_staging_role<0, 0>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
+        else if (sw == 1) w4n_staging_role<1, 0>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
+        else if (sw == 2) w4n_staging_role<0, 1>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
+        else w4n_staging_role<1, 1>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
         return;
-#undef RPN_WN_LOAD_RAW
-#undef RPN_WN_RAW_TO_LDS
     }
 
     // ---- MFMA waves: xi = 3 wave + j, 16 tiles x 128 channels = eight 16 x 16 blocks per xi
@@ -1129,39 +1205,64 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const unsigned u_voff = (unsigned)(((3 * wave) * (kW4KS * kWnBN) + lane * 8) * 4);
 #define RPN_WN_LOAD_U(SLICE, J)                                                                                             \
     {                                                                                                                       \
-        ureg[J][0] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff + (unsigned)((J) * (kW4KS * kWnBN) * 4), (SLICE) * kWnUFloats * 4, 0));        \
-        ureg[J][1] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff + (unsigned)((J) * (kW4KS * kWnBN) * 4 + 16), (SLICE) * kWnUFloats * 4, 0));   \
+        /* (xi j's 2 KB step rides in the SCALAR offset: as a vector-offset constant beyond 4095 it cost an address register) */                                               \
+        ureg[J][0] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, (SLICE) * kWnUFloats * 4 + (J) * (kW4KS * kWnBN) * 4, 0));        \
+        ureg[J][1] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, (SLICE) * kWnUFloats * 4 + (J) * (kW4KS * kWnBN) * 4 + 16, 0));  \
     }
+    RPN_WN_STAMP(60);
     RPN_WN_LOAD_U(0, 0);
     RPN_WN_LOAD_U(0, 1);
     RPN_WN_LOAD_U(0, 2);
+    __syncthreads();                                                       // (A) (B) (C): see w4n_staging_role
     __syncthreads();
     __syncthreads();
+    RPN_WN_STAMP(61);
+    // Slice s's operands (3 values of V per lane, one per xi) are read during slice s - 1, in front of the barrier that ends it (V is
+    // triple-buffered and transformed two slices ahead): xi j's operand right behind xi j's MFMAs, INTO THE SAME REGISTER -- so the
+    // first MFMA of a slice issues right behind the barrier (its operand was read two thirds of a slice earlier; the last xi's
+    // read, issued in front of the barrier, has the next slice's first sixteen MFMAs to land).  Per slice the order is pinned: per
+    // xi its eight MFMAs, the next slice's two filter requests of THAT xi, its operand read.  (Left alone hipcc mixes the three xi
+    // and sinks the requests of two of them to the end of the slice, in front of the barrier, and the next slice then waits for
+    // them -- `s_waitcnt vmcnt(0)` behind its third MFMA: an L2 round trip exposed per slice on all three waves of a SIMD at once.)
+    const int v_lane = k4 * kWnNT + l15;
+    float av[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) av[j] = ldsVR[((3 * wave + j) * kW4KS) * kWnNT + v_lane];
+    int vcur = 0;
     for (int s = 0; s < n_slices; ++s) {
-        const float *V = ldsVR + (s & 1) * kWnVFloats;
 #ifdef RPN_EXP_WN_U0         /* timing experiment (wrong results): every filter request hits slice 0 */
         const int nxt = 0;
 #else
         const int nxt = s + 1 < n_slices ? s + 1 : s;                 // (past the end: the last slice again, unused)
 #endif
-        float av[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) av[j] = V[((3 * wave + j) * kW4KS + k4) * kWnNT + l15];
-        // (hipcc mixes the three xi and sinks the requests to the end of the slice, so the next slice starts with s_waitcnt vmcnt(0);
-        // forcing the order with full scheduling barriers measured 2 % SLOWER, with and without staging)
+        vcur = vcur + kWnVFloats == 3 * kWnVFloats ? 0 : vcur + kWnVFloats;       // V buffer of slice s + 1 (past the end: stale, unused)
+        const float *Vn = ldsVR + vcur;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
 #pragma unroll
-#ifdef RPN_EXP_WN_HALFMFMA   /* timing experiment (wrong results) */
-            for (int nb = 0; nb < 4; ++nb)
-#else
             for (int nb = 0; nb < 8; ++nb)
-#endif
                 acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ureg[j][nb >> 2][nb & 3], acc[j][nb], 0, 0, 0);
             if (j == 0) { RPN_WN_LOAD_U(nxt, 0); } else if (j == 1) { RPN_WN_LOAD_U(nxt, 1); } else { RPN_WN_LOAD_U(nxt, 2); }
+            av[j] = Vn[((3 * wave + j) * kW4KS) * kWnNT + v_lane];
         }
-        __syncthreads();
+#ifndef RPN_EXP_WN_NOSCHED
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
+        RPN_WN_STAMP(s < 28 ? 2 * s : 99);
+        // a bare barrier: this role writes no LDS in the loop, and its last operand read must NOT be waited for here (__syncthreads'
+        // fence would: `s_waitcnt lgkmcnt(0)`) -- the MFMAs that consume it sit in front of the next barrier, which is what keeps
+        // the staging waves from overwriting that V buffer (two iterations later) before it is read
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        RPN_WN_STAMP(s < 28 ? 2 * s + 1 : 99);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (the operand reads past the end: landed before LDS is re-used)
+    RPN_WN_STAMP(62);
 #undef RPN_WN_LOAD_U
 
     // ---- epilogue: two phases of 64 channels: park [xi 36][tile 16][64 channels] = 144 KB over both arrays, every thread transforms
