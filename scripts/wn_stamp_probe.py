@@ -37,6 +37,11 @@ def run(B, H, Cin, Cout):
     print("  (latest staging arrival) - (latest MFMA arrival): median %d [p10 %d p90 %d]" % (np.median(lag), *np.percentile(lag, [10, 90])))
     spread = arr[:, :12, 4:ns - 1].max(axis=1) - arr[:, :12, 4:ns - 1].min(axis=1)
     print("  MFMA waves' arrival spread: median %d [p90 %d]" % (np.median(spread), np.percentile(spread, 90)))
+    m = s[:, :12, :]
+    tot, pro, loop, epi = m[:, :, 63] - m[:, :, 60], m[:, :, 61] - m[:, :, 60], m[:, :, 62] - m[:, :, 61], m[:, :, 63] - m[:, :, 62]
+    rt = (m[:, :, 59] - m[:, :, 58]).astype(np.float64)          # s_memrealtime ticks of 10 ns
+    print("  per workgroup (MFMA waves, median): total %d = prologue %d + loop %d (%d per slice) + epilogue %d cycles;  in-kernel clock %.2f GHz" % (
+        np.median(tot), np.median(pro), np.median(loop), np.median(loop) / (Cin // 4), np.median(epi), np.median(tot / np.maximum(rt, 1.0)) * 0.1))
     w0 = s[0]
     print("  workgroup 0: entry->loop %d, loop %d (%d slices), per-wave first work:" % (np.median(w0[:12, 61] - w0[:12, 60]), np.median(w0[:12, 62] - w0[:12, 61]), Cin // 4),
           (arr[0, :, 5] - rel[0, :, 4]).tolist())

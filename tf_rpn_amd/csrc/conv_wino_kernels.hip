@@ -46,8 +46,14 @@ extern "C" int rpn_debug_read_wn_stamps(unsigned long long *out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wn_stamps), (size_t)n * 8);
 }
+#define RPN_WN_STAMP_RT(k)                                                                                 \
+    do {                                                                                                   \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64)                                                    \
+            g_wn_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define RPN_WN_STAMP(k) ((void)0)
+#define RPN_WN_STAMP_RT(k) ((void)0)
 #endif
 
 namespace rpn {
@@ -497,10 +503,85 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4])
     y[3] = __builtin_fmaf(8.0f, s, q) + m[5];
 }
 
+// The tail of an epilogue phase, shared by the F(4x4, 3x3) forms: a thread holds the 4 x 4 outputs y of one (tile, channel) pair and
+// writes them (+ bias, activation; `pool`: the 2 x 2 maxima).  Round 6: one epilogue phase was ~490 vector instructions per thread
+// (stamps: 20 k cycles of epilogue per workgroup, a quarter of a 128-channel layer) -- sixteen 64-bit address computations, a
+// scalar branch on `act` and an exec-mask branch per output.  Now: buffer stores whose per-(row, column) step rides in the SCALAR
+// offset (one 32-bit vector offset per thread), one branch on `act` for all sixteen values (ReLU = v_max), and the edge tests only
+// for tiles that cross the image border (`interior`: wave-uniform in the wide form, a ballot in the 64-channel form).
+// out_rs: the image's output tensor (H x W x Cout, or pooled); voff: byte offset of (oy, ox, n) (pooled: of (oy / 2, ox / 2, n)).
+__device__ __forceinline__ void w4_store_outputs(const WinoArgs &a, float (&y)[4][4], __amdgpu_buffer_rsrc_t out_rs, unsigned voff, int oy, int ox,
+                                                 float bias, bool interior)
+{
+    if (a.pool) {
+        const int PH = a.H >> 1, PW = a.W >> 1;
+        float v[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                v[i][j] = fmaxf(fmaxf(y[2 * i][2 * j], y[2 * i][2 * j + 1]), fmaxf(y[2 * i + 1][2 * j], y[2 * i + 1][2 * j + 1])) + bias;
+        if (a.act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) v[i][j] = fmaxf(v[i][j], 0.0f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) v[i][j] = wino_act(v[i][j], a.act);
+        }
+        const int row = PW * a.Cout * 4, col = a.Cout * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (interior || ((oy >> 1) + i < PH && (ox >> 1) + j < PW))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i][j]), out_rs, voff, i * row + j * col, 0);
+        return;
+    }
+    if (a.act == ACT_RELU) {                              // (v_max: a NaN becomes 0, as with `v > 0 ? v : 0`)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[p][q] = fmaxf(y[p][q] + bias, 0.0f);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[p][q] = wino_act(y[p][q] + bias, a.act);
+    }
+    const int row = a.W * a.Cout * 4, col = a.Cout * 4;
+    if (interior) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[p][q]), out_rs, voff, p * row + q * col, 0);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (oy + p < a.H && ox + q < a.W)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[p][q]), out_rs, voff, p * row + q * col, 0);
+    }
+}
+
+// the image's output tensor as a buffer (launch_conv3x3_wino checks that it is below 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_out_rsrc(const WinoArgs &a, int img)
+{
+    const int OH = a.pool ? a.H >> 1 : a.H, OW = a.pool ? a.W >> 1 : a.W;
+    return __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * OH * OW * a.Cout, (short)0, OH * OW * a.Cout * 4, 0x00020000);
+}
+
 // Output transform of one (tile, channel) pair of an epilogue phase: thread -> (channel = tid & 31, tile = tid >> 5); MsA / MsB = the parked
-// accumulators [xi][tile][32] of xi 0 .. 17 / 18 .. 35; Y = A^T M A, + bias, activation, 128-byte NHWC stores (or the 2 x 2 max of the pooled form).
+// accumulators [xi][tile][32] of xi 0 .. 17 / 18 .. 35; Y = A^T M A in ONE pass over the 36 parked values: column j's six values ->
+// R[0..3][j] = A^T m, then the four column transforms.  (Round 5 made two passes of two output rows each under a run-time loop,
+// whose branch inside the unrolled column loop cut the reads into twelve groups of six, each waited for at once.)
 __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0,
-                                               bool split, __amdgpu_buffer_rsrc_t part_rs)
+                                               bool split, __amdgpu_buffer_rsrc_t part_rs, __amdgpu_buffer_rsrc_t out_rs)
 {
     const int e_n = tid & 31, e_tile = tid >> 5;
     const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
@@ -509,56 +590,34 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
     const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
     if (n >= a.Cout) return;
     constexpr int kSc1 = 16;                                             // cache-policy bit 4 = sc1 (device scope, write-through)
-    // two output rows at a time, as two STRAIGHT-LINE passes over the 36 parked values (see w4n_output_pair)
+    float R[4][6];
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {
-        float R0[6], R1[6];
+    for (int j = 0; j < 6; ++j) {
+        float m[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float m[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * 32 + e_tile) * 32 + e_n];     // xi = 6 i + j
-            const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
-            if (hp == 0) {
-                R0[j] = m[0] + pp + rr;
-                R1[j] = __builtin_fmaf(2.0f, ss, qq);
-            } else {
-                R0[j] = __builtin_fmaf(4.0f, rr, pp);
-                R1[j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int p = 2 * hp;
-        float y0[4], y1[4];
-        w4_at(R0, y0);
-        w4_at(R1, y1);
-        if (split) {                                                     // K split: the raw partial tile [16 x 32 pixels][64 channels]
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pix = (4 * e_ty + p) * 32 + 4 * e_tx + q;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0[q]), part_rs, (pix * kWinoBN + ph * 32 + e_n) * 4, 0, kSc1);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1[q]), part_rs, ((pix + 32) * kWinoBN + ph * 32 + e_n) * 4, 0, kSc1);
-            }
-        } else if (a.pool) {
-            const int PH = a.H >> 1, PW = a.W >> 1, py = (oy + p) >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; q += 2) {
-                const int px = (ox + q) >> 1;
-                if (py < PH && px < PW) {
-                    const float v = fmaxf(fmaxf(y0[q], y0[q + 1]), fmaxf(y1[q], y1[q + 1]));
-                    a.out[(((size_t)img * PH + py) * PW + px) * a.Cout + n] = wino_act(v + bias, a.act);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (oy + p < a.H && ox + q < a.W)
-                    a.out[(((size_t)img * a.H + oy + p) * a.W + ox + q) * a.Cout + n] = wino_act(y0[q] + bias, a.act);
-                if (oy + p + 1 < a.H && ox + q < a.W)
-                    a.out[(((size_t)img * a.H + oy + p + 1) * a.W + ox + q) * a.Cout + n] = wino_act(y1[q] + bias, a.act);
-            }
-        }
+        for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * 32 + e_tile) * 32 + e_n];     // xi = 6 i + j
+        const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
+        R[0][j] = m[0] + pp + rr;
+        R[1][j] = __builtin_fmaf(2.0f, ss, qq);
+        R[2][j] = __builtin_fmaf(4.0f, rr, pp);
+        R[3][j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
     }
+    float y[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w4_at(R[p], y[p]);
+    if (split) {                                                         // K split: the raw partial tile [16 x 32 pixels][64 channels]
+        const unsigned pv = (unsigned)((((4 * e_ty) * 32 + 4 * e_tx) * kWinoBN + ph * 32 + e_n) * 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[p][q]), part_rs, pv, ((p * 32 + q) * kWinoBN) * 4, kSc1);
+        return;
+    }
+    const bool inside = a.pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);
+    const bool interior = __builtin_amdgcn_ballot_w64(!inside) == 0ull;    // (a wave holds two tiles here)
+    const unsigned voff = a.pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
+    w4_store_outputs(a, y, out_rs, voff, oy, ox, bias, interior);
 }
 
 // K split, after the workgroup's partial tile is written: take the tile's ticket; the LAST of the two arrivers adds the halves in
@@ -698,17 +757,16 @@ do {                                                                            
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kW4Plane] = v_[i_];                  \
         }                                                                                                               \
 }
-    auto transform = [&](int buf) {
+    auto transform = [&](int buf, int vofs) {               // raws[buf] (in ldsU) -> V at float offset vofs of ldsVR (one of three buffers)
         // T = B^T d over the patch rows for the three output rows of this part, then V = T B along the columns
-        // (one opaque index, constants behind it: the reads keep the alias scope of ldsVR -- see conv3x3_wino_f32_kernel)
         // Bank skew: tile columns are 4 floats apart and four tile rows 144 = 16 (mod 32) floats, so the 32 tiles of a wave's
         // 8-byte read would fall on 16 of the 32 banks; patch rows 4 .. 7, 12 .. 15 are stored two floats to the right
         // (raw_to_lds), which puts odd tile rows on the other 16.  A tile's rows 4, 5 belong to the next tile row: second base.
-        int ro = 2 * kW4VFloats + buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
+        int ro = buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
         int ro45 = ro + 2 - (t_ty & 1) * 4;
         asm volatile("" : "+v"(ro), "+v"(ro45));
-        const float *rp = ldsVR + ro;
-        const float *rp45 = ldsVR + ro45;
+        const float *rp = ldsU + ro;
+        const float *rp45 = ldsU + ro45;
         float T[3][6];
 #pragma unroll
         for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
@@ -724,8 +782,8 @@ do {                                                                            
 #pragma unroll
             for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
         }
-        int vo = buf * kW4VFloats + (18 * t_part) * (kW4KS * 32) + t_c * 32 + t_tile;      // (opaque for the same reason: the writes
-        asm volatile("" : "+v"(vo));                                                         // need not wait for the DMA either)
+        int vo = vofs + (18 * t_part) * (kW4KS * 32) + t_c * 32 + t_tile;
+        asm volatile("" : "+v"(vo));
         float *vp = ldsVR + vo;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -737,29 +795,40 @@ do {                                                                            
     };
     // (Touching the filter slice three ahead -- one 128-byte line per staging thread, results unused, left in flight by a counted
     // wait -- to turn the LDS-DMA's Infinity-Cache / HBM misses into L2 hits measured SLOWER: 1 717 -> 1 639 images/s.)
+    // Pipeline as in w4n_staging_role: slice t is requested in iteration t - 4 (register set t & 1), written to raws[t & 1] in
+    // iteration t - 3, transformed into V[t % 3] in iteration t - 2, read by the MFMA waves during iteration t - 1, multiplied in
+    // iteration t; no conditions in the loop body (requests clamped to the last slice, the tail works on stale data nobody reads).
     const int last = n_slices - 1;
     RPN_W4_LOAD_RAW(0, 0);
+    RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);
+    u32x4_w p2[3], p3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        p2[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[j], (2 < last ? 2 : last) * kW4KS * 4, 0);
+        p3[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[j], (3 < last ? 3 : last) * kW4KS * 4, 0);
+    }
     RPN_W4_RAW_TO_LDS(0, 0);
-    RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);                      // (clamped requests past the end: the last slice again, unused)
-    RPN_W4_LOAD_RAW(2 < last ? 2 : last, 0);
-    __syncthreads();
-    transform(0);
     RPN_W4_RAW_TO_LDS(1, 1);
-    __syncthreads();
-    // iteration s (between its barriers the MFMA waves run slice s): request slice s + 3 into the set slice s + 1 has left,
-    // transform slice s + 1 (raws[(s + 1) & 1] -> V[(s + 1) & 1]), write slice s + 2 (requested an iteration ago) to raws[s & 1]
+    __syncthreads();                                                       // (A)
+    transform(0, 0);
+    transform(1, kW4VFloats);
+    __syncthreads();                                                       // (B)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rr[0][j] = p2[j];
+    RPN_W4_RAW_TO_LDS(0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rr[1][j] = p3[j];
+    __syncthreads();                                                       // (C): V[0], V[1] complete, slice 2 in raws[0], slice 3 in register set 1
 #define RPN_W4_STAGE(S, SET)                                                                                                \
 {                                                                                                                       \
-    if ((S) + 2 < n_slices) {                                                                                           \
-        RPN_W4_LOAD_RAW((S) + 3 < last ? (S) + 3 : last, (SET) ^ 1);                                                    \
-        transform((SET) ^ 1);                                                                                           \
-        RPN_W4_RAW_TO_LDS(SET, SET);                                                                                    \
-    } else if ((S) + 1 < n_slices) {                                                                                    \
-        transform((SET) ^ 1);                                                                                           \
-    }                                                                                                                   \
+    RPN_W4_LOAD_RAW((S) + 4 < last ? (S) + 4 : last, SET);                                                              \
+    transform(SET, vnext);                                           /* slice S + 2: raws[S & 1] -> V[(S + 2) % 3] */   \
+    RPN_W4_RAW_TO_LDS((SET) ^ 1, (SET) ^ 1);                         /* slice S + 3 */                                  \
+    vnext = vnext + kW4VFloats == 3 * kW4VFloats ? 0 : vnext + kW4VFloats;                                              \
     __syncthreads();                                                                                                    \
 }
     {
+        int vnext = 2 * kW4VFloats;                                  // V buffer of slice s + 2
         int s = 0;
         for (; s + 1 < n_slices; s += 2) {
             RPN_W4_STAGE(s, 0);
@@ -772,7 +841,7 @@ do {                                                                            
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         __syncthreads();                                         // the phase's accumulators are in LDS
-        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
+        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
         __syncthreads();                                         // the staging area may be overwritten
     }
     if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
@@ -788,11 +857,11 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     // by LDS-DMA into ldsU: hipcc's waitcnt pass lets an LDS access overtake an LDS-DMA in flight only when the two carry the alias
     // scopes of DIFFERENT __shared__ arrays.)
     constexpr int kW4Half = 18 * 32 * 32;                                  // floats per array
-    static_assert(2 * kW4UFloats == kW4Half && 2 * (kW4VFloats + kW4KS * kW4Plane) <= kW4Half, "LDS layout");
+    static_assert(3 * kW4VFloats <= kW4Half && 2 * kW4KS * kW4Plane <= kW4Half, "LDS layout");
     __shared__ __attribute__((aligned(16))) float ldsU[kW4Half];
     __shared__ __attribute__((aligned(16))) float ldsVR[kW4Half];
-    float (*Vs)[kW4VFloats] = reinterpret_cast<float (*)[kW4VFloats]>(ldsVR);
-    float (*raws)[kW4KS * kW4Plane] = reinterpret_cast<float (*)[kW4KS * kW4Plane]>(ldsVR + 2 * kW4VFloats);
+    // slice loop (round 6): V x 3 in ldsVR (54 KB), the raw patch x 2 in ldsU (21 KB; the filters no longer pass through LDS)
+    float (*raws)[kW4KS * kW4Plane] = reinterpret_cast<float (*)[kW4KS * kW4Plane]>(ldsU);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -856,41 +925,45 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #define RPN_W4_LOAD_U1(SLICE, G)                                                                                            \
     ureg[G] = __builtin_bit_cast(f32x2_w, __builtin_amdgcn_raw_buffer_load_b64(                                             \
         urs, u_voff + (unsigned)(((((G) % 3) * kW4KS + 2 * ((G) / 3)) * kWinoBN) * 4), (SLICE) * kW4UFloats * 4, 0))
-#define RPN_W4_SLICE(S)                                                                                                     \
-    {                                                                                                                       \
-        const int nxt_ = (S) + 1 < n_slices ? (S) + 1 : (S);          /* (past the end: the last slice again, unused) */    \
-        const float *V = Vs[(S) & 1];                                                                                       \
-        float av[2];                                                                                                        \
-        av[0] = V[((3 * wave) * kW4KS + kh) * 32 + l31];                                                                    \
-        _Pragma("unroll") for (int g = 0; g < 6; ++g) {              /* group g = (k pair g / 3, xi j = g % 3) */           \
-            if (g + 1 < 6) av[(g + 1) & 1] = V[((3 * wave + ((g + 1) % 3)) * kW4KS + 2 * ((g + 1) / 3) + kh) * 32 + l31];   \
-            const int j = g % 3;                                                                                            \
-            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[g][0], acc[j][0], 0, 0, 0);                    \
-            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1], ureg[g][1], acc[j][1], 0, 0, 0);                    \
-            RPN_W4_LOAD_U1(nxt_, g);                                                                                        \
-        }                                                                                                                   \
-        /* pipeline: two operand reads up front, then per group [2 MFMA, its filter request, the operand read of group g + 2] */ \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                                  \
-        _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
-            if (g + 2 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-        }                                                                                                                   \
-        __syncthreads();                                                                                                    \
-    }
+    // Slice s's six operand values (one per group g = (k pair, xi)) are read during slice s - 1, in front of the barrier that ends it
+    // (V triple-buffered, transformed two slices ahead): xi j's two operands right behind its second group's MFMAs, into the same
+    // registers -- so a slice's first MFMA issues right behind the barrier.  Order pinned per group: 2 MFMAs, the filter request,
+    // (groups 3 .. 5) the operand reads.
+    const int v_lane = kh * 32 + l31;
+    float av[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) RPN_W4_LOAD_U1(0, g);
+    __syncthreads();                                                       // (A) (B) (C): see w4_staging_role
     __syncthreads();
     __syncthreads();
-    {
-        int s = 0;
-        for (; s + 1 < n_slices; s += 2) {
-            RPN_W4_SLICE(s);
-            RPN_W4_SLICE(s + 1);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) av[g] = ldsVR[((3 * wave + (g % 3)) * kW4KS + 2 * (g / 3)) * 32 + v_lane];
+    int vcur = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const int nxt = s + 1 < n_slices ? s + 1 : s;                      // (past the end: the last slice again, unused)
+        vcur = vcur + kW4VFloats == 3 * kW4VFloats ? 0 : vcur + kW4VFloats;   // V buffer of slice s + 1 (past the end: stale, unused)
+        const float *Vn = ldsVR + vcur;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {                                      // group g = (k pair g / 3, xi j = g % 3)
+            const int j = g % 3;
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], ureg[g][0], acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], ureg[g][1], acc[j][1], 0, 0, 0);
+            RPN_W4_LOAD_U1(nxt, g);
+            if (g >= 3) {            // xi j's two operands (k pairs 0, 1: one ds_read2) once both of its groups have issued
+                av[g - 3] = Vn[((3 * wave + j) * kW4KS) * 32 + v_lane];
+                av[g] = Vn[((3 * wave + j) * kW4KS + 2) * 32 + v_lane];
+            }
         }
-        if (s < n_slices) RPN_W4_SLICE(s);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (g >= 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_s_barrier();                                      // (bare: see conv3x3_wino4n_f32_kernel)
+        __builtin_amdgcn_sched_barrier(0);
     }
-#undef RPN_W4_SLICE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (the operand reads past the end: landed before LDS is re-used)
 #undef RPN_W4_LOAD_U1
 
     // ---- epilogue: park the 32 channels of N block ph ([xi 36][tile 32][32 channels] = 144 KB over the whole LDS block: the slice
@@ -910,7 +983,7 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             }
         }
         __syncthreads();
-        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs);
+        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
         __syncthreads();
     }
     if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
@@ -961,60 +1034,35 @@ void pack_weights_wino4n_host(const float *hwio, const float *scale, int Cin, in
 }
 
 // output transform of one (tile, channel) pair of an epilogue phase of the wide form: thread -> (channel = tid & 63 of the phase's
-// 64, tile = tid >> 6); MsA / MsB = the parked accumulators [xi][16 tiles][64 channels] of xi 0 .. 17 / 18 .. 35
-__device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0)
+// 64, tile = tid >> 6: one tile per WAVE); MsA / MsB = the parked accumulators [xi][16 tiles][64 channels] of xi 0 .. 17 / 18 .. 35;
+// one pass over the 36 values (see w4_output_pair)
+__device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *MsA, const float *MsB, int tid, int ph, int img, int oy0, int ox0, int n0,
+                                                __amdgpu_buffer_rsrc_t out_rs)
 {
-    const int e_n = tid & 63, e_tile = tid >> 6;
+    const int e_n = tid & 63, e_tile = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e_ty = e_tile >> 2, e_tx = e_tile & 3;
     const int n = n0 + ph * 64 + e_n;
     const float bias = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
     const int oy = oy0 + 4 * e_ty, ox = ox0 + 4 * e_tx;
     if (n >= a.Cout) return;
-    // two output rows at a time (all four at once: 24 intermediates + 16 outputs + their store addresses beside the other N block's
-    // 48 live accumulators spill), as two STRAIGHT-LINE passes over the 36 parked values (round 5: `hp` a run-time loop, whose
-    // branch on hp inside the unrolled column loop cut the reads into twelve groups of six, each waited for at once)
+    float R[4][6];
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {
-        float R0[6], R1[6];
+    for (int j = 0; j < 6; ++j) {
+        float m[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float m[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * kWnNT + e_tile) * 64 + e_n];     // xi = 6 i + j
-            const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
-            if (hp == 0) {
-                R0[j] = m[0] + pp + rr;
-                R1[j] = __builtin_fmaf(2.0f, ss, qq);
-            } else {
-                R0[j] = __builtin_fmaf(4.0f, rr, pp);
-                R1[j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);                   // (the second pass's reads stay behind the first pass's stores)
-        const int p = 2 * hp;
-        float y0[4], y1[4];
-        w4_at(R0, y0);
-        w4_at(R1, y1);
-        if (a.pool) {
-            const int PH = a.H >> 1, PW = a.W >> 1, py = (oy + p) >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; q += 2) {
-                const int px = (ox + q) >> 1;
-                if (py < PH && px < PW) {
-                    const float v = fmaxf(fmaxf(y0[q], y0[q + 1]), fmaxf(y1[q], y1[q + 1]));
-                    a.out[(((size_t)img * PH + py) * PW + px) * a.Cout + n] = wino_act(v + bias, a.act);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (oy + p < a.H && ox + q < a.W)
-                    a.out[(((size_t)img * a.H + oy + p) * a.W + ox + q) * a.Cout + n] = wino_act(y0[q] + bias, a.act);
-                if (oy + p + 1 < a.H && ox + q < a.W)
-                    a.out[(((size_t)img * a.H + oy + p + 1) * a.W + ox + q) * a.Cout + n] = wino_act(y1[q] + bias, a.act);
-            }
-        }
+        for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * kWnNT + e_tile) * 64 + e_n];     // xi = 6 i + j
+        const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
+        R[0][j] = m[0] + pp + rr;
+        R[1][j] = __builtin_fmaf(2.0f, ss, qq);
+        R[2][j] = __builtin_fmaf(4.0f, rr, pp);
+        R[3][j] = __builtin_fmaf(8.0f, ss, qq) + m[5];
     }
+    float y[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w4_at(R[p], y[p]);
+    const bool interior = a.pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);   // wave-uniform
+    const unsigned voff = a.pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
+    w4_store_outputs(a, y, out_rs, voff, oy, ox, bias, interior);
 }
 
 // The staging role of the wide form (waves 12 .. 15, one per SIMD), one instantiation per wave: PART / HALF select the wave's QUARTER of
@@ -1103,18 +1151,25 @@ do {                                                                            
     // iterations' transforms / writes work on stale data that nobody reads: the loop body has no conditions, so hipcc's counted
     // waits stay exact.
     const int last = n_slices - 1;
+    // prologue: the first FOUR slices requested at once (one memory latency, not three dependent ones: round 6's deeper pipeline had
+    // taken the kernel's entry -> loop time from 5.5 k to 8.4 k cycles); slices 2, 3 wait in two more register sets
     RPN_WN_LOAD_RAW(0, 0);
-    RPN_WN_RAW_TO_LDS(0, 0);
     RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);
-    RPN_WN_LOAD_RAW(2 < last ? 2 : last, 0);
+    u32x4_w p2[2], p3[2];
+    p2[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (2 < last ? 2 : last) * kW4KS * 4, 0);
+    p2[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (2 < last ? 2 : last) * kW4KS * 4, 0);
+    p3[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (3 < last ? 3 : last) * kW4KS * 4, 0);
+    p3[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (3 < last ? 3 : last) * kW4KS * 4, 0);
+    RPN_WN_RAW_TO_LDS(0, 0);
+    RPN_WN_RAW_TO_LDS(1, 1);
     __syncthreads();                                                       // (A)
     transform(0, 0);
-    RPN_WN_RAW_TO_LDS(1, 1);
-    RPN_WN_LOAD_RAW(3 < last ? 3 : last, 1);
-    __syncthreads();                                                       // (B)
     transform(1, kWnVFloats);
+    __syncthreads();                                                       // (B)
+    rr[0][0] = p2[0]; rr[0][1] = p2[1];
     RPN_WN_RAW_TO_LDS(0, 0);
-    __syncthreads();                                                       // (C): V[0], V[1] complete, slice 2 in raws[0], slice 3 requested
+    rr[1][0] = p3[0]; rr[1][1] = p3[1];
+    __syncthreads();                                                       // (C): V[0], V[1] complete, slice 2 in raws[0], slice 3 in register set 1
 #ifdef RPN_EXP_WN_NOSTAGE    /* timing experiment (wrong results): the staging waves only keep the barriers */
 #define RPN_WN_STAGE(S, SET) __syncthreads();
 #else
@@ -1143,7 +1198,7 @@ do {                                                                            
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         __syncthreads();                                         // the phase's accumulators are in LDS
-        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
+        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
         __syncthreads();                                         // the staging area may be overwritten
     }
 #undef RPN_WN_LOAD_RAW
@@ -1210,6 +1265,7 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         ureg[J][1] = __builtin_bit_cast(f32x4_w, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, (SLICE) * kWnUFloats * 4 + (J) * (kW4KS * kWnBN) * 4 + 16, 0));  \
     }
     RPN_WN_STAMP(60);
+    RPN_WN_STAMP_RT(58);
     RPN_WN_LOAD_U(0, 0);
     RPN_WN_LOAD_U(0, 1);
     RPN_WN_LOAD_U(0, 2);
@@ -1279,9 +1335,11 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
                 for (int r = 0; r < 4; ++r) park[(xi * kWnNT + 4 * k4 + r) * 64 + q * 16 + l15] = acc[j][4 * ph + q][r];
         }
         __syncthreads();
-        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0);
+        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
         __syncthreads();
     }
+    RPN_WN_STAMP(63);
+    RPN_WN_STAMP_RT(59);
 }
 #undef RPN_WINO_LDS_PTR
 
@@ -1337,7 +1395,7 @@ size_t wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int variant)
 bool wino_launchable(int B, int H, int W, int Cin, int Cout, int variant)
 {
     if (!wino_supported(Cin, Cout) || B < 1 || H < 1 || W < 1 || (variant != 2 && variant != 4 && variant != 8 && variant != 16)) return false;
-    if ((long long)H * W * Cin * 4 > 0x7fffffffll) return false;
+    if ((long long)H * W * Cin * 4 > 0x7fffffffll || (long long)H * W * Cout * 4 > 0x7fffffffll) return false;   // 32-bit buffer offsets per image, input and output
     if (variant == 8 && (Cin / kW4KS < 2 || wino4_tiles(B, H, W, Cout) > kW4Tickets)) return false;
     if (variant == 16 && Cout % kWnBN != 0) return false;
     return true;
