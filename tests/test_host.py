@@ -73,9 +73,9 @@ KERNEL_BUDGETS = {
     r"conv_igemm_f32_dma<2,2,2,2,(false|true)>": (96, 0, 32768),        # five 4-wave workgroups per CU
     r"conv_igemm_f32<2,2,2,2,false,(false|true)>": (128, 0, 33024),     # four
     r"conv_igemm_f32(_dma)?<4,1,1,[12],": (80, 0, 24832),               # six
-    r"conv3x3_split16_dma_kernel<(false|true),(false|true),128,false>": (256, 44, 163840),   # one 8-wave workgroup, 2 waves / SIMD: the cliff is 256 (round 6, halo_swz = hx & 6: 247-249, was 226-227)
-    r"conv3x3_split16_dma_kernel<(false|true),(false|true),64,false>": (176, 40, 113664),
-    r"conv3x3_split16_dma_kernel<(false|true),false,64,true>": (240, 76, 113664),            # K-tree fold: two more accumulator sets
+    r"conv3x3_split16_dma_kernel<(false|true),(false|true),128,false>": (256, 52, 163840),   # one 8-wave workgroup, 2 waves / SIMD: the cliff is 256 (round 6, halo_swz = hx & 6: 247-249, was 226-227)
+    r"conv3x3_split16_dma_kernel<(false|true),(false|true),64,false>": (176, 52, 113664),
+    r"conv3x3_split16_dma_kernel<(false|true),false,64,true>": (240, 88, 113664),            # K-tree fold: two more accumulator sets
     r"conv3x3_split16_kernel<8,2,8,": (240, 0, 136448),
     r"nms_kernel<(false|true)>": (128, 104, 0),                          # 1024 threads = 4 waves per SIMD (dynamic LDS); SGPR spills go to VGPR lanes
     r"stem_block_kernel<8>": (96, 0, 27648),                             # five workgroups per CU

@@ -525,39 +525,44 @@ conv3x3_split_kernel(SplitConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
     const int cout_chunks = a.Cout >> 4;
     const int nbase = n0 + wn * (NI * 32);                             // first channel of this wave's 64
-    // write NPX staged pixels x 64 channels of output row `oy` (output image OHo x OWo, first column oxb)
+    // write NPX staged pixels x 64 channels of output row `oy` (output image OHo x OWo, first column oxb): one buffer per row
+    // segment [oxb, OWo), a lane owns eight channels of a pixel and writes their hi and lo pieces (split16_epilogue has the why)
+    const int pix_bytes = a.out_f32 ? a.Cout * 4 : cout_chunks * 64;
     auto store_stage = [&](int npx_log2, int oy, int oxb, int OHo, int OWo) {
         if (oy >= OHo) return;
-        const int rounds = (16 << npx_log2) >> 6;                      // (npx * 16 pieces) / 64 lanes
+        const long long row_off = (((long long)img * OHo + oy) * OWo + oxb) * (long long)pix_bytes;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.out) + row_off, (short)0,
+                                                                              (OWo - oxb) * pix_bytes, 0x00020000);
         if (a.out_f32) {
-            float *out = reinterpret_cast<float *>(a.out);
+            const int rounds = (16 << npx_log2) >> 6;                  // (npx * 16 float4s) / 64 lanes
+            const int px_l = lane >> 4, q_l = lane & 15;
+            const int n = nbase + 4 * q_l;
+            unsigned voff = n < a.Cout ? (unsigned)(px_l * pix_bytes + n * 4) : 0x80000000u;
+#pragma unroll
             for (int rd = 0; rd < rounds; ++rd) {
-                const int e = rd * 64 + lane;
-                const int px = e >> 4, q = e & 15;
-                const int ox = oxb + px, n = nbase + 4 * q;
-                if (ox < OWo && n < a.Cout) {
-                    const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
-                    *reinterpret_cast<float4 *>(out + (((size_t)img * OHo + oy) * OWo + ox) * a.Cout + n) = v;
-                }
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&stage[(rd * 4 + px_l) * STAGE_LD + 4 * q_l]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
+                voff += (unsigned)(4 * pix_bytes);
             }
         } else {
-            uint4 *out = reinterpret_cast<uint4 *>(a.out);
-            for (int rd = 0; rd < rounds; ++rd) {
-                const int e = rd * 64 + lane;
-                const int px = e >> 4, q = e & 15;                     // q: 16-slice (q >> 2), piece (q & 3)
-                const int ox = oxb + px;
-                const int cl = q >> 2, pc = q & 3;
-                const int n = nbase + cl * 16;
-                if (ox < OWo && n < a.Cout) {
-                    float xs[8];
-                    const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
-                    const float4 v0 = *reinterpret_cast<const float4 *>(src);
-                    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
-                    xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-                    out[((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc] =
-                        split_piece<F16>(xs, (pc & 1) != 0, a.status);
-                }
+            const int rounds2 = (8 << npx_log2) >> 6;                  // (npx * 8 lanes) / 64
+            const int px2 = lane >> 3, q2 = lane & 7;
+            const int cl = q2 >> 1, hf = q2 & 1;
+            const int n = nbase + cl * 16;
+            unsigned voff = n < a.Cout ? (unsigned)(px2 * pix_bytes + (n >> 4) * 64 + hf * 32) : 0x80000000u;
+#pragma unroll
+            for (int rd = 0; rd < rounds2; ++rd) {
+                float xs[8];
+                const float *src = &stage[(rd * 8 + px2) * STAGE_LD + cl * 16 + hf * 8];
+                const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                const u32x4 hi = __builtin_bit_cast(u32x4, split_piece<F16>(xs, false, a.status));
+                const u32x4 lo = __builtin_bit_cast(u32x4, split_piece<F16>(xs, true, nullptr));
+                __builtin_amdgcn_raw_buffer_store_b128(hi, ors, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, ors, voff + 16u, 0, 0);
+                voff += (unsigned)(8 * pix_bytes);
             }
         }
     };
@@ -647,38 +652,64 @@ __device__ __forceinline__ void split16_epilogue(f32x4 (&acc)[RW * 2][NJ], float
     const float act_hi = a.act == ACT_RELU6 ? 6.0f : INFINITY;
     const int cout_chunks = a.Cout >> 4;
     const int nbase = n0 + wn * CW;
+    // Stores (round 6): one buffer per output ROW SEGMENT [oxb, OWo) of the image -- a pixel past the right edge is past the buffer's
+    // end and the hardware drops it, a lane whose channels lie beyond Cout carries an out-of-range offset -- so a round is two LDS
+    // reads, the hi / lo split and ONE buffer store whose 32-bit offset advances by a constant: no branch, no 64-bit index
+    // arithmetic, no integer multiply.  (Rounds 1-5 recomputed (((img * OH + oy) * OW + ox) * chunks + n / 16) * 4 + pc in 64 bits
+    // and branched on ox < OW && n < Cout in every round: ~100 v_mul_lo_u32 / v_lshl_add_u64 / v_mad_u64_u32 and 92 exec branches per
+    // tile and thread -- a third of the epilogue's 2 600 vector instructions.)
+    const int pix_bytes = a.out_f32 ? a.Cout * 4 : cout_chunks * 64;       // bytes per output pixel
+    constexpr int PXR = 64 / PP;                                          // pixels per round of 64 lanes
+    const int px_l = lane / PP, q_l = lane % PP;
     auto store_stage = [&](int npx_log2, int oy, int oxb, int OHo, int OWo) {
         if (oy >= OHo) return;
         const int rounds = (PP << npx_log2) >> 6;
+        const long long row_off = (((long long)img * OHo + oy) * OWo + oxb) * (long long)pix_bytes;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.out) + row_off, (short)0,
+                                                                              (OWo - oxb) * pix_bytes, 0x00020000);
         if (a.out_f32) {
-            float *out = reinterpret_cast<float *>(a.out);
+            const int n = nbase + 4 * q_l;
+            unsigned voff = n < a.Cout ? (unsigned)(px_l * pix_bytes + n * 4) : 0x80000000u;
+#pragma unroll
             for (int rd = 0; rd < rounds; ++rd) {
-                const int e = rd * 64 + lane;
-                const int px = e / PP, q = e % PP;
-                const int ox = oxb + px, n = nbase + 4 * q;
-                if (ox < OWo && n < a.Cout) {
-                    const float4 v = *reinterpret_cast<const float4 *>(&stage[px * STAGE_LD + 4 * q]);
-                    *reinterpret_cast<float4 *>(out + (((size_t)img * OHo + oy) * OWo + ox) * a.Cout + n) = v;
-                }
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&stage[(rd * PXR + px_l) * STAGE_LD + 4 * q_l]);
+#ifdef RPN_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b128(v, ors, (unsigned)(lane * 16), 0, 0);
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
+#endif
+                voff += (unsigned)(PXR * pix_bytes);
             }
         } else {
-            uint4 *out = reinterpret_cast<uint4 *>(a.out);
-            for (int rd = 0; rd < rounds; ++rd) {
-                const int e = rd * 64 + lane;
-                const int px = e / PP, q = e % PP;
-                const int ox = oxb + px;
-                const int cl = q >> 2, pc = q & 3;
-                const int n = nbase + cl * 16;
-                if (ox < OWo && n < a.Cout) {
-                    float xs[8];
-                    const float *src = &stage[px * STAGE_LD + cl * 16 + (pc >> 1) * 8];
-                    const float4 v0 = *reinterpret_cast<const float4 *>(src);
-                    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-                    xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
-                    xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
-                    out[RPN_STORE_INDEX(((((size_t)img * OHo + oy) * OWo + ox) * cout_chunks + (n >> 4)) * 4 + pc)] =
-                        split_piece<F16>(xs, (pc & 1) != 0, a.status);
-                }
+            // a lane owns EIGHT channels of a pixel and writes their hi piece and their lo piece -- 32 contiguous bytes of the pixel's
+            // SPLIT16 record -- from one read of the eight floats: 8 conversions to 16 bits, 8 back, 8 subtractions, 8 conversions
+            // per 32 bytes.  (Rounds 1-5: a lane per 16-byte piece, hi or lo by lane parity -- both computed, one selected (8
+            // v_cndmask), the same eight floats read by two lanes: 40 vector instructions and two LDS reads per 16 bytes.)
+            constexpr int LPP = CW / 8;                                   // lanes per pixel: 8 | 4
+            constexpr int PXR2 = 64 / LPP;                                // pixels per round: 8 | 16
+            const int px2 = lane / LPP, q2 = lane % LPP;
+            const int cl = q2 >> 1, hf = q2 & 1;                          // 16-channel slice of the wave's channels, its half
+            const int n = nbase + cl * 16;
+            unsigned voff = n < a.Cout ? (unsigned)(px2 * pix_bytes + (n >> 4) * 64 + hf * 32) : 0x80000000u;
+            const int rounds2 = (1 << npx_log2) / PXR2;
+#pragma unroll
+            for (int rd = 0; rd < rounds2; ++rd) {
+                float xs[8];
+                const float *src = &stage[(rd * PXR2 + px2) * STAGE_LD + cl * 16 + hf * 8];
+                const float4 v0 = *reinterpret_cast<const float4 *>(src);
+                const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+                xs[0] = v0.x; xs[1] = v0.y; xs[2] = v0.z; xs[3] = v0.w;
+                xs[4] = v1.x; xs[5] = v1.y; xs[6] = v1.z; xs[7] = v1.w;
+                const u32x4 hi = __builtin_bit_cast(u32x4, split_piece<F16>(xs, false, a.status));
+                const u32x4 lo = __builtin_bit_cast(u32x4, split_piece<F16>(xs, true, nullptr));
+#ifdef RPN_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b128(hi, ors, (unsigned)(lane * 32), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, ors, (unsigned)(lane * 32 + 16), 0, 0);
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(hi, ors, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, ors, voff + 16u, 0, 0);
+#endif
+                voff += (unsigned)(PXR2 * pix_bytes);
             }
         }
     };
