@@ -101,6 +101,9 @@ copy("bbox_c3.json", "%s_c3_bbox_kernels.json" % tag)
 for part in ("A", "B"):
     copy("device_%s.txt" % part, "%s_device_%s.txt" % (tag, part))
 copy("bw_probe.txt", "%s_bw_probe.txt" % tag)
+copy("bench_forcedist.json", "%s_forcedist_bench.json" % tag)          # (round 6) `multi_gpu_configs`: configs[3] / [4] through pack + all-gather
+copy("wn_stamps.txt", "%s_f32w_wave_stamps.txt" % tag)                  # (round 6) scripts/wn_stamp_probe.py, -DRPN_STAMP build
+copy("mfma_f32_rate.txt", "%s_mfma_f32_rate.txt" % tag)                 # (round 6) scripts/micro/mfma_f32_rate.hip
 stats(os.path.join(src, "c3_stats", "c3_kernel_stats.csv"), "%s_c3_kernel_stats.csv" % tag)
 traffic("c3", "%s_c3_traffic.json" % tag,
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) of scripts/bench_bbox.py: B=64, A=8649 (vgg16) and 9216 (mobilenet_v2), G=42")
