@@ -762,19 +762,22 @@ do {                                                                            
         // Bank skew: tile columns are 4 floats apart and four tile rows 144 = 16 (mod 32) floats, so the 32 tiles of a wave's
         // 8-byte read would fall on 16 of the 32 banks; patch rows 4 .. 7, 12 .. 15 are stored two floats to the right
         // (raw_to_lds), which puts odd tile rows on the other 16.  A tile's rows 4, 5 belong to the next tile row: second base.
-        int ro = buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2;
-        int ro45 = ro + 2 - (t_ty & 1) * 4;
-        asm volatile("" : "+v"(ro), "+v"(ro45));
-        const float *rp = ldsU + ro;
-        const float *rp45 = ldsU + ro45;
+        // (indices in float PAIRS, so that a column pair is ONE ds_read_b64: see w4n_staging_role)
+        static_assert((kW4KS * kW4Plane) % 2 == 0 && kW4Plane % 2 == 0 && kW4Pitch % 2 == 0, "pair index");
+        int ro2 = (buf * (kW4KS * kW4Plane) + t_c * kW4Plane + (4 * t_ty) * kW4Pitch + 4 * t_tx + (t_ty & 1) * 2) / 2;
+        int ro45 = ro2 + 1 - (t_ty & 1) * 2;
+        asm volatile("" : "+v"(ro2), "+v"(ro45));
+        const f32x2_w *rp = reinterpret_cast<const f32x2_w *>(ldsU) + ro2;
+        const f32x2_w *rp45 = reinterpret_cast<const f32x2_w *>(ldsU) + ro45;
         float T[3][6];
 #pragma unroll
         for (int jp = 0; jp < 3; ++jp) {              // column pairs (2 jp, 2 jp + 1)
             float d0[6], d1[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                d0[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp];
-                d1[r] = (r < 4 ? rp : rp45)[r * kW4Pitch + 2 * jp + 1];
+                const f32x2_w dd = (r < 4 ? rp : rp45)[(r * kW4Pitch) / 2 + jp];
+                d0[r] = dd[0];
+                d1[r] = dd[1];
             }
             float t0[3], t1[3];
             if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
@@ -998,12 +1001,18 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 // registers: 24 per slice and wave, two 16-byte loads per xi).  LDS-pipe and vector-ALU time are ADDED to the float32 MFMA time on
 // this chip, so this is the lever.  Layers with Cout % 128 == 0 whose 16 x 16-pixel tiles fill the chip (wino_variant 16).
 //   U packing: [n_tile][slice][xi][k 4][c 16][nb 8]: lane (k = lane >> 4, c = lane & 15) holds channel nb * 16 + c of its k for the
-//   eight N blocks as 32 contiguous bytes.   V: [xi][k][16 tiles].   raw: [channel][18][20] + padding (plane = 18 (mod 32) floats: a
-//   transform wave's 32 (tile, channel) pairs cover all 32 banks with their 8-byte reads).
-constexpr int kWnBN = 128, kWnNT = 16, kWnPatch = 18, kWnPitch = 20, kWnPlane = kWnPatch * kWnPitch + 10;
+//   eight N blocks as 32 contiguous bytes.   V: [xi][k][16 tiles].   raw: [channel][18][20] + padding, rows 8 .. 15 skewed (the
+//   layout comment at kWnPlane).
+constexpr int kWnBN = 128, kWnNT = 16, kWnPatch = 18, kWnPitch = 20, kWnPlane = kWnPatch * kWnPitch + 56;
 constexpr int kWnUFloats = kW4Xi * kW4KS * kWnBN;                        // 18432 floats = 72 KB per slice and N tile
 constexpr int kWnVFloats = kW4Xi * kW4KS * kWnNT;                        // 2304 floats = 9 KB
-static_assert(kWnPlane % 32 == 18, "raw plane stride");
+// raw-patch layout (round 6, checked exhaustively over (row, column pair) for both read forms hipcc emits): a staging lane = (channel
+// lane >> 4, tile lane & 15) reads column PAIRS of its 6 x 6 patch.  As ds_read2_b64 (two adjacent pairs, 8-byte aligned: what the
+// vectoriser makes of most of them) the sixteen tiles of a channel are one bank group over 32 dwords: tile columns are 4 floats apart,
+// tile rows 80 = 16 (mod 32), so tile rows 0 / 2 and 1 / 3 met on the same banks (2-way conflicts on every read: the 37 % conflict
+// share of profiles/r06_f32w_pmc.txt) -- patch rows 8 .. 15 are stored two floats to the right (tile rows land on 0, 16, 2, 18).
+// As ds_read_b64 two channels are one group over 64 dwords: the plane stride is 32 (mod 64).
+static_assert(kWnPlane % 64 == 32 && kWnPitch >= kWnPatch + 2, "raw plane stride / skew room");
 constexpr int kWnRawAt = 3 * kWnVFloats;                                 // LDS (ldsVR): three V buffers, then two raw-patch buffers
 
 size_t wino4n_weight_floats(int Cin, int Cout) { return (size_t)((Cout + kWnBN - 1) / kWnBN) * (Cin / kW4KS) * kWnUFloats; }
@@ -1087,7 +1096,7 @@ __device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA,
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         const bool v = pix < kWnPatch * kWnPatch && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
-        r_lds[j] = py * kWnPitch + px;
+        r_lds[j] = py * kWnPitch + px + ((py >> 3) & 1) * 2;      // (rows 8 .. 15 skewed by two floats: see kWnPlane)
     }
     const bool second = hid + 256 < kWnPatch * kWnPatch;
     // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
@@ -1114,17 +1123,26 @@ do {                                                                            
         }                                                                                                               \
 }
     auto transform = [&](int buf, int vofs) {            // raws[buf] -> V at float offset vofs (one of the three V buffers)
-        int ro = kWnRawAt + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx;
-        asm volatile("" : "+v"(ro));
-        const float *rp = ldsVR + ro;
+        // (the opaque index counts float PAIRS: every term is even, and only a provably 8-byte-aligned address makes hipcc read a column
+        // pair as ONE ds_read_b64 -- banked over 64 dwords, which is what the plane / pitch padding is designed for; as
+        // ds_read2_b32 the same reads are banked over 32 and every one paid a 2-way conflict: the 37 % conflict share of
+        // profiles/r06_f32w_pmc.txt)
+        static_assert(kWnRawAt % 2 == 0 && (kW4KS * kWnPlane) % 2 == 0 && kWnPlane % 2 == 0 && kWnPitch % 2 == 0, "pair index");
+        // (a tile's patch rows 0 .. 3 carry the skew of patch row 4 ty, its rows 4, 5 that of row 4 ty + 4: second base)
+        int ro2 = (kWnRawAt + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx) / 2 + ((t_ty >> 1) & 1);
+        int ro45 = ro2 - ((t_ty >> 1) & 1) + (((t_ty + 1) >> 1) & 1);
+        asm volatile("" : "+v"(ro2), "+v"(ro45));
+        const f32x2_w *rp2 = reinterpret_cast<const f32x2_w *>(ldsVR) + ro2;
+        const f32x2_w *rp45 = reinterpret_cast<const f32x2_w *>(ldsVR) + ro45;
         float T[3][6];
 #pragma unroll
         for (int jp = 0; jp < 3; ++jp) {
             float d0[6], d1[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                d0[r] = rp[r * kWnPitch + 2 * jp];
-                d1[r] = rp[r * kWnPitch + 2 * jp + 1];
+                const f32x2_w dd = (r < 4 ? rp2 : rp45)[(r * kWnPitch) / 2 + jp];
+                d0[r] = dd[0];
+                d1[r] = dd[1];
             }
             float t0[3], t1[3];
             if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
