@@ -53,7 +53,7 @@ def bench_name(k):
     if m: return "conv3x3_split<%s>" % prec(m.group(5))
     m = re.search(r"pw_x3_kernel<(\d+), (\d+), (\d+)>", k)
     if m: return "pw_f16x3<%s,576>" % m.group(1)
-    m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>", k)        # (, POOL since round 5)
+    m = re.search(r"conv_igemm_f32_dma<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))*>", k)        # (, POOL since round 5, LEAN since round 6)
     if m: return "conv_igemm_f32_dma<128x%d>" % (32 * int(m.group(2)) * int(m.group(4)))
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>", k)
     if m: return "conv_igemm_f32<128x%d%s>" % (32 * int(m.group(2)) * int(m.group(4)), ",generic" if m.group(5) == "true" else "")

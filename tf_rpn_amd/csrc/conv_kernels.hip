@@ -113,7 +113,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // matrix pipe busy 78 % of the time with the waves parked at the slice barrier for 18 % of theirs (profiles/r03_f32_pmc.txt).
 // With it the 128 x 128 tile takes 104 VGPRs, accumulators included: up to four workgroups per CU (33 KB of LDS each) whose
 // barrier waits cover one another.  Same instruction sequence per accumulator, same bits: 705 -> 722 images/s.
-template <int WM, int WN, int MI, int NI, bool GENERIC, bool POOL>
+template <int WM, int WN, int MI, int NI, bool GENERIC, bool POOL, bool LEAN = false>      // (LEAN: see conv_igemm_f32_dma)
 __global__ void __launch_bounds__(kConvThreads, 2)
 conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -331,7 +331,9 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     return;
 #endif
 
+#define RPN_F32_EPI_LEAN LEAN
 #include "conv_f32_epilogue.inc"
+#undef RPN_F32_EPI_LEAN
 }
 
 // ---- the same GEMM with LDS-DMA staging (`buffer_load ... lds`) --------------------------------------------------------
@@ -352,7 +354,10 @@ conv_igemm_f32(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 //     this kernel at every tile width, so an image's bits do not depend on the batch it is in (tests: batch invariance).
 //   B tile: the packed weight rows of the slice, [16][BN] floats, a linear copy (BN / 64 instructions per wave; at BN = 32
 //     two waves issue one each).
-template <int WM, int WN, int MI, int NI, bool POOL>
+// LEAN: the epilogue is the fast path alone (conv_f32_epilogue.inc: one float32 output, no residual, ReLU / linear, the image's output
+// below 2 GiB -- conv_f32_lean_ok, checked by the launcher); with both epilogues in one kernel the general one's registers (the
+// sigmoid's divide, the SPLIT16 output) set the allocation: 102 instead of 92, four workgroups per CU instead of five.
+template <int WM, int WN, int MI, int NI, bool POOL, bool LEAN = false>
 __global__ void __launch_bounds__(kConvThreads, 2)
 conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
 {
@@ -390,14 +395,13 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
         const_cast<float *>(a.w), (short)0, (int)(a.ps.floats() * 4 > 0x7fffffffull ? 0x7fffffff : a.ps.floats() * 4), 0x00020000);
 
     // this lane's two pieces of an A slice: instruction 2 wave + j, pixel m_j = 32 wave + 16 j + (lane >> 2)
-    int a_off0[2], a_cq[2];             // byte offset of (pixel, tap (0,0), its channel quad) -- may be negative; the quad's first channel
+    int a_off0[2];                      // byte offset of (pixel, tap (0,0), its channel quad) -- may be negative
     unsigned a_taps[2];                 // bit t: tap t of the pixel lies inside the image
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = 32 * wave + 16 * j + (lane >> 2);
         const int q = (lane & 3) ^ ((m >> 2) & 3);
         const int iy0 = (oy0 + (m >> 4)) * a.stride - a.pad_t, ix0 = (ox0 + (m & 15)) * a.stride - a.pad_l;
-        a_cq[j] = 4 * q;
         a_off0[j] = ((iy0 * a.W + ix0) * a.Cin + 4 * q) * 4;
         unsigned msk = 0;
         int t = 0;
@@ -424,13 +428,28 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     int w_tap = 0, w_r = 0, w_s = 0, w_cs = 0, w_tapoff = 0, w_brow = 0;
     const int b_step = 16 * a.ps.cout_pad * 4;          // bytes per slice of the packed weight matrix
 #define RPN_F32_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+    // (round 6) the lane's source offset of the tap being fetched is computed once per TAP (validity of the tap folded in) and the
+    // slice's channel step rides in the scalar offset: a slice's fetch is four DMA issues and scalar bookkeeping -- it was ~18 vector
+    // instructions and four exec branches per slice and wave, and vector-ALU time is float32-MFMA time on this chip
+    const bool whole_slices = a.Cin % BK == 0;           // (else the last slice of a tap is partial: per-slice channel test)
+    unsigned a_tapoff[2];
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_tapoff[j] = ((a_taps[j] >> w_tap) & 1u) ? (unsigned)(a_off0[j] + w_tapoff) : kOobF;
+    };
+    set_tap();
     auto fetch = [&](int buf) {
         const int c0 = w_cs * BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const bool v = c0 + a_cq[j] < a.Cin && ((a_taps[j] >> w_tap) & 1u);
-            const unsigned off = v ? (unsigned)(a_off0[j] + w_tapoff + c0 * 4) : kOobF;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, RPN_F32_LDS_PTR(&As4[buf][(2 * wave + j) * 64]), 16, off, 0, 0, 0);
+            unsigned off = a_tapoff[j];
+            if (!whole_slices) {                         // (the lane's channel quad, recomputed: not worth a register across the loop)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int mq = 32 * wave + 16 * j + (ln >> 2);
+                if (c0 + 4 * ((ln & 3) ^ ((mq >> 2) & 3)) >= a.Cin) off = kOobF;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, RPN_F32_LDS_PTR(&As4[buf][(2 * wave + j) * 64]), 16, off, c0 * 4, 0, 0);
         }
         if (b_wave) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, RPN_F32_LDS_PTR(&Bs[buf][0][0] + (B_PER_WAVE * wave) * 256), 16, b_off0,
@@ -445,6 +464,7 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
             ++w_tap;
             if (++w_s == a.S) { w_s = 0; ++w_r; }
             w_tapoff = (w_r * a.W + w_s) * a.Cin * 4;
+            set_tap();
         }
     };
 
@@ -503,7 +523,9 @@ conv_igemm_f32_dma(ConvArgs a, int tiles_x, int tiles_y, int n_tiles)
     }
 #undef RPN_F32_LDS_PTR
 
+#define RPN_F32_EPI_LEAN LEAN
 #include "conv_f32_epilogue.inc"
+#undef RPN_F32_EPI_LEAN
 }
 
 bool conv_f32_uses_dma(int tile_n, int generic);
@@ -516,6 +538,9 @@ static hipError_t launch_variant_p(const ConvArgs &a, hipStream_t stream)
     const int n_tiles = (a.Cout + BN - 1) / BN;
     const long long nblocks = (long long)tiles_x * tiles_y * a.B * n_tiles;
     if (nblocks <= 0 || nblocks > 0x7fffffffll) return hipErrorInvalidValue;
+    const int OHo = POOL ? a.OH >> 1 : a.OH, OWo = POOL ? a.OW >> 1 : a.OW;
+    const bool lean = !a.residual && a.split >= a.Cout && !a.out_split && (a.act == ACT_RELU || a.act == ACT_LINEAR) &&
+                      (long long)OHo * OWo * a.ld1 * 4 <= 0x7fffffffll;
     if (a.ps.generic)
         hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                            stream, a, tiles_x, tiles_y, n_tiles);
@@ -523,11 +548,19 @@ static hipError_t launch_variant_p(const ConvArgs &a, hipStream_t stream)
         // (laboratory builds: RPN_F32_DMA=0: register-staged kernel everywhere, 2: DMA kernel everywhere; same bits)
         // the DMA kernel on the 128-wide tile (+2.5 ... 3.6 % per layer); the narrower tiles are what small grids get (two
         // workgroups per CU: nothing covers the DMA's longer latency there -- 31 x 31 x 512 at batch 8: 0.406 against 0.341 ms)
-        if (conv_f32_uses_dma(BN, 0))
-            hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream, a,
-                               tiles_x, tiles_y, n_tiles);
+        if (conv_f32_uses_dma(BN, 0)) {
+            if (lean)
+                hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI, POOL, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream,
+                                   a, tiles_x, tiles_y, n_tiles);
+            else
+                hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI, POOL, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream,
+                                   a, tiles_x, tiles_y, n_tiles);
+        }
+        else if (lean)
+            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false, POOL, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+                               stream, a, tiles_x, tiles_y, n_tiles);
         else
-            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
+            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, false, POOL, false>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                                stream, a, tiles_x, tiles_y, n_tiles);
     }
     return hipGetLastError();
