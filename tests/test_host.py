@@ -88,7 +88,7 @@ KERNEL_BUDGETS = {
     r"rpn_head_kernel<": (192, 0, 49152),
     r"conv3x3_wino_f32_kernel": (168, 0, 160 * 1024),                   # twelve waves (8 MFMA + 4 staging): three per SIMD
     r"conv3x3_wino4_f32_kernel": (128, 96, 160 * 1024),                 # (round 6: 80 SGPRs parked in VGPR lanes, none inside the slice loops)                  # sixteen waves (12 MFMA + 4 staging): four per SIMD
-    r"conv3x3_wino4n_f32_kernel": (128, 0, 160 * 1024),                 # the wide form: the same sixteen waves
+    r"conv3x3_wino4n_f32_kernel": (128, 8, 160 * 1024),                 # the wide form: the same sixteen waves (persistent: four scalars parked in lanes)
 }
 
 

@@ -503,6 +503,14 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4])
     y[3] = __builtin_fmaf(8.0f, s, q) + m[5];
 }
 
+// a.pool as an opaque scalar: derived values (output sizes, edge tests) are invariant in the persistent kernels' tile loop and were
+// hoisted to the top of the kernel -- one of them as a 0 / 1 VECTOR register held (and spilled to scratch) across the slice loop
+__device__ __forceinline__ int w4_pool(const WinoArgs &a)
+{
+    int p = a.pool;
+    asm volatile("" : "+s"(p));
+    return p;
+}
 // The tail of an epilogue phase, shared by the F(4x4, 3x3) forms: a thread holds the 4 x 4 outputs y of one (tile, channel) pair and
 // writes them (+ bias, activation; `pool`: the 2 x 2 maxima).  Round 6: one epilogue phase was ~490 vector instructions per thread
 // (stamps: 20 k cycles of epilogue per workgroup, a quarter of a 128-channel layer) -- sixteen 64-bit address computations, a
@@ -513,7 +521,7 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4])
 __device__ __forceinline__ void w4_store_outputs(const WinoArgs &a, float (&y)[4][4], __amdgpu_buffer_rsrc_t out_rs, unsigned voff, int oy, int ox,
                                                  float bias, bool interior)
 {
-    if (a.pool) {
+    if (w4_pool(a)) {
         const int PH = a.H >> 1, PW = a.W >> 1;
         float v[2][2];
 #pragma unroll
@@ -532,7 +540,8 @@ __device__ __forceinline__ void w4_store_outputs(const WinoArgs &a, float (&y)[4
 #pragma unroll
                 for (int j = 0; j < 2; ++j) v[i][j] = wino_act(v[i][j], a.act);
         }
-        const int row = PW * a.Cout * 4, col = a.Cout * 4;
+        int row = PW * a.Cout * 4, col = a.Cout * 4;
+        asm volatile("" : "+s"(row), "+s"(col));          // (opaque: see below)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -552,7 +561,10 @@ __device__ __forceinline__ void w4_store_outputs(const WinoArgs &a, float (&y)[4
 #pragma unroll
             for (int q = 0; q < 4; ++q) y[p][q] = wino_act(y[p][q] + bias, a.act);
     }
-    const int row = a.W * a.Cout * 4, col = a.Cout * 4;
+    // (opaque scalars: in the persistent kernels the sixteen (row, column) steps are invariant in the tile loop and were hoisted to
+    // the top of the kernel -- twenty scalar registers held for its whole life, which pushed others into vector-register lanes)
+    int row = a.W * a.Cout * 4, col = a.Cout * 4;
+    asm volatile("" : "+s"(row), "+s"(col));
     if (interior) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -572,7 +584,8 @@ __device__ __forceinline__ void w4_store_outputs(const WinoArgs &a, float (&y)[4
 // the image's output tensor as a buffer (launch_conv3x3_wino checks that it is below 2 GiB)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_out_rsrc(const WinoArgs &a, int img)
 {
-    const int OH = a.pool ? a.H >> 1 : a.H, OW = a.pool ? a.W >> 1 : a.W;
+    const int pool = w4_pool(a);
+    const int OH = pool ? a.H >> 1 : a.H, OW = pool ? a.W >> 1 : a.W;
     return __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * OH * OW * a.Cout, (short)0, OH * OW * a.Cout * 4, 0x00020000);
 }
 
@@ -614,9 +627,10 @@ __device__ __forceinline__ void w4_output_pair(const WinoArgs &a, const float *M
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[p][q]), part_rs, pv, ((p * 32 + q) * kWinoBN) * 4, kSc1);
         return;
     }
-    const bool inside = a.pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);
+    const int pool = w4_pool(a);
+    const bool inside = pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);
     const bool interior = __builtin_amdgcn_ballot_w64(!inside) == 0ull;    // (a wave holds two tiles here)
-    const unsigned voff = a.pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
+    const unsigned voff = pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
     w4_store_outputs(a, y, out_rs, voff, oy, ox, bias, interior);
 }
 
@@ -1069,9 +1083,52 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
     float y[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) w4_at(R[p], y[p]);
-    const bool interior = a.pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);   // wave-uniform
-    const unsigned voff = a.pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
+    const int pool = w4_pool(a);
+    const bool interior = pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);   // wave-uniform
+    const unsigned voff = pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
     w4_store_outputs(a, y, out_rs, voff, oy, ox, bias, interior);
+}
+
+// Persistent workgroups of the wide form (round 6): the grid is one workgroup per CU (or fewer), workgroup w walks the tiles
+// L, L + G, L + 2 G, ... (L = wino_xcd_remap(w, G): consecutive tiles -- the N tiles of a pixel block, neighbouring blocks -- on one
+// XCD, as before).  What it buys: the staging waves request the NEXT tile's first four slices in front of the epilogue of the current
+// one, so a tile's prologue no longer waits for a first-touch memory latency (~2.5 k of its ~6.5 k cycles).
+struct WnTile {
+    int img, oy0, ox0, n0, nt;
+};
+__device__ __forceinline__ WnTile wn_tile(int t, int tiles_x, int tiles_y, int n_tiles)
+{
+    WnTile r;
+    r.nt = t % n_tiles;
+    int mt = t / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    r.img = mt / tiles_y;
+    r.oy0 = ty * 16;
+    r.ox0 = tx * 16;
+    r.n0 = r.nt * kWnBN;
+    return r;
+}
+// tile + step, digit by digit with carries (st = wn_tile(step): its oy0 / ox0 carry the scaled digits): no division per tile
+__device__ __forceinline__ void wn_advance(WnTile &tl, const WnTile &st, int tiles_x, int tiles_y, int n_tiles)
+{
+    int nt = tl.nt + st.nt, c = nt >= n_tiles;
+    nt -= c ? n_tiles : 0;
+    int ox = tl.ox0 + st.ox0 + 16 * c;
+    c = ox >= 16 * tiles_x;
+    ox -= c ? 16 * tiles_x : 0;
+    int oy = tl.oy0 + st.oy0 + 16 * c;
+    c = oy >= 16 * tiles_y;
+    oy -= c ? 16 * tiles_y : 0;
+    tl.img += st.img + c;
+    tl.nt = nt; tl.n0 = nt * kWnBN; tl.ox0 = ox; tl.oy0 = oy;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_image_rsrc(const WinoArgs &a, int img)
+{
+    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)img * a.H * a.W * a.Cin, (short)0,
+                                             (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
 }
 
 // The staging role of the wide form (waves 12 .. 15, one per SIMD), one instantiation per wave: PART / HALF select the wave's QUARTER of
@@ -1080,24 +1137,31 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
 // and waited for at once (`s_waitcnt lgkmcnt(1)`, `lgkmcnt(0)` eighteen times per slice): a staging wave's slice was a chain of
 // ~18 exposed LDS round trips.  As template parameters the slice is straight-line: 18 reads in flight, one wait.
 template <int PART, int HALF>
-__device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA, float *ldsVR, __amdgpu_buffer_rsrc_t xrs, int tid, int lane,
-                                                 int img, int oy0, int ox0, int n0, int n_slices)
+__device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA, float *ldsVR, int tid, int lane, int t_first, int t_step,
+                                                 int t_total, int tiles_x, int tiles_y, int n_tiles, int n_slices)
 {
     constexpr unsigned kOob = 0x80000000u;
     const int hid = tid - 768;             // staging thread 0 .. 255
     __builtin_amdgcn_s_setprio(3);                 // (see conv3x3_wino4_f32_kernel)
     // a staging thread's pixels of a slice's raw patch (18 x 18 = 324 pixels, one 16-byte load = 4 channels each)
     unsigned r_off[2];
-    int r_lds[2];
+    int r_lds[2], r_py[2], r_px[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pix = hid + j * 256;
         const int py = pix / kWnPatch, px = pix - py * kWnPatch;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool v = pix < kWnPatch * kWnPatch && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        r_py[j] = pix < kWnPatch * kWnPatch ? py : -100000;       // (no such pixel: never inside an image)
+        r_px[j] = px;
         r_lds[j] = py * kWnPitch + px + ((py >> 3) & 1) * 2;      // (rows 8 .. 15 skewed by two floats: see kWnPlane)
     }
+    auto set_offsets = [&](const WnTile &tl) {                    // this thread's source offsets inside the tile's image
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = tl.oy0 - 1 + r_py[j], ix = tl.ox0 - 1 + r_px[j];
+            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        }
+    };
     const bool second = hid + 256 < kWnPatch * kWnPatch;
     // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
     // QUARTER of every pair's 6 x 6 transform -- output rows 3 part .. 3 part + 2, output columns 3 half .. 3 half + 2, part and half
@@ -1169,15 +1233,29 @@ do {                                                                            
     // iterations' transforms / writes work on stale data that nobody reads: the loop body has no conditions, so hipcc's counted
     // waits stay exact.
     const int last = n_slices - 1;
+    u32x4_w p2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, p3[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    // the first four slices of a tile: requested here for the workgroup's first tile, in front of the previous tile's epilogue for
+    // every other one (below)
+#define RPN_WN_REQUEST_TILE()                                                                                               \
+{                                                                                                                       \
+    RPN_WN_LOAD_RAW(0, 0);                                                                                              \
+    RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);                                                                            \
+    p2[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (2 < last ? 2 : last) * kW4KS * 4, 0);                 \
+    p2[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (2 < last ? 2 : last) * kW4KS * 4, 0);                 \
+    p3[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (3 < last ? 3 : last) * kW4KS * 4, 0);                 \
+    p3[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (3 < last ? 3 : last) * kW4KS * 4, 0);                 \
+}
+    WnTile tl = wn_tile(t_first, tiles_x, tiles_y, n_tiles);
+    // (the walk to the next tile is INCREMENTAL here -- the step's (N tile, column, row, image) digits added with carries: three
+    // divisions by run-time values per tile cost this role the scalar registers that keep the kernel free of scratch)
+    const WnTile st = wn_tile(t_step, tiles_x, tiles_y, n_tiles);          // digits of the step (oy0 / ox0 / n0 carry the scaled digits)
+    __amdgpu_buffer_rsrc_t xrs = wn_image_rsrc(a, tl.img);
+    set_offsets(tl);
+    RPN_WN_REQUEST_TILE();
+    for (int t = t_first; t < t_total; t += t_step) {
+    const int img = tl.img, oy0 = tl.oy0, ox0 = tl.ox0, n0 = tl.n0;
     // prologue: the first FOUR slices requested at once (one memory latency, not three dependent ones: round 6's deeper pipeline had
     // taken the kernel's entry -> loop time from 5.5 k to 8.4 k cycles); slices 2, 3 wait in two more register sets
-    RPN_WN_LOAD_RAW(0, 0);
-    RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);
-    u32x4_w p2[2], p3[2];
-    p2[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (2 < last ? 2 : last) * kW4KS * 4, 0);
-    p2[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (2 < last ? 2 : last) * kW4KS * 4, 0);
-    p3[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (3 < last ? 3 : last) * kW4KS * 4, 0);
-    p3[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (3 < last ? 3 : last) * kW4KS * 4, 0);
     RPN_WN_RAW_TO_LDS(0, 0);
     RPN_WN_RAW_TO_LDS(1, 1);
     __syncthreads();                                                       // (A)
@@ -1212,13 +1290,22 @@ do {                                                                            
         }
         if (s < n_slices) RPN_WN_STAGE(s, 0);
     }
-#undef RPN_WN_STAGE
+    // the next tile's first four slices: in flight across this tile's epilogue (eight 16-byte registers per thread)
+    if (t + t_step < t_total) {
+        wn_advance(tl, st, tiles_x, tiles_y, n_tiles);
+        xrs = wn_image_rsrc(a, tl.img);
+        set_offsets(tl);
+        RPN_WN_REQUEST_TILE();
+    }
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         __syncthreads();                                         // the phase's accumulators are in LDS
         w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
         __syncthreads();                                         // the staging area may be overwritten
     }
+    }   // tile loop
+#undef RPN_WN_STAGE
+#undef RPN_WN_REQUEST_TILE
 #undef RPN_WN_LOAD_RAW
 #undef RPN_WN_RAW_TO_LDS
 }
@@ -1235,38 +1322,36 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = wg % n_tiles;
-    int mt = wg / n_tiles;
-    const int tx = mt % tiles_x;
-    mt /= tiles_x;
-    const int ty = mt % tiles_y;
-    const int img = mt / tiles_y;
-    const int oy0 = ty * 16, ox0 = tx * 16, n0 = nt * kWnBN;
-
+    // persistent workgroups: tiles t_first, t_first + gridDim.x, ... (see wn_tile); both roles walk the same tiles with the same
+    // number of barriers per tile
+    const int t_first = wino_xcd_remap(blockIdx.x, gridDim.x), t_step = gridDim.x;
+    const int t_total = tiles_x * tiles_y * a.B * n_tiles;
     const int n_slices = a.Cin / kW4KS;
-    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin;
-    constexpr unsigned kOob = 0x80000000u;
-    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), (short)0, (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
-    const float *ubase = a.u + (size_t)nt * n_slices * kWnUFloats;
     const long long ubytes = (long long)n_slices * kWnUFloats * 4;
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
 
     const bool stager = wave >= 12;
-    const int hid = tid - 768;             // staging thread 0 .. 255
-    const int k4 = lane >> 4, l15 = lane & 15;
 
     if (stager) {
         const int sw = wave - 12;          // t_part = sw & 1, t_half = sw >> 1
-        if (sw == 0) w4n_staging_role<0, 0>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
-        else if (sw == 1) w4n_staging_role<1, 0>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
-        else if (sw == 2) w4n_staging_role<0, 1>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
-        else w4n_staging_role<1, 1>(a, ldsA, ldsVR, xrs, tid, lane, img, oy0, ox0, n0, n_slices);
+        if (sw == 0) w4n_staging_role<0, 0>(a, ldsA, ldsVR, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, n_slices);
+        else if (sw == 1) w4n_staging_role<1, 0>(a, ldsA, ldsVR, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, n_slices);
+        else if (sw == 2) w4n_staging_role<0, 1>(a, ldsA, ldsVR, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, n_slices);
+        else w4n_staging_role<1, 1>(a, ldsA, ldsVR, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, n_slices);
         return;
     }
 
     // ---- MFMA waves: xi = 3 wave + j, 16 tiles x 128 channels = eight 16 x 16 blocks per xi
+    WnTile tl = wn_tile(t_first, tiles_x, tiles_y, n_tiles);
+    const WnTile tstep = wn_tile(t_step, tiles_x, tiles_y, n_tiles);       // (the walk is incremental: wn_advance)
+    for (int t = t_first; t < t_total; t += t_step) {
+    const int img = tl.img, oy0 = tl.oy0, ox0 = tl.ox0, n0 = tl.n0;
+    // (the lane index re-derived per tile, opaque: what is computed from it is otherwise hoisted out of the tile loop and -- the
+    // slice loop runs at exactly 128 registers -- spilled to scratch around it)
+    int lane_t;                          // (volatile asm: the builtin's value is loop-invariant too and would be hoisted and kept)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+    const int k4 = lane_t >> 4, l15 = lane_t & 15;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.u) + (size_t)tl.nt * n_slices * kWnUFloats, (short)0,
+                                                                          (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
     f32x4_w acc[3][8];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -1275,7 +1360,7 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     // filter fragments: ONE register set; xi j's fragments of the next slice are requested right behind its MFMAs of this slice (a
     // whole slice of latency budget; two sets would be 48 registers beside the 96 accumulators)
     f32x4_w ureg[3][2];
-    const unsigned u_voff = (unsigned)(((3 * wave) * (kW4KS * kWnBN) + lane * 8) * 4);
+    const unsigned u_voff = (unsigned)(((3 * wave) * (kW4KS * kWnBN) + lane_t * 8) * 4);
 #define RPN_WN_LOAD_U(SLICE, J)                                                                                             \
     {                                                                                                                       \
         /* (xi j's 2 KB step rides in the SCALAR offset: as a vector-offset constant beyond 4095 it cost an address register) */                                               \
@@ -1341,6 +1426,11 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 
     // ---- epilogue: two phases of 64 channels: park [xi 36][tile 16][64 channels] = 144 KB over both arrays, every thread transforms
     // one (tile, channel) pair; C / D of the 16x16 MFMA: column (channel) = lane & 15, row (tile) = 4 * (lane >> 4) + register
+    // (the lane index re-derived here, opaque: everything the epilogue computes from the thread index is loop-invariant in the
+    // tile loop, gets hoisted in front of it and -- the slice loop runs at exactly 128 registers -- was spilled to scratch)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int tid_e = wave * 64 + lane_e, k4e = lane_e >> 4, l15e = lane_e & 15;
     float *park = wave < 6 ? ldsA : ldsVR - kHalf;                        // xi = 3 wave + j: waves 0 .. 5 own xi 0 .. 17
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
@@ -1350,14 +1440,16 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) park[(xi * kWnNT + 4 * k4 + r) * 64 + q * 16 + l15] = acc[j][4 * ph + q][r];
+                for (int r = 0; r < 4; ++r) park[(xi * kWnNT + 4 * k4e + r) * 64 + q * 16 + l15e] = acc[j][4 * ph + q][r];
         }
         __syncthreads();
-        w4n_output_pair(a, ldsA, ldsVR, tid, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
+        w4n_output_pair(a, ldsA, ldsVR, tid_e, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
         __syncthreads();
     }
     RPN_WN_STAMP(63);
     RPN_WN_STAMP_RT(59);
+    wn_advance(tl, tstep, tiles_x, tiles_y, n_tiles);
+    }   // tile loop
 }
 #undef RPN_WINO_LDS_PTR
 
@@ -1438,7 +1530,9 @@ hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias
         const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, n_tiles = Cout / kWnBN;
         const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles;
         if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(conv3x3_wino4n_f32_kernel, dim3((unsigned)nblocks), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
+        // persistent: one workgroup per CU walks its tiles (wn_tile); fewer tiles than CUs: one tile each
+        const long long grid = nblocks < (long long)wino_cus_of_current_device() ? nblocks : (long long)wino_cus_of_current_device();
+        hipLaunchKernelGGL(conv3x3_wino4n_f32_kernel, dim3((unsigned)grid), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
         return hipGetLastError();
     }
     if (variant == 4 || variant == 8) {
