@@ -1136,68 +1136,70 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_image_rsrc(const WinoArgs &
 // run-time (wave-uniform) values they compiled into a branch around every 1-D transform with the patch reads issued two at a time
 // and waited for at once (`s_waitcnt lgkmcnt(1)`, `lgkmcnt(0)` eighteen times per slice): a staging wave's slice was a chain of
 // ~18 exposed LDS round trips.  As template parameters the slice is straight-line: 18 reads in flight, one wait.
-template <int PART, int HALF>
+template <int PART, int CHALF>
 __device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA, float *ldsVR, int tid, int lane, int t_first, int t_step,
                                                  int t_total, int tiles_x, int tiles_y, int n_tiles, int n_slices)
 {
+    // Round 6, second form: the staging waves work in PAIRS of slices (8 input channels): a wave owns output rows 3 PART .. 3 PART + 2
+    // of the transforms of FOUR channels (4 CHALF .. + 3 = slice 2 P + CHALF of pair P) -- the column stage (36 operations) is then
+    // shared by all six output columns instead of being repeated by the two waves that split them: 72 vector instructions per pair
+    // and wave instead of 2 x 58 -- and the workgroup meets at a barrier once per pair.  V is a ring of six slice buffers (three
+    // pairs), the raw patch (8 planes per buffer, two buffers) lives in ldsA, which the slice loop does not use otherwise.
     constexpr unsigned kOob = 0x80000000u;
+    constexpr int kRawBuf = 2 * kW4KS * kWnPlane;            // floats per raw buffer (8 channel planes)
+    constexpr int kItems = 2 * kWnPatch * kWnPatch;          // (pixel, channel half) items of a pair's patch: 648 16-byte loads
+    static_assert(2 * kRawBuf <= 18 * kWnNT * 64 && 6 * kWnVFloats <= 18 * kWnNT * 64, "LDS layout");
     const int hid = tid - 768;             // staging thread 0 .. 255
     __builtin_amdgcn_s_setprio(3);                 // (see conv3x3_wino4_f32_kernel)
-    // a staging thread's pixels of a slice's raw patch (18 x 18 = 324 pixels, one 16-byte load = 4 channels each)
-    unsigned r_off[2];
-    int r_lds[2], r_py[2], r_px[2];
+    unsigned r_off[3];
+    int r_lds[3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pix = hid + j * 256;
+    for (int j = 0; j < 3; ++j) {
+        const int item = hid + j * 256;
+        const int half = item >= kWnPatch * kWnPatch ? 1 : 0, pix = item - half * (kWnPatch * kWnPatch);
         const int py = pix / kWnPatch, px = pix - py * kWnPatch;
-        r_py[j] = pix < kWnPatch * kWnPatch ? py : -100000;       // (no such pixel: never inside an image)
-        r_px[j] = px;
-        r_lds[j] = py * kWnPitch + px + ((py >> 3) & 1) * 2;      // (rows 8 .. 15 skewed by two floats: see kWnPlane)
+        r_lds[j] = (4 * half) * kWnPlane + py * kWnPitch + px + ((py >> 3) & 1) * 2;      // (rows 8 .. 15 skewed by two floats: see kWnPlane)
     }
     auto set_offsets = [&](const WnTile &tl) {                    // this thread's source offsets inside the tile's image
+        int h = hid;                                              // (opaque: the item's row / column are recomputed per tile, not kept in
+        asm volatile("" : "+v"(h));                               // nine registers across the tile loop)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int iy = tl.oy0 - 1 + r_py[j], ix = tl.ox0 - 1 + r_px[j];
-            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        for (int j = 0; j < 3; ++j) {
+            const int item = h + j * 256;
+            const int half = item >= kWnPatch * kWnPatch ? 1 : 0, pix = item - half * (kWnPatch * kWnPatch);
+            const int py = pix / kWnPatch, px = pix - py * kWnPatch;
+            const int iy = tl.oy0 - 1 + py, ix = tl.ox0 - 1 + px;
+            const bool v = item < kItems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4 + 16 * half) : kOob;
         }
     };
-    const bool second = hid + 256 < kWnPatch * kWnPatch;
-    // transform role: a lane = one (tile, channel) pair of the slice's 64; the four staging waves (one per SIMD) each compute a
-    // QUARTER of every pair's 6 x 6 transform -- output rows 3 part .. 3 part + 2, output columns 3 half .. 3 half + 2, part and half
-    // wave-uniform (no divergent halves) -- so that the transform's vector instructions, which take float32-MFMA time, are spread
-    // evenly over the four SIMDs (two waves doing halves loaded two SIMDs with all of it)
-    constexpr int t_part = PART, t_half = HALF;     // (template parameters: the staging waves' four streams are straight-line code)
-    const int t_tile = lane & 15, t_c = lane >> 4;
+    const bool third = hid + 512 < kItems;
+    const int t_tile = lane & 15, t_cl = lane >> 4;               // transform role: tile, channel 4 CHALF + t_cl of the pair
     const int t_ty = t_tile >> 2, t_tx = t_tile & 3;
-    // (two register sets, a slice's patch requested two iterations before its transform: see conv3x3_wino4_f32_kernel)
-    u32x4_w rr[2][2] = {{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}};
-#define RPN_WN_LOAD_RAW(SLICE, SET)                                                                                         \
-do {                                                                                                                    \
-    rr[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (SLICE) * kW4KS * 4, 0);                          \
-    rr[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (SLICE) * kW4KS * 4, 0);   /* (no piece: kOob, zeros) */ \
-} while (0)
-#define RPN_WN_RAW_TO_LDS(BUF, SET)                                                                                         \
-{                                                                                                                       \
-    float *raw_ = ldsVR + kWnRawAt + (BUF) * (kW4KS * kWnPlane);                                                        \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                    \
-        if (j_ < 1 || second) {                                                                                         \
-            const f32x4_w v_ = __builtin_bit_cast(f32x4_w, rr[SET][j_]);                                                \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kWnPlane] = v_[i_];                  \
-        }                                                                                                               \
-}
-    auto transform = [&](int buf, int vofs) {            // raws[buf] -> V at float offset vofs (one of the three V buffers)
-        // (the opaque index counts float PAIRS: every term is even, and only a provably 8-byte-aligned address makes hipcc read a column
-        // pair as ONE ds_read_b64 -- banked over 64 dwords, which is what the plane / pitch padding is designed for; as
-        // ds_read2_b32 the same reads are banked over 32 and every one paid a 2-way conflict: the 37 % conflict share of
-        // profiles/r06_f32w_pmc.txt)
-        static_assert(kWnRawAt % 2 == 0 && (kW4KS * kWnPlane) % 2 == 0 && kWnPlane % 2 == 0 && kWnPitch % 2 == 0, "pair index");
-        // (a tile's patch rows 0 .. 3 carry the skew of patch row 4 ty, its rows 4, 5 that of row 4 ty + 4: second base)
-        int ro2 = (kWnRawAt + buf * (kW4KS * kWnPlane) + t_c * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx) / 2 + ((t_ty >> 1) & 1);
+    u32x4_w rr[2][3], p2[3], p3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rr[0][j] = rr[1][j] = p2[j] = p3[j] = u32x4_w{0u, 0u, 0u, 0u};
+#define RPN_WN_LOAD_PAIR(DST, PAIR)                                                                                         \
+    _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                                        \
+        DST[j_] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[j_], (PAIR) * (2 * kW4KS * 4), 0)   /* (no item: kOob, zeros) */
+#define RPN_WN_RAW_TO_LDS(BUF, SRC)                                                                                         \
+    {                                                                                                                       \
+        float *raw_ = ldsA + (BUF) * kRawBuf;                                                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                                    \
+            if (j_ < 2 || third) {                                                                                          \
+                const f32x4_w v_ = __builtin_bit_cast(f32x4_w, SRC[j_]);                                                    \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) raw_[r_lds[j_] + i_ * kWnPlane] = v_[i_];                  \
+            }                                                                                                               \
+    }
+    auto transform = [&](int buf, int vofs) {                // raws[buf] -> the pair's two V buffers at float offset vofs (slice CHALF)
+        // (indices in float PAIRS: a column pair is one 8-byte read; a tile's patch rows 0 .. 3 carry the skew of patch row 4 ty, its
+        // rows 4, 5 that of row 4 ty + 4: second base -- see kWnPlane)
+        static_assert(kRawBuf % 2 == 0 && kWnPlane % 2 == 0 && kWnPitch % 2 == 0, "pair index");
+        int ro2 = (buf * kRawBuf + (4 * CHALF + t_cl) * kWnPlane + (4 * t_ty) * kWnPitch + 4 * t_tx) / 2 + ((t_ty >> 1) & 1);
         int ro45 = ro2 - ((t_ty >> 1) & 1) + (((t_ty + 1) >> 1) & 1);
         asm volatile("" : "+v"(ro2), "+v"(ro45));
-        const f32x2_w *rp2 = reinterpret_cast<const f32x2_w *>(ldsVR) + ro2;
-        const f32x2_w *rp45 = reinterpret_cast<const f32x2_w *>(ldsVR) + ro45;
+        const f32x2_w *rp2 = reinterpret_cast<const f32x2_w *>(ldsA) + ro2;
+        const f32x2_w *rp45 = reinterpret_cast<const f32x2_w *>(ldsA) + ro45;
         float T[3][6];
 #pragma unroll
         for (int jp = 0; jp < 3; ++jp) {
@@ -1209,88 +1211,80 @@ do {                                                                            
                 d1[r] = dd[1];
             }
             float t0[3], t1[3];
-            if (t_part == 0) { w4_bt3<0>(d0, t0); w4_bt3<0>(d1, t1); }
-            else { w4_bt3<1>(d0, t0); w4_bt3<1>(d1, t1); }
+            w4_bt3<PART>(d0, t0);
+            w4_bt3<PART>(d1, t1);
 #pragma unroll
             for (int i = 0; i < 3; ++i) { T[i][2 * jp] = t0[i]; T[i][2 * jp + 1] = t1[i]; }
         }
-        int vo = vofs + (18 * t_part + 3 * t_half) * (kW4KS * kWnNT) + t_c * kWnNT + t_tile;
+        int vo = vofs + CHALF * kWnVFloats + (18 * PART) * (kW4KS * kWnNT) + t_cl * kWnNT + t_tile;
         asm volatile("" : "+v"(vo));
         float *vp = ldsVR + vo;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            float v[3];
-            if (t_half == 0) w4_bt3<0>(T[i], v);
-            else w4_bt3<1>(T[i], v);
+            float v[6];
+            w4_bt6(T[i], v);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+            for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
         }
     };
-    // Pipeline (round 6: one slice deeper, V triple-buffered, so that the MFMA waves can read slice s + 1's operands BEFORE the
-    // barrier that ends slice s and issue their first MFMA right behind it): slice t is requested in iteration t - 4 into register
-    // set t & 1, written to raws[t & 1] in iteration t - 3, transformed into V[t % 3] in iteration t - 2, read by the MFMA waves
-    // during iteration t - 1 and multiplied in iteration t.  Requests past the end are clamped to the last slice and the last
-    // iterations' transforms / writes work on stale data that nobody reads: the loop body has no conditions, so hipcc's counted
-    // waits stay exact.
-    const int last = n_slices - 1;
-    u32x4_w p2[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, p3[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    // the first four slices of a tile: requested here for the workgroup's first tile, in front of the previous tile's epilogue for
-    // every other one (below)
+    // Pipeline: pair P is requested in iteration P - 4 (register set P & 1), written to raws[P & 1] in iteration P - 3, transformed into
+    // the V ring's pair buffer P % 3 in iteration P - 2, read by the MFMA waves from iteration P - 1 on, multiplied in iteration P.
+    // No conditions in the loop body (requests clamped to the last pair, the tail works on stale data that nobody reads).
+    const int n_pairs = n_slices >> 1, last = n_pairs - 1;
+    // the first two pairs of a tile: requested here for the workgroup's first tile, in front of the previous tile's epilogue for
+    // every other one (below; all four pairs held across the epilogue were 48 registers beside its ~75: spills); pairs 2, 3 at the
+    // top of the tile (they are needed behind barrier (B))
 #define RPN_WN_REQUEST_TILE()                                                                                               \
 {                                                                                                                       \
-    RPN_WN_LOAD_RAW(0, 0);                                                                                              \
-    RPN_WN_LOAD_RAW(1 < last ? 1 : last, 1);                                                                            \
-    p2[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (2 < last ? 2 : last) * kW4KS * 4, 0);                 \
-    p2[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (2 < last ? 2 : last) * kW4KS * 4, 0);                 \
-    p3[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[0], (3 < last ? 3 : last) * kW4KS * 4, 0);                 \
-    p3[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, r_off[1], (3 < last ? 3 : last) * kW4KS * 4, 0);                 \
+    RPN_WN_LOAD_PAIR(rr[0], 0);                                                                                         \
+    RPN_WN_LOAD_PAIR(rr[1], 1 < last ? 1 : last);                                                                       \
 }
     WnTile tl = wn_tile(t_first, tiles_x, tiles_y, n_tiles);
-    // (the walk to the next tile is INCREMENTAL here -- the step's (N tile, column, row, image) digits added with carries: three
-    // divisions by run-time values per tile cost this role the scalar registers that keep the kernel free of scratch)
-    const WnTile st = wn_tile(t_step, tiles_x, tiles_y, n_tiles);          // digits of the step (oy0 / ox0 / n0 carry the scaled digits)
+    const WnTile st = wn_tile(t_step, tiles_x, tiles_y, n_tiles);          // digits of the step (wn_advance)
     __amdgpu_buffer_rsrc_t xrs = wn_image_rsrc(a, tl.img);
     set_offsets(tl);
     RPN_WN_REQUEST_TILE();
     for (int t = t_first; t < t_total; t += t_step) {
     const int img = tl.img, oy0 = tl.oy0, ox0 = tl.ox0, n0 = tl.n0;
-    // prologue: the first FOUR slices requested at once (one memory latency, not three dependent ones: round 6's deeper pipeline had
-    // taken the kernel's entry -> loop time from 5.5 k to 8.4 k cycles); slices 2, 3 wait in two more register sets
-    RPN_WN_RAW_TO_LDS(0, 0);
-    RPN_WN_RAW_TO_LDS(1, 1);
+    RPN_WN_LOAD_PAIR(p2, 2 < last ? 2 : last);
+    RPN_WN_LOAD_PAIR(p3, 3 < last ? 3 : last);
+    RPN_WN_RAW_TO_LDS(0, rr[0]);
+    RPN_WN_RAW_TO_LDS(1, rr[1]);
     __syncthreads();                                                       // (A)
     transform(0, 0);
-    transform(1, kWnVFloats);
+    transform(1, 2 * kWnVFloats);
     __syncthreads();                                                       // (B)
-    rr[0][0] = p2[0]; rr[0][1] = p2[1];
-    RPN_WN_RAW_TO_LDS(0, 0);
-    rr[1][0] = p3[0]; rr[1][1] = p3[1];
-    __syncthreads();                                                       // (C): V[0], V[1] complete, slice 2 in raws[0], slice 3 in register set 1
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rr[0][j] = p2[j];
+    RPN_WN_RAW_TO_LDS(0, rr[0]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rr[1][j] = p3[j];
+    __syncthreads();                                                       // (C): pairs 0, 1 in the V ring, pair 2 in raws[0], pair 3 in register set 1
 #ifdef RPN_EXP_WN_NOSTAGE    /* timing experiment (wrong results): the staging waves only keep the barriers */
-#define RPN_WN_STAGE(S, SET) __syncthreads();
+#define RPN_WN_STAGE(P, SET) __syncthreads();
 #else
-#define RPN_WN_STAGE(S, SET)                                                                                                \
+#define RPN_WN_STAGE(P, SET)                                                                                                \
 {                                                                                                                       \
-    RPN_WN_LOAD_RAW((S) + 4 < last ? (S) + 4 : last, SET);                                                              \
-    transform(SET, vnext);                                           /* slice S + 2: raws[S & 1] -> V[(S + 2) % 3] */   \
-    RPN_WN_RAW_TO_LDS((SET) ^ 1, (SET) ^ 1);                         /* slice S + 3 */                                  \
-    vnext = vnext + kWnVFloats == 3 * kWnVFloats ? 0 : vnext + kWnVFloats;                                              \
-    RPN_WN_STAMP((S) < 28 ? 2 * (S) : 99);                                                                              \
+    RPN_WN_LOAD_PAIR(rr[SET], (P) + 4 < last ? (P) + 4 : last);                                                         \
+    transform(SET, vnext);                                           /* pair P + 2: raws[P & 1] -> ring buffer (P + 2) % 3 */ \
+    RPN_WN_RAW_TO_LDS((SET) ^ 1, rr[(SET) ^ 1]);                     /* pair P + 3 */                                   \
+    vnext = vnext + 2 * kWnVFloats == 6 * kWnVFloats ? 0 : vnext + 2 * kWnVFloats;                                      \
+    RPN_WN_STAMP((P) < 14 ? 4 * (P) + 2 : 99);                                                                          \
     __syncthreads();                                                                                                    \
-    RPN_WN_STAMP((S) < 28 ? 2 * (S) + 1 : 99);                                                                          \
+    RPN_WN_STAMP((P) < 14 ? 4 * (P) + 3 : 99);                                                                          \
 }
 #endif
     {
-        int vnext = 2 * kWnVFloats;                                  // V buffer of slice s + 2
+        int vnext = 4 * kWnVFloats;                                  // ring buffer of pair P + 2
         (void)vnext;
-        int s = 0;
-        for (; s + 1 < n_slices; s += 2) {
-            RPN_WN_STAGE(s, 0);
-            RPN_WN_STAGE(s + 1, 1);
+        int P = 0;
+        for (; P + 1 < n_pairs; P += 2) {
+            RPN_WN_STAGE(P, 0);
+            RPN_WN_STAGE(P + 1, 1);
         }
-        if (s < n_slices) RPN_WN_STAGE(s, 0);
+        if (P < n_pairs) RPN_WN_STAGE(P, 0);
     }
-    // the next tile's first four slices: in flight across this tile's epilogue (eight 16-byte registers per thread)
+    // the next tile's first four pairs: in flight across this tile's epilogue (twelve 16-byte registers per thread)
     if (t + t_step < t_total) {
         wn_advance(tl, st, tiles_x, tiles_y, n_tiles);
         xrs = wn_image_rsrc(a, tl.img);
@@ -1306,9 +1300,10 @@ do {                                                                            
     }   // tile loop
 #undef RPN_WN_STAGE
 #undef RPN_WN_REQUEST_TILE
-#undef RPN_WN_LOAD_RAW
+#undef RPN_WN_LOAD_PAIR
 #undef RPN_WN_RAW_TO_LDS
 }
+
 
 __global__ void __launch_bounds__(kW4Threads, 1)
 conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
@@ -1316,7 +1311,7 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     // two arrays of 72 KB: the slice loop uses ldsVR only (V x 2: 18 KB, raw x 2: 11.6 KB); the epilogue parks the 36 x 16 x 64
     // accumulators of a phase (144 KB) over both: xi 0 .. 17 in ldsA, xi 18 .. 35 in ldsVR
     constexpr int kHalf = 18 * kWnNT * 64;                                 // floats per array
-    static_assert(kWnRawAt + 2 * kW4KS * kWnPlane <= kHalf, "LDS layout");
+    static_assert(6 * kWnVFloats <= kHalf && 4 * kW4KS * kWnPlane <= kHalf, "LDS layout");
     __shared__ __attribute__((aligned(16))) float ldsA[kHalf];
     __shared__ __attribute__((aligned(16))) float ldsVR[kHalf];
 
@@ -1394,7 +1389,7 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #else
         const int nxt = s + 1 < n_slices ? s + 1 : s;                 // (past the end: the last slice again, unused)
 #endif
-        vcur = vcur + kWnVFloats == 3 * kWnVFloats ? 0 : vcur + kWnVFloats;       // V buffer of slice s + 1 (past the end: stale, unused)
+        vcur = vcur + kWnVFloats == 6 * kWnVFloats ? 0 : vcur + kWnVFloats;       // ring buffer of slice s + 1 (past the end: stale, unused)
         const float *Vn = ldsVR + vcur;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1412,13 +1407,16 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #endif
-        RPN_WN_STAMP(s < 28 ? 2 * s : 99);
-        // a bare barrier: this role writes no LDS in the loop, and its last operand read must NOT be waited for here (__syncthreads'
-        // fence would: `s_waitcnt lgkmcnt(0)`) -- the MFMAs that consume it sit in front of the next barrier, which is what keeps
-        // the staging waves from overwriting that V buffer (two iterations later) before it is read
-        __builtin_amdgcn_s_barrier();
+        // ONE barrier per PAIR of slices (the staging waves work in pairs: w4n_staging_role), behind the pair's second slice.  A bare
+        // barrier: this role writes no LDS in the loop, and its last operand read must NOT be waited for here (__syncthreads' fence
+        // would: `s_waitcnt lgkmcnt(0)`) -- the MFMAs that consume it sit in front of the next barrier, which is what keeps the
+        // staging waves from overwriting that ring buffer (two pairs later) before it is read
+        if (s & 1) {
+            RPN_WN_STAMP(s < 28 ? 2 * s : 99);
+            __builtin_amdgcn_s_barrier();
+            RPN_WN_STAMP(s < 28 ? 2 * s + 1 : 99);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        RPN_WN_STAMP(s < 28 ? 2 * s + 1 : 99);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (the operand reads past the end: landed before LDS is re-used)
     RPN_WN_STAMP(62);
