@@ -545,9 +545,7 @@ static hipError_t launch_variant_p(const ConvArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((conv_igemm_f32<WM, WN, MI, NI, true, POOL>), dim3((unsigned)nblocks), dim3(kConvThreads), 0,
                            stream, a, tiles_x, tiles_y, n_tiles);
     else {
-        // (laboratory builds: RPN_F32_DMA=0: register-staged kernel everywhere, 2: DMA kernel everywhere; same bits)
-        // the DMA kernel on the 128-wide tile (+2.5 ... 3.6 % per layer); the narrower tiles are what small grids get (two
-        // workgroups per CU: nothing covers the DMA's longer latency there -- 31 x 31 x 512 at batch 8: 0.406 against 0.341 ms)
+        // (conv_f32_uses_dma: the DMA kernel on every tile width since round 6; same bits as the register-staged kernel)
         if (conv_f32_uses_dma(BN, 0)) {
             if (lean)
                 hipLaunchKernelGGL((conv_igemm_f32_dma<WM, WN, MI, NI, POOL, true>), dim3((unsigned)nblocks), dim3(kConvThreads), 0, stream,
@@ -598,8 +596,12 @@ int conv_f32_tile_n(int B, int OH, int OW, int Cout)
 
 bool conv_f32_uses_dma(int tile_n, int generic)
 {
+    // (round 6: on every tile width -- with the fetch's source offsets computed once per tap the DMA kernel is 3 % faster on the 64-wide
+    // tiles too (block1_conv2 1.186 -> 1.146 ms, the 31 x 31 layers 0.336 -> 0.325 at batch 8); rounds 3-5 used it for 128-wide tiles
+    // only.  Laboratory knob: 0 = the register-staged kernel everywhere, 3 = the old rule.  Same bits either way.)
     static const int dma = RPN_LAB_KNOB("RPN_F32_DMA", 1);
-    return !generic && (dma == 2 || (dma == 1 && tile_n == 128));
+    (void)tile_n;
+    return !generic && (dma == 1 || dma == 2 || (dma == 3 && tile_n == 128));
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, hipStream_t stream)
