@@ -19,32 +19,28 @@ def run(B, H, Cin, Cout):
     assert raw.rpn_debug_read_wn_stamps(st.ctypes.data, n) == 0
     s = st.reshape(64, 16, 64).astype(np.int64)
     ns = min(28, Cin // 4)
-    arr, rel = s[:, :, 0:2 * ns:2], s[:, :, 1:2 * ns:2]
-    work = arr[:, :, 1:] - rel[:, :, :-1]          # slice s's work (s >= 1)
+    npair = ns // 2
+    # slots (conv_wino_kernels.hip): MFMA waves stamp 2 s / 2 s + 1 around the barrier behind every ODD slice s; staging waves stamp
+    # 4 P + 2 / 4 P + 3 around the barrier of pair P -- the same slots
+    arr, rel = s[:, :, 2:4 * npair:4], s[:, :, 3:4 * npair:4]
+    work = arr[:, :, 1:] - rel[:, :, :-1]          # a pair's work (pair >= 1)
     wait = rel - arr
     period = rel[:, :, 1:] - rel[:, :, :-1]
-    sl = slice(3, ns - 1)
-    print("layer B%d %dx%d %d->%d  slices stamped %d" % (B, H, H, Cin, Cout, ns))
-    print("  slice period (release to release), median over workgroups/waves: %d cycles" % np.median(period[:, :, sl]))
-    print("  MFMA waves 0..11: work median %d [p10 %d p90 %d]  wait at the barrier median %d [p10 %d p90 %d]" % (
-        np.median(work[:, :12, sl]), *np.percentile(work[:, :12, sl], [10, 90]), np.median(wait[:, :12, 4:ns - 1]), *np.percentile(wait[:, :12, 4:ns - 1], [10, 90])))
-    print("  staging waves 12..15: work median %d [p10 %d p90 %d]  wait median %d [p10 %d p90 %d]" % (
-        np.median(work[:, 12:, sl]), *np.percentile(work[:, 12:, sl], [10, 90]), np.median(wait[:, 12:, 4:ns - 1]), *np.percentile(wait[:, 12:, 4:ns - 1], [10, 90])))
-    # who arrives last at a barrier?  index of the latest arrival per (workgroup, slice)
-    last = arr[:, :, 4:ns - 1].argmax(axis=1)
+    sl = slice(2, npair - 1)
+    print("layer B%d %dx%d %d->%d  pairs of slices stamped %d" % (B, H, H, Cin, Cout, npair))
+    print("  pair period (release to release), median over workgroups/waves: %d cycles = %d per slice" % (np.median(period[:, :, sl]), np.median(period[:, :, sl]) / 2))
+    print("  MFMA waves 0..11: work per pair median %d [p10 %d p90 %d]  wait at the barrier median %d [p10 %d p90 %d]" % (
+        np.median(work[:, :12, sl]), *np.percentile(work[:, :12, sl], [10, 90]), np.median(wait[:, :12, 2:npair - 1]), *np.percentile(wait[:, :12, 2:npair - 1], [10, 90])))
+    print("  staging waves 12..15: work per pair median %d [p10 %d p90 %d]  wait median %d [p10 %d p90 %d]" % (
+        np.median(work[:, 12:, sl]), *np.percentile(work[:, 12:, sl], [10, 90]), np.median(wait[:, 12:, 2:npair - 1]), *np.percentile(wait[:, 12:, 2:npair - 1], [10, 90])))
+    last = arr[:, :, 2:npair - 1].argmax(axis=1)
     print("  last arriver is a staging wave in %.0f %% of the barriers" % (100.0 * (last >= 12).mean()))
-    lag = arr[:, 12:, 4:ns - 1].max(axis=1) - arr[:, :12, 4:ns - 1].max(axis=1)
-    print("  (latest staging arrival) - (latest MFMA arrival): median %d [p10 %d p90 %d]" % (np.median(lag), *np.percentile(lag, [10, 90])))
-    spread = arr[:, :12, 4:ns - 1].max(axis=1) - arr[:, :12, 4:ns - 1].min(axis=1)
-    print("  MFMA waves' arrival spread: median %d [p90 %d]" % (np.median(spread), np.percentile(spread, 90)))
     m = s[:, :12, :]
     tot, pro, loop, epi = m[:, :, 63] - m[:, :, 60], m[:, :, 61] - m[:, :, 60], m[:, :, 62] - m[:, :, 61], m[:, :, 63] - m[:, :, 62]
     rt = (m[:, :, 59] - m[:, :, 58]).astype(np.float64)          # s_memrealtime ticks of 10 ns
     print("  per workgroup (MFMA waves, median): total %d = prologue %d + loop %d (%d per slice) + epilogue %d cycles;  in-kernel clock %.2f GHz" % (
         np.median(tot), np.median(pro), np.median(loop), np.median(loop) / (Cin // 4), np.median(epi), np.median(tot / np.maximum(rt, 1.0)) * 0.1))
-    w0 = s[0]
-    print("  workgroup 0: entry->loop %d, loop %d (%d slices), per-wave first work:" % (np.median(w0[:12, 61] - w0[:12, 60]), np.median(w0[:12, 62] - w0[:12, 61]), Cin // 4),
-          (arr[0, :, 5] - rel[0, :, 4]).tolist())
+    print("  (persistent workgroups: the stamps are those of a workgroup's LAST tile -- its prologue had its first pairs requested in front of the previous epilogue)")
 cfgs = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 125, 256, 256), (8, 250, 128, 128)]
 for cfg in cfgs:
     run(*cfg)
