@@ -29,9 +29,9 @@ def _elf_notes(elf):
             yield name, ntype, desc
 
 
-def kernels(so_path):
+def code_objects(so_path):
+    """The gfx950 ELF images inside the library's offload bundles."""
     blob = open(so_path, "rb").read()
-    out = {}
     for m in re.finditer(MAGIC, blob):
         base = m.start()
         n, = struct.unpack_from("<Q", blob, base + len(MAGIC))
@@ -42,13 +42,52 @@ def kernels(so_path):
             pos += 24 + tlen
             if "amdgcn" not in triple or size == 0:
                 continue
-            elf = blob[base + offset:base + offset + size]
-            for name, ntype, desc in _elf_notes(elf):
-                if name == b"AMDGPU" and ntype == 32:
-                    meta = msgpack.unpackb(desc, raw=False, strict_map_key=False)
-                    for k in meta.get("amdhsa.kernels", []):
-                        out[k[".name"]] = k
+            yield blob[base + offset:base + offset + size]
+
+
+def kernels(so_path):
+    out = {}
+    for elf in code_objects(so_path):
+        for name, ntype, desc in _elf_notes(elf):
+            if name == b"AMDGPU" and ntype == 32:
+                meta = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                for k in meta.get("amdhsa.kernels", []):
+                    out[k[".name"]] = k
     return out
+
+
+def _vregs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def store_data_hazards(asm_text):
+    """Candidates for the store-data hazard hipcc does not guard on gfx950 (NOTES round 6, scripts/micro/store_hazard.hip): a buffer store
+    of MORE than 64 bits whose scalar offset is a REGISTER, followed -- with no other instruction in between -- by an instruction that
+    writes one of the store's data registers.  (One wait state is enough; with a constant scalar offset the compiler inserts two itself;
+    dword stores are not affected.)  Accepts `hipcc -S` output and `llvm-objdump -d` output.  Returns [(kernel, store, next)]."""
+    found, kernel, prev = [], "?", None
+    for raw in asm_text.splitlines():
+        line = raw.split("//")[0].split(";")[0].strip()
+        m = re.match(r"(?:[0-9a-f]+ <)?(_Z\w+)>?:$", line)
+        if m:
+            kernel, prev = m.group(1), None
+            continue
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        if prev is not None:
+            op = line.split()[0]
+            if op.startswith(("v_", "ds_read", "buffer_load", "global_load")) and not op.startswith("v_cmp") and len(line.split()) > 1:
+                if _vregs(line.split()[1].rstrip(",")) & prev[0]:
+                    found.append((kernel, prev[1], line))
+        prev = None
+        m = re.match(r"buffer_store_dwordx([34])\s+(v\[\d+:\d+\]),\s*(\S+),\s*(s\[\d+:\d+\]),\s*(\S+)", line)
+        if m and re.fullmatch(r"s\d+|m0|vcc_lo|vcc_hi", m.group(5)):
+            prev = (_vregs(m.group(2)), line)
+    return found
 
 
 def short_name(mangled):

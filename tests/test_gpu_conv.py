@@ -81,6 +81,45 @@ def test_conv2d_no_bias_matches():
     assert np.abs(_conv_gpu(x, w, None, 1, 1, 1, 12, 12, "linear") - ref).max() <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 3, 15), (1, 5, 16), (1, 4, 17), (2, 9, 64), (1, 8, 65), (1, 2, 66), (3, 7, 130),
+                                   (1, 13, 500), (1, 17, 70), (2, 16, 129)], ids=lambda s: "x".join(map(str, s)))
+def test_first_layer_float32_matrix_pipe_kernel(shape):
+    """conv_cin3_f32_mfma_kernel (VGG16 block1_conv1 of the float32 graphs: Cin 3 -> 64, 'same'): every border case of its 64-pixel row
+    segments and 8-row tiles (widths 1 .. 500 around the 16 / 64 steps, heights that leave waves without a row), ReLU and linear,
+    with and without a bias, against float64 and against the plain-C direct convolution."""
+    B, H, W = shape
+    rng = np.random.RandomState(B * 1000 + H * 31 + W)
+    x = rng.uniform(-1, 1, size=(B, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(64,)).astype(np.float32)
+    for act, bias in (("relu", b), ("linear", b), ("linear", None)):
+        ref = cv.conv2d_nhwc(x, w, bias, pad=(1, 1, 1, 1), act=act, dtype=torch.float64)
+        got = _conv_gpu(x, w, bias, 1, 1, 1, H, W, act)
+        assert not np.isnan(got).any(), "some outputs were never written"
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+        if bias is not None:
+            cref = co.conv2d(x, w, bias, stride=1, pad_t=1, pad_l=1, out_hw=(H, W), act=act)
+            assert np.abs(got - cref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max()))     # (both are bias-first fma chains in tap order)
+
+
+def test_first_layer_float32_matrix_pipe_kernel_is_exact_on_integers_at_full_size():
+    """Batch 4 of 500 x 500 (the persistent kernel's tile loop, ~4 tiles per workgroup, the chip's store path busy) with small-integer
+    images, weights and biases: every product and sum is exact in float32, so the kernel must match torch's convolution BIT FOR BIT,
+    twice.  (The first build of this kernel passed every tolerance test of small shapes and stored garbage into 0.006 % of these
+    outputs, differently from run to run: a store-data hazard hipcc does not guard -- tests/test_host.py scans for it.)"""
+    rng = np.random.RandomState(12)
+    B, H, W = 4, 500, 500
+    x = rng.randint(-4, 5, size=(B, H, W, 3)).astype(np.float32)
+    w = rng.randint(-3, 4, size=(3, 3, 3, 64)).astype(np.float32)
+    b = rng.randint(-2, 3, size=(64,)).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(3, 2, 0, 1), torch.from_numpy(b),
+                                     padding=1).clamp_(min=0).permute(0, 2, 3, 1).numpy()
+    for _ in range(2):
+        got = _conv_gpu(x, w, b, 1, 1, 1, H, W, "relu")
+        wrong = np.argwhere(got != ref)
+        assert len(wrong) == 0, "%d wrong values, first at %s: got %r want %r" % (len(wrong), wrong[0], got[tuple(wrong[0])], ref[tuple(wrong[0])])
+
+
 def test_maxpool_and_depthwise():
     rng = np.random.RandomState(6)
     x = rng.uniform(-1, 1, size=(2, 125, 37, 64)).astype(np.float32)            # odd sizes: 'valid' floors

@@ -88,6 +88,7 @@ KERNEL_BUDGETS = {
     r"rpn_head_kernel<": (192, 0, 49152),
     r"conv3x3_wino_f32_kernel": (168, 0, 160 * 1024),                   # twelve waves (8 MFMA + 4 staging): three per SIMD
     r"conv3x3_wino4_f32_kernel": (128, 96, 160 * 1024),                 # (round 6: 80 SGPRs parked in VGPR lanes, none inside the slice loops)                  # sixteen waves (12 MFMA + 4 staging): four per SIMD
+    r"conv_cin3_f32_mfma_kernel": (168, 0, 20 * 1024),                  # first layer of the float32 graphs: three persistent workgroups per CU
     r"conv3x3_wino4n_f32_kernel": (128, 8, 160 * 1024),                 # the wide form: the same sixteen waves (persistent: four scalars parked in lanes)
 }
 
@@ -105,6 +106,35 @@ def test_kernel_register_budgets(lib):
             assert sspill <= max_sspill, "%s: %d SGPR spills > %d" % (name, sspill, max_sspill)
             assert vspill == 0 and scratch == 0, "%s spills to scratch" % name
             assert lds <= max_lds, "%s: %d B of LDS > %d" % (name, lds, max_lds)
+
+
+def test_no_unguarded_store_data_hazard(lib, tmp_path):
+    """gfx950 needs one wait state between a 16-byte buffer store whose scalar offset is a REGISTER and a vector instruction that
+    overwrites the store's data registers; hipcc inserts none (it guards the constant-offset form only) and the first float32-MFMA
+    first-layer kernel stored an LDS address into 0.5 % of its outputs (scripts/micro/store_hazard.hip measures the rule).  The shipped
+    library's disassembly must not contain the pattern."""
+    import shutil
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import codeobj
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump")
+    if not objdump:
+        pytest.skip("no llvm-objdump")
+    bad = codeobj.store_data_hazards("_Z3foov:\n buffer_store_dwordx4 v[18:21], v26, s[12:15], s54 offen\n v_add_u32_e32 v18, 0x1000, v120\n")
+    assert len(bad) == 1                                    # (the scanner itself: the instruction pair of the bug)
+    assert not codeobj.store_data_hazards("_Z3foov:\n buffer_store_dwordx4 v[18:21], v26, s[12:15], s54 offen\n s_nop 0\n v_add_u32_e32 v18, 0x1000, v120\n")
+    n = stores = 0
+    for elf in codeobj.code_objects(L.LIB_PATH):
+        f = tmp_path / ("co%d.elf" % n)
+        f.write_bytes(elf)
+        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(f)], capture_output=True, text=True, check=True).stdout
+        stores += text.count("buffer_store_dwordx4")
+        found = codeobj.store_data_hazards(text)
+        assert not found, found[:3]
+        n += 1
+    assert n >= 8 and stores > 500                          # (every code object of the library was disassembled)
 
 
 def test_no_torch_types_in_the_abi():

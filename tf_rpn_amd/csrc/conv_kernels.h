@@ -199,6 +199,9 @@ hipError_t launch_vgg_block1(const float *img, const void *w1, const float *b1, 
 hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, void *out, int B, int H, int W,
                             int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
                             hipStream_t s);
+// true when launch_conv_cin3 runs the layer on the float32 matrix pipe (conv_cin3_f32_mfma_kernel: float32 output, 64 channels,
+// stride 1, 'same', ReLU / linear, the image's output below 2 GiB) instead of the vector-ALU kernel
+bool conv_cin3_uses_f32_mfma(int B, int H, int W, int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt);
 
 // first layer on the matrix cores (split precisions only): Cout in {32, 64}; w = pack_weights_cin3_mfma_host output
 void pack_weights_cin3_mfma_host(const float *hwio, const float *scale, int Cout, int cout_pad, bool f16, int shift,

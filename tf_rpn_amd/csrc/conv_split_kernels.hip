@@ -2223,12 +2223,227 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
     }
 }
 
+// ---- first layer of the float32 graphs on the float32 matrix pipe (round 6): Cin = 3, 3x3, stride 1, 'same', Cout = 64 --------
+// VGG16 block1_conv1 in the f32 / f32w precisions.  The vector-ALU kernel above needs 432 packed FMAs + a staged store per thread and
+// ran at 0.154 ms (batch 8, 500 x 500); a kernel that ONLY writes the layer's 512 MB takes 0.092 ms with 32 waves per CU and 0.12 ms
+// with 8 (scripts/micro/store_rate.hip, store_overlap.hip).  This one: 0.139 ms.
+// The 27 taps are ONE K = 28 reduction of v_mfma_f32_16x16x4_f32 (twice the vector ALU's FMA rate): the WEIGHTS are the A operand
+// (rows = 16 output channels), a 16-pixel run of an output row is the B operand (columns), so that a lane's four accumulators are four
+// CONSECUTIVE channels of one pixel -- a 16-byte store, four lanes complete 64 contiguous bytes, no transpose through LDS.  K index
+// e = 9 r + 3 s + c (filter row, filter column, input channel) = the (27, Cout) weight order; for a fixed r the nine (s, c) values of a
+// pixel are nine CONSECUTIVE floats of input row y + r - 1 starting at 3 (x - 1).  Bias first, then k ascending: the order of the
+// vector-ALU kernel's chain.
+// A first form read the B operand straight from global memory (one dword per lane and K step) and the weights per wave: 72 narrow
+// load instructions per wave, and the texture-address path alone took 0.076 ms of its 0.166.
+// So: PERSISTENT workgroups (the 28 + 16 weight / bias registers are loaded once per workgroup, not per tile), a tile = 8 output rows x
+// 64 pixels (a wave = rows wv and wv + 4), its 10 x 66-pixel input patch staged through LDS by 8 coalesced dword loads per thread
+// (requested one tile ahead, double-buffered: ONE barrier per tile), the B operand read from there (ds_read_b32, conflict-free: lanes
+// 12 bytes apart).  The float32 MFMA executes on the vector ALU's lanes, so every other instruction of the tile loop is MFMA time
+// as well: the tile's coordinates advance incrementally (two divisions per tile were ~90 scalar instructions), interior tiles
+// have their tile offset in the loads' SCALAR offset (no per-lane address arithmetic), ReLU is one integer max.
+// Reference op: Conv2D(64, (3, 3), padding="same", activation="relu") = VGG16 block1_conv1 behind /root/reference/rpn.py:26-33.
+constexpr int kC3Rows = 8;                          // output rows per tile
+constexpr int kC3PatchRow = 200;                    // floats per staged patch row (198 used)
+constexpr int kC3Stage = ((kC3Rows + 2) * 198 + 255) / 256;            // staging loads per thread (8)
+constexpr int kC3PatchFloats = (kC3Stage * 256 / 198 + 1) * kC3PatchRow;   // 10 rows + the row that takes the idle threads' writes
+struct C3Tile {
+    int img, by, bx;
+};
+template <bool RELU>
+__global__ void __launch_bounds__(256, 2)       // (<= 256 registers: the accumulators stay in the VGPR file, no v_accvgpr copies)
+conv_cin3_f32_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27, 64) */, const float *__restrict__ bias,
+                          float *__restrict__ out, int H, int W, int tiles_x, int tiles_y, int n_tiles)
+{
+    __shared__ float patch[2][kC3PatchFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kq = lane >> 4;
+    constexpr unsigned kOob = 0x80000000u;
+    float aw[7][4];                                                      // A: W[channel 16 nb + (lane & 15)][k = 4 kk + kq]
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+        const int k = 4 * kk + kq;                                       // (k = 27, the padding: row 26 read, zero kept)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float v = w[(k < 27 ? k : 26) * 64 + nb * 16 + px];
+            aw[kk][nb] = k < 27 ? v : 0.0f;
+        }
+    }
+    f32x4 bv[4];                                                         // the lane's channels 16 nb + 4 kq + (0..3)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) bv[nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) {                                                          // (the caller's pointer: 4-byte alignment only)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[nb][i] = bias[nb * 16 + 4 * kq + i];
+    }
+    int rd[7];                                                           // B: patch[row wv + 4 h + r][3 (16 mb + px) + t] of k = 9 r + t, floats
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+        const int e = 4 * kk + kq < 27 ? 4 * kk + kq : 26, r = e / 9, t = e - 9 * r;   // (k = 27: any address, its weight is 0 -- but finite data: row 26's)
+        rd[kk] = (wv + r) * kC3PatchRow + 3 * px + t;
+    }
+    // staging: element i = tid + 256 it of the 10 x 198 patch (row r = i / 198, float j of the row: column x0 - 1 + j / 3)
+    int st_lds[kC3Stage];
+    unsigned st_off[kC3Stage];                                           // byte offset from the patch's first float; out of range for the idle threads
+#pragma unroll
+    for (int it = 0; it < kC3Stage; ++it) {
+        const int i = tid + 256 * it, r = i / 198, j = i - 198 * r;
+        st_lds[it] = r * kC3PatchRow + j;
+        st_off[it] = r < kC3Rows + 2 ? (unsigned)((r * W * 3 + j) * 4) : kOob;
+    }
+    const int tiles_xy = tiles_x * tiles_y;
+    // tile t = (img, by, bx); a workgroup's tiles are gridDim.x apart: the step as (d_img, d_by, d_bx), added with carries
+    const int g = (int)gridDim.x, d_img = g / tiles_xy, d_by = (g - d_img * tiles_xy) / tiles_x, d_bx = g - d_img * tiles_xy - d_by * tiles_x;
+    auto advance = [&](C3Tile t) {
+        t.bx += d_bx;
+        if (t.bx >= tiles_x) {
+            t.bx -= tiles_x;
+            ++t.by;
+        }
+        t.by += d_by;
+        if (t.by >= tiles_y) {
+            t.by -= tiles_y;
+            ++t.img;
+        }
+        t.img += d_img;
+        return t;
+    };
+    float pre[kC3Stage];
+    auto request = [&](C3Tile t) {                                       // the tile's patch -> registers (zero outside the image)
+        const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + (size_t)t.img * H * W * 3, (short)0,
+                                                                               H * W * 12, 0x00020000);
+        if (t.by >= 1 && t.by * kC3Rows + kC3Rows + 1 <= H && t.bx >= 1 && t.bx * 192 + 195 <= 3 * W) {   // (uniform) all inside the image:
+            const int tbase = (((t.by * kC3Rows - 1) * W * 3) + t.bx * 192 - 3) * 4;   // no vector ALU work -- the tile in the SCALAR offset
+#pragma unroll
+            for (int it = 0; it < kC3Stage; ++it)
+                pre[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, st_off[it], tbase, 0));
+        } else {
+#pragma unroll
+            for (int it = 0; it < kC3Stage; ++it) {
+                const int i = tid + 256 * it, r = i / 198, j = i - 198 * r;
+                const int iy = t.by * kC3Rows - 1 + r, fx = t.bx * 192 - 3 + j;
+                const bool ok = r < kC3Rows + 2 && iy >= 0 && iy < H && fx >= 0 && fx < 3 * W;
+                pre[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rs, ok ? (unsigned)((iy * W * 3 + fx) * 4) : kOob, 0, 0));
+            }
+        }
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < kC3Stage; ++it) patch[buf][st_lds[it]] = pre[it];
+    };
+    const unsigned st_out = (unsigned)((px * 64 + 4 * kq) * 4);          // the lane's bytes from the tile row's first output
+    int tile = blockIdx.x, buf = 0;
+    C3Tile cur;
+    cur.img = tile / tiles_xy;
+    cur.by = (tile - cur.img * tiles_xy) / tiles_x;
+    cur.bx = tile - cur.img * tiles_xy - cur.by * tiles_x;
+    if (tile < n_tiles) {
+        request(cur);
+        deposit(0);
+    }
+    __syncthreads();
+    // The loop body is STRAIGHT-LINE (a row past the image's end computes on zeros and stores out of range; the last tile requests an
+    // out-of-range patch): the vector-memory counter is in order, so "the next patch has arrived" is `s_waitcnt vmcnt(32)` -- the 32
+    // stores issued behind the request may still be in flight -- and hipcc can only count that far when no branch lies between.  With the
+    // stores in a branch the wait became vmcnt(4): every tile waited for its own stores' acknowledgements.
+    for (; tile < n_tiles; tile += g, buf ^= 1) {
+        const bool more = tile + g < n_tiles;
+        C3Tile nxt = advance(cur);
+        if (!more) nxt.by = -0x100000;                                   // (every row out of the image: eight loads that fetch nothing)
+        const int x0 = cur.bx * 64;
+        const bool whole = x0 + 64 <= W;
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)cur.img * H * W * 64, (short)0, H * W * 256,
+                                                                                0x00020000);
+        float pin[4][7];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) pin[mb][kk] = patch[buf][rd[kk] + mb * 48];
+        request(nxt);                                                    // (in flight across the tile's MFMAs)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int y = cur.by * kC3Rows + wv + 4 * h;
+            const bool row = y < H;                                      // (uniform)
+            const int tb = (y * W + x0) * 256;                           // (scalar) the tile row's first output, bytes into the image
+            if (h == 1) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) pin[mb][kk] = patch[buf][4 * kC3PatchRow + rd[kk] + mb * 48];
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = bv[nb];
+#pragma unroll
+                for (int kk = 0; kk < 7; ++kk)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[kk][nb], pin[mb][kk], acc[nb], 0, 0, 0);
+                if constexpr (RELU) {
+                    // max(x, 0) on the BITS (v_max_i32: one instruction; fmaxf is a canonicalising v_max v, v, v + the max).  Negative floats
+                    // are negative integers -> +0; -0.0 -> +0; a NaN with the sign bit clear stays a NaN (as in the reference's ReLU), with
+                    // it set -> 0.
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float f = acc[nb][i];                  // (a VALUE: __builtin_bit_cast of the vector-element lvalue read element 0 four times)
+                            acc[nb][i] = __int_as_float(__builtin_elementwise_max(__float_as_int(f), 0));
+                        }
+                }
+                // The tile offset goes into the VECTOR offset (one v_add per 16 pixels), the scalar offset is the constant 0.  Behind a
+                // 16-byte store whose scalar offset is a REGISTER hipcc leaves NO wait state before a vector instruction that overwrites the
+                // store's data registers (its hazard table knows the hazard for a constant offset only), and gfx950 needs one:
+                // `buffer_store_dwordx4 v[18:21], v26, s[12:15], s54 offen` + `v_add_u32 v18, 0x1000, v120` stored the LDS address in
+                // element 0 of lanes 12-15 of every 16, differently from run to run (scripts/micro/store_hazard.hip measures it: 0.5 % of
+                // the stores with no wait state, none with one; dword stores are not affected).  scripts/isa_store_hazard.py scans the
+                // library's assembly for the pattern.
+                const unsigned vo = (row && (whole || x0 + 16 * mb + px < W)) ? st_out + (unsigned)(tb + mb * 4096) : kOob;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nb]), out_rs, vo + (unsigned)(nb * 64), 0, 0);
+            }
+        }
+        deposit(buf ^ 1);                                                // (the other buffer: every wave left it at the last barrier)
+        cur = nxt;
+        __syncthreads();
+    }
+}
+
+bool conv_cin3_uses_f32_mfma(int B, int H, int W, int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt)
+{
+    // (laboratory knob 0 = the vector-ALU kernel; same contract)
+    static const int f32_mfma = RPN_LAB_KNOB("RPN_CIN3_F32_MFMA", 1);
+    return f32_mfma && out_fmt == 0 && Cout == 64 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W &&
+           (act == ACT_RELU || act == ACT_LINEAR) && (long long)H * W * 256 < 0x7fffffffll && B > 0 && B <= 65535 && H > 0 && W > 0;
+}
+
 // w: (27, Cout) float32 = HWIO flattened (BatchNorm scale already folded); out_fmt: 0 float32 NHWC, 1 SPLIT16
 hipError_t launch_conv_cin3(const float *x, const float *w, const float *bias, void *out, int B, int H, int W,
                             int OH, int OW, int Cout, int stride, int pad_t, int pad_l, int act, int out_fmt, bool f16,
                             hipStream_t s)
 {
     if (Cout % 16 != 0 || Cout > 256 || 256 % (Cout / 16) != 0 || act == ACT_SIGMOID) return hipErrorInvalidValue;
+    if (conv_cin3_uses_f32_mfma(B, H, W, OH, OW, Cout, stride, pad_t, pad_l, act, out_fmt)) {
+        const int tiles_x = (W + 63) / 64, tiles_y = (H + kC3Rows - 1) / kC3Rows;
+        const long long n_tiles = (long long)tiles_x * tiles_y * B;
+        if (n_tiles >= 0x7fffffffll) return hipErrorInvalidValue;
+        int dev = 0, n_cus = 0;                                          // persistent: 3 workgroups per CU (<= 168 registers) of the CURRENT device
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            n_cus < 1)
+            n_cus = 256;
+        const dim3 grid((unsigned)(n_tiles < 3ll * n_cus ? n_tiles : 3ll * n_cus));
+        if (act == ACT_RELU)
+            hipLaunchKernelGGL(conv_cin3_f32_mfma_kernel<true>, grid, dim3(256), 0, s, x, w, bias, static_cast<float *>(out), H, W,
+                               tiles_x, tiles_y, (int)n_tiles);
+        else
+            hipLaunchKernelGGL(conv_cin3_f32_mfma_kernel<false>, grid, dim3(256), 0, s, x, w, bias, static_cast<float *>(out), H, W,
+                               tiles_x, tiles_y, (int)n_tiles);
+        return hipGetLastError();
+    }
     const long long npairs = (long long)B * OH * ((OW + 1) / 2);
     const long long threads = npairs * (Cout / 16);
     if (threads <= 0) return hipSuccess;

@@ -1151,7 +1151,9 @@ extern "C" int rpn_model_op_info(const rpn_model *m, int i, char *name, int name
     } else if (op.kind == OP_CONV && op.cin3) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 27.0;
         by = in_b + out_b;
-        k = op.cin3_mfma ? "conv_cin3_mfma" : "conv_cin3_direct";
+        k = op.cin3_mfma ? "conv_cin3_mfma"
+            : conv_cin3_uses_f32_mfma(1, op.H, op.W, op.OH, op.OW, op.Cout, op.stride, op.pad_t, op.pad_l, op.act,
+                                      m->tensors[op.out].split_fmt ? 1 : 0) ? "conv_cin3_f32_mfma" : "conv_cin3_direct";
     } else if (op.kind == OP_CONV && op.split) {
         fl = 2.0 * op.OH * op.OW * op.Cout * 9.0 * op.Cin;
         by = in_b + out_b + 4.0 * 9 * op.Cin * op.Cout;
