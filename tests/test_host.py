@@ -87,7 +87,7 @@ KERNEL_BUDGETS = {
     r"iou_map_rows_kernel<": (128, 0, 0),
     r"rpn_head_kernel<": (192, 0, 49152),
     r"conv3x3_wino_f32_kernel": (168, 0, 160 * 1024),                   # twelve waves (8 MFMA + 4 staging): three per SIMD
-    r"conv3x3_wino4_f32_kernel": (128, 96, 160 * 1024),                 # (round 6: 80 SGPRs parked in VGPR lanes, none inside the slice loops)                  # sixteen waves (12 MFMA + 4 staging): four per SIMD
+    r"conv3x3_wino4_f32_kernel": (128, 180, 160 * 1024),                # sixteen waves (12 MFMA + 4 staging): four per SIMD; persistent (round 6): 174 scalar spill instructions into VGPR lanes, all in per-TILE code -- none inside the slice loops (checked on the ISA)
     r"conv_cin3_f32_mfma_kernel": (168, 0, 20 * 1024),                  # first layer of the float32 graphs: three persistent workgroups per CU
     r"conv3x3_wino4n_f32_kernel": (128, 8, 160 * 1024),                 # the wide form: the same sixteen waves (persistent: four scalars parked in lanes)
 }

@@ -714,12 +714,58 @@ __device__ __forceinline__ void w4_ksplit_finish(const WinoArgs &a, float *lds, 
     }
 }
 
+// Persistent workgroups of the wide form (round 6): the grid is one workgroup per CU (or fewer), workgroup w walks the tiles
+// L, L + G, L + 2 G, ... (L = wino_xcd_remap(w, G): consecutive tiles -- the N tiles of a pixel block, neighbouring blocks -- on one
+// XCD, as before).  What it buys: the staging waves request the NEXT tile's first four slices in front of the epilogue of the current
+// one, so a tile's prologue no longer waits for a first-touch memory latency (~2.5 k of its ~6.5 k cycles).
+struct WnTile {
+    int img, oy0, ox0, n0, nt;
+};
+// (tw: the tile's pixel width -- 16 in the wide form, 32 in the 64-channel form --, bn: its channel width)
+__device__ __forceinline__ WnTile wn_tile(int t, int tiles_x, int tiles_y, int n_tiles, int tw = 16, int bn = 128)
+{
+    WnTile r;
+    r.nt = t % n_tiles;
+    int mt = t / n_tiles;
+    const int tx = mt % tiles_x;
+    mt /= tiles_x;
+    const int ty = mt % tiles_y;
+    r.img = mt / tiles_y;
+    r.oy0 = ty * 16;
+    r.ox0 = tx * tw;
+    r.n0 = r.nt * bn;
+    return r;
+}
+// tile + step, digit by digit with carries (st = wn_tile(step): its oy0 / ox0 carry the scaled digits): no division per tile
+__device__ __forceinline__ void wn_advance(WnTile &tl, const WnTile &st, int tiles_x, int tiles_y, int n_tiles, int tw = 16, int bn = 128)
+{
+    int nt = tl.nt + st.nt, c = nt >= n_tiles;
+    nt -= c ? n_tiles : 0;
+    int ox = tl.ox0 + st.ox0 + tw * c;
+    c = ox >= tw * tiles_x;
+    ox -= c ? tw * tiles_x : 0;
+    int oy = tl.oy0 + st.oy0 + 16 * c;
+    c = oy >= 16 * tiles_y;
+    oy -= c ? 16 * tiles_y : 0;
+    tl.img += st.img + c;
+    tl.nt = nt; tl.n0 = nt * bn; tl.ox0 = ox; tl.oy0 = oy;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_image_rsrc(const WinoArgs &a, int img)
+{
+    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)img * a.H * a.W * a.Cin, (short)0,
+                                             (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
+}
+
 // The staging role of the 64-channel F(4x4, 3x3) form (waves 12 .. 15), one instantiation per PART (output rows 3 PART .. 3 PART + 2
 // of every pair's transform; pair_half: which 64 of the slice's 128 (tile, channel) pairs): straight-line code, see w4n_staging_role.
+// Round 6, last pass: PERSISTENT like the wide form (one workgroup per CU walks tiles t_first, t_first + t_step, ...; the next tile's
+// first two slices are requested in front of the current tile's epilogue).  With the input channels split over two workgroups
+// (variant 8) the grid is two workgroups per tile as before and t_step = t_total: one turn of the tile loop.
 template <int PART>
 __device__ __forceinline__ void w4_staging_role(const WinoArgs &a, float *ldsU, float *ldsVR, float (*raws)[kW4KS * kW4Plane],
-                                                __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t prs, bool split, int pair_half, int tid,
-                                                int lane, int tile_id, int img, int oy0, int ox0, int n0, int n_slices)
+                                                int pair_half, int tid, int lane, int t_first, int t_step, int t_total, int tiles_x,
+                                                int tiles_y, int n_tiles, int khalf, int s_begin, int n_slices)
 {
     constexpr unsigned kOob = 0x80000000u;
     constexpr int kW4Half = 18 * 32 * 32;
@@ -736,11 +782,25 @@ __device__ __forceinline__ void w4_staging_role(const WinoArgs &a, float *ldsU, 
     for (int j = 0; j < 3; ++j) {
         const int pix = hid + j * 256;
         const int py = pix / kW4PatchW, px = pix - py * kW4PatchW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool v = pix < kW4PatchH * kW4PatchW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
         r_lds[j] = py * kW4Pitch + px + ((py >> 2) & 1) * 2;      // rows of odd tile rows skewed by two floats (see transform)
     }
+    auto set_offsets = [&](const WnTile &tl) {                    // this thread's source offsets inside the tile's image
+        int h = hid;                                              // (opaque: the pixel's row / column are recomputed per tile, not kept in
+        asm volatile("" : "+v"(h));                               // registers across the tile loop)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int pix = h + j * 256;
+            const int py = pix / kW4PatchW, px = pix - py * kW4PatchW;
+            const int iy = tl.oy0 - 1 + py, ix = tl.ox0 - 1 + px;
+            const bool v = pix < kW4PatchH * kW4PatchW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            r_off[j] = v ? (unsigned)(((iy * a.W + ix) * a.Cin) * 4) : kOob;
+        }
+    };
+    auto image_rsrc = [&](int img) {                              // the image's input from this workgroup's first slice on
+        const long long xbytes = (long long)a.H * a.W * a.Cin * 4 - (long long)s_begin * kW4KS * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)img * a.H * a.W * a.Cin + s_begin * kW4KS, (short)0,
+                                                 (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
+    };
     const bool third = hid + 512 < kW4PatchH * kW4PatchW;
     // transform role: a lane = one (tile, channel) pair, two WAVES per pair (output rows 3 part .. 3 part + 2)
     // (the part is wave-uniform: with a lane-dependent part every wave runs both halves of the row transform under exec masks.
@@ -816,8 +876,14 @@ do {                                                                            
     // iteration t - 3, transformed into V[t % 3] in iteration t - 2, read by the MFMA waves during iteration t - 1, multiplied in
     // iteration t; no conditions in the loop body (requests clamped to the last slice, the tail works on stale data nobody reads).
     const int last = n_slices - 1;
+    const bool split = a.ksplit == 2;
+    WnTile tl = wn_tile(t_first, tiles_x, tiles_y, n_tiles, 4 * kW4TX, kWinoBN);
+    __amdgpu_buffer_rsrc_t xrs = image_rsrc(tl.img);
+    set_offsets(tl);
     RPN_W4_LOAD_RAW(0, 0);
     RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);
+    for (int t = t_first; t < t_total; t += t_step) {
+    const int tile_id = t, img = tl.img, oy0 = tl.oy0, ox0 = tl.ox0, n0 = tl.n0;
     u32x4_w p2[3], p3[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -854,14 +920,27 @@ do {                                                                            
         if (s < n_slices) RPN_W4_STAGE(s, 0);
     }
 #undef RPN_W4_STAGE
+    // the next tile's first two slices: in flight across this tile's epilogue
+    if (t + t_step < t_total) {
+        tl = wn_tile(t + t_step, tiles_x, tiles_y, n_tiles, 4 * kW4TX, kWinoBN);     // (by division: see the MFMA role)
+        xrs = image_rsrc(tl.img);
+        set_offsets(tl);
+        RPN_W4_LOAD_RAW(0, 0);
+        RPN_W4_LOAD_RAW(1 < last ? 1 : last, 1);
+    }
     // ---- epilogue: two phases of 32 output channels; every thread of the workgroup transforms one (tile, channel) pair per phase
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        split ? a.part + ((size_t)tile_id * 2 + khalf) * (512 * kWinoBN) : nullptr, (short)0, split ? 512 * kWinoBN * 4 : 0, 0x00020000);
+    int tid_o = tid;                                             // (opaque: what the epilogue derives from the thread index is invariant in
+    asm volatile("" : "+v"(tid_o));                              //  the tile loop and was hoisted in front of it -- into scratch)
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         __syncthreads();                                         // the phase's accumulators are in LDS
-        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
+        w4_output_pair(a, ldsU, ldsVR, tid_o, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
         __syncthreads();                                         // the staging area may be overwritten
     }
-    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
+    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid_o, tile_id, img, oy0, ox0, n0);
+    }   // tile loop
 #undef RPN_W4_LOAD_RAW
 #undef RPN_W4_RAW_TO_LDS
 }
@@ -883,44 +962,41 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int khalf = a.ksplit == 2 ? (wg & 1) : 0;      // K split: the two halves of a tile are neighbours (same XCD, same time)
-    if (a.ksplit == 2) wg >>= 1;
-    const int tile_id = wg;
-    const int nt = wg % n_tiles;
-    int mt = wg / n_tiles;
-    const int tx = mt % tiles_x;
-    mt /= tiles_x;
-    const int ty = mt % tiles_y;
-    const int img = mt / tiles_y;
-    const int oy0 = ty * 4 * kW4TY, ox0 = tx * 4 * kW4TX, n0 = nt * kWinoBN;
+    // persistent workgroups (see w4_staging_role): tiles t_first, t_first + t_step, ...; both roles walk the same tiles with the same
+    // number of barriers per tile.  K split (variant 8): two workgroups per tile -- neighbours: same XCD, same time --, one turn.
+    const int wg = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int t_total = tiles_x * tiles_y * a.B * n_tiles;
+    const int khalf = a.ksplit == 2 ? (wg & 1) : 0;
+    const int t_first = a.ksplit == 2 ? wg >> 1 : wg, t_step = a.ksplit == 2 ? t_total : (int)gridDim.x;
 
     const int all_slices = a.Cin / kW4KS;
     const int s_begin = khalf ? all_slices / 2 : 0;      // this workgroup's slices [s_begin, s_begin + n_slices)
     const int n_slices = a.ksplit == 2 ? (khalf ? all_slices - all_slices / 2 : all_slices / 2) : all_slices;
-    const float *__restrict__ xin = a.x + (size_t)img * a.H * a.W * a.Cin + s_begin * kW4KS;
-    constexpr unsigned kOob = 0x80000000u;
-    const long long xbytes = (long long)a.H * a.W * a.Cin * 4 - (long long)s_begin * kW4KS * 4;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xin), (short)0, (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
-    const float *ubase = a.u + ((size_t)nt * all_slices + s_begin) * kW4UFloats;
     const long long ubytes = (long long)n_slices * kW4UFloats * 4;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        a.ksplit == 2 ? a.part + ((size_t)tile_id * 2 + khalf) * (512 * kWinoBN) : nullptr, (short)0, a.ksplit == 2 ? 512 * kWinoBN * 4 : 0, 0x00020000);
     const bool split = a.ksplit == 2;
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), (short)0, (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
 
     const bool stager = wave >= 12;
-    const int hid = tid - 768;             // staging thread 0 .. 255
-    const int kh = lane >> 5, l31 = lane & 31;
 
     if (stager) {
         const int sw = wave - 12;          // t_part = sw & 1, pairs (sw >> 1) * 64 .. + 63
-        if (sw & 1) w4_staging_role<1>(a, ldsU, ldsVR, raws, xrs, prs, split, sw >> 1, tid, lane, tile_id, img, oy0, ox0, n0, n_slices);
-        else w4_staging_role<0>(a, ldsU, ldsVR, raws, xrs, prs, split, sw >> 1, tid, lane, tile_id, img, oy0, ox0, n0, n_slices);
+        if (sw & 1) w4_staging_role<1>(a, ldsU, ldsVR, raws, sw >> 1, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, khalf, s_begin, n_slices);
+        else w4_staging_role<0>(a, ldsU, ldsVR, raws, sw >> 1, tid, lane, t_first, t_step, t_total, tiles_x, tiles_y, n_tiles, khalf, s_begin, n_slices);
         return;
     }
 
     // ---- MFMA waves: xi = 3 wave + j, 32 tiles x 64 channels
+    for (int t = t_first; t < t_total; t += t_step) {
+    // (the tile's coordinates by division, once per ~60 k-cycle tile: carried incrementally -- wn_advance -- they were ten more scalar
+    // registers across a slice loop that already parks scalars in vector-register lanes)
+    const WnTile tl = wn_tile(t, tiles_x, tiles_y, n_tiles, 4 * kW4TX, kWinoBN);
+    const int tile_id = t, img = tl.img, oy0 = tl.oy0, ox0 = tl.ox0, n0 = tl.n0;
+    // (the lane index re-derived per tile, opaque: what is computed from it is otherwise hoisted out of the tile loop and kept in
+    // registers the 128-register slice loop does not have -- see conv3x3_wino4n_f32_kernel)
+    int lane_t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+    const int kh = lane_t >> 5, l31 = lane_t & 31;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.u) + ((size_t)tl.nt * all_slices + s_begin) * kW4UFloats, (short)0,
+                                                                          (int)(ubytes > 0x7fffffffll ? 0x7fffffff : ubytes), 0x00020000);
     f32x16_w acc[3][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -987,7 +1063,12 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
     // loop's buffers are dead), then every thread transforms one (tile, channel) pair; the accumulators of the other N block stay in
     // registers meanwhile (48 + the transform's ~60: inside the 128 a sixteen-wave workgroup may have).  (First version: four rounds
     // of 16 channels transformed by the 256 staging threads alone: 32 k cycles per workgroup, 10 % of a 256-channel layer.)
+    int lane_e;                                                           // (opaque again: see lane_t)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int tid_e = wave * 64 + lane_e, khe = lane_e >> 5, l31e = lane_e & 31;
     float *park = wave < 6 ? ldsU : ldsVR - kW4Half;                       // xi = 3 wave + j: waves 0 .. 5 own xi 0 .. 17
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        split ? a.part + ((size_t)tile_id * 2 + khalf) * (512 * kWinoBN) : nullptr, (short)0, split ? 512 * kWinoBN * 4 : 0, 0x00020000);
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
 #pragma unroll
@@ -995,15 +1076,16 @@ conv3x3_wino4_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
             const int xi = 3 * wave + j;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;            // tile
-                park[(xi * 32 + row) * 32 + l31] = acc[j][ph][e];
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * khe;           // tile
+                park[(xi * 32 + row) * 32 + l31e] = acc[j][ph][e];
             }
         }
         __syncthreads();
-        w4_output_pair(a, ldsU, ldsVR, tid, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
+        w4_output_pair(a, ldsU, ldsVR, tid_e, ph, img, oy0, ox0, n0, split, prs, w4_out_rsrc(a, img));
         __syncthreads();
     }
-    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid, tile_id, img, oy0, ox0, n0);
+    if (a.ksplit == 2) w4_ksplit_finish(a, ldsU, tid_e, tile_id, img, oy0, ox0, n0);
+    }   // tile loop
 }
 
 // =================================================================================================================================
@@ -1027,7 +1109,6 @@ constexpr int kWnVFloats = kW4Xi * kW4KS * kWnNT;                        // 2304
 // share of profiles/r06_f32w_pmc.txt) -- patch rows 8 .. 15 are stored two floats to the right (tile rows land on 0, 16, 2, 18).
 // As ds_read_b64 two channels are one group over 64 dwords: the plane stride is 32 (mod 64).
 static_assert(kWnPlane % 64 == 32 && kWnPitch >= kWnPatch + 2, "raw plane stride / skew room");
-constexpr int kWnRawAt = 3 * kWnVFloats;                                 // LDS (ldsVR): three V buffers, then two raw-patch buffers
 
 size_t wino4n_weight_floats(int Cin, int Cout) { return (size_t)((Cout + kWnBN - 1) / kWnBN) * (Cin / kW4KS) * kWnUFloats; }
 
@@ -1087,48 +1168,6 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
     const bool interior = pool ? ((oy >> 1) + 2 <= (a.H >> 1) && (ox >> 1) + 2 <= (a.W >> 1)) : (oy + 4 <= a.H && ox + 4 <= a.W);   // wave-uniform
     const unsigned voff = pool ? (unsigned)((((oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.Cout + n) * 4) : (unsigned)(((oy * a.W + ox) * a.Cout + n) * 4);
     w4_store_outputs(a, y, out_rs, voff, oy, ox, bias, interior);
-}
-
-// Persistent workgroups of the wide form (round 6): the grid is one workgroup per CU (or fewer), workgroup w walks the tiles
-// L, L + G, L + 2 G, ... (L = wino_xcd_remap(w, G): consecutive tiles -- the N tiles of a pixel block, neighbouring blocks -- on one
-// XCD, as before).  What it buys: the staging waves request the NEXT tile's first four slices in front of the epilogue of the current
-// one, so a tile's prologue no longer waits for a first-touch memory latency (~2.5 k of its ~6.5 k cycles).
-struct WnTile {
-    int img, oy0, ox0, n0, nt;
-};
-__device__ __forceinline__ WnTile wn_tile(int t, int tiles_x, int tiles_y, int n_tiles)
-{
-    WnTile r;
-    r.nt = t % n_tiles;
-    int mt = t / n_tiles;
-    const int tx = mt % tiles_x;
-    mt /= tiles_x;
-    const int ty = mt % tiles_y;
-    r.img = mt / tiles_y;
-    r.oy0 = ty * 16;
-    r.ox0 = tx * 16;
-    r.n0 = r.nt * kWnBN;
-    return r;
-}
-// tile + step, digit by digit with carries (st = wn_tile(step): its oy0 / ox0 carry the scaled digits): no division per tile
-__device__ __forceinline__ void wn_advance(WnTile &tl, const WnTile &st, int tiles_x, int tiles_y, int n_tiles)
-{
-    int nt = tl.nt + st.nt, c = nt >= n_tiles;
-    nt -= c ? n_tiles : 0;
-    int ox = tl.ox0 + st.ox0 + 16 * c;
-    c = ox >= 16 * tiles_x;
-    ox -= c ? 16 * tiles_x : 0;
-    int oy = tl.oy0 + st.oy0 + 16 * c;
-    c = oy >= 16 * tiles_y;
-    oy -= c ? 16 * tiles_y : 0;
-    tl.img += st.img + c;
-    tl.nt = nt; tl.n0 = nt * kWnBN; tl.ox0 = ox; tl.oy0 = oy;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_image_rsrc(const WinoArgs &a, int img)
-{
-    const long long xbytes = (long long)a.H * a.W * a.Cin * 4;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)img * a.H * a.W * a.Cin, (short)0,
-                                             (int)(xbytes > 0x7fffffffll ? 0x7fffffff : xbytes), 0x00020000);
 }
 
 // The staging role of the wide form (waves 12 .. 15, one per SIMD), one instantiation per wave: PART / HALF select the wave's QUARTER of
@@ -1538,7 +1577,10 @@ hipError_t launch_conv3x3_wino(const float *x, const float *u, const float *bias
         const int n_tiles = (Cout + kWinoBN - 1) / kWinoBN;
         const long long nblocks = (long long)tiles_x * tiles_y * B * n_tiles * a.ksplit;
         if (nblocks > 0x7fffffffll) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(conv3x3_wino4_f32_kernel, dim3((unsigned)nblocks), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
+        // variant 4: persistent, one workgroup per CU walks its tiles (wn_tile); variant 8: two workgroups per tile, one tile each
+        const long long cus = wino_cus_of_current_device();
+        const long long grid = (a.ksplit == 2 || nblocks < cus) ? nblocks : cus;
+        hipLaunchKernelGGL(conv3x3_wino4_f32_kernel, dim3((unsigned)grid), dim3(kW4Threads), 0, s, a, tiles_x, tiles_y, n_tiles);
         return hipGetLastError();
     }
     const int tiles_x = (W + 2 * kWinoTT - 1) / (2 * kWinoTT), tiles_y = (H + 2 * kWinoTT - 1) / (2 * kWinoTT);
