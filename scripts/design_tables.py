@@ -147,7 +147,7 @@ w("")
 w("### 5.6 Code objects of the shipped library (`tests/codeobj.py`; budgets held by `tests/test_host.py::test_kernel_register_budgets`)\n")
 tab = codeobj.table(os.path.join(ROOT, "tf_rpn_amd", "csrc", "librpn_hip.so"))
 keys = [r"conv3x3_split16_dma_kernel<true,(false|true),128,false>", r"conv3x3_split16_dma_kernel<true,false,64,(false|true)>", r"conv3x3_split_kernel<8,1,2,4,true,true,true>",
-        r"conv_igemm_f32_dma<2,2,2,2,(false|true),true>", r"conv_igemm_f32<2,2,2,2,false,false,true>", r"conv_igemm_f32<4,1,1,2,false,false,true>", r"conv3x3_wino4n_f32_kernel", r"conv3x3_wino4_f32_kernel", r"conv3x3_wino_f32_kernel",
+        r"conv_igemm_f32_dma<2,2,2,2,(false|true),true>", r"conv_igemm_f32<2,2,2,2,false,false,true>", r"conv_igemm_f32<4,1,1,2,false,false,true>", r"conv3x3_wino4n_f32_kernel", r"conv3x3_wino4_f32_kernel", r"conv3x3_wino_f32_kernel", r"conv_cin3_f32_mfma_kernel<true>",
         r"nms_kernel<true>", r"iou_map_rows_kernel<true,4,true,64>", r"stem_block_kernel<8>", r"ir_block_hrx3_kernel<16,96,32,24,2,false,1,1>",
         r"ir_block_x3_kernel<64,384,64,true>", r"pw_x3_kernel<96,96,8>", r"rpn_head_kernel<3,2,16>", r"decode_kernel"]
 w("| kernel | VGPRs | LDS bytes | threads | workgroups per CU (registers / LDS) | SGPR spills | scratch |")
