@@ -120,6 +120,28 @@ def test_first_layer_float32_matrix_pipe_kernel_is_exact_on_integers_at_full_siz
         assert len(wrong) == 0, "%d wrong values, first at %s: got %r want %r" % (len(wrong), wrong[0], got[tuple(wrong[0])], ref[tuple(wrong[0])])
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("shape", [(8, 125, 125, 256, 256), (4, 250, 250, 64, 128), (8, 31, 31, 512, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_full_size_layers_are_exact_on_integers(shape, precision):
+    """Race / hazard detector for the persistent conv kernels at the sizes the bench runs (a chip full of workgroups, several tiles per
+    workgroup): small-integer inputs, weights and biases make every product and every partial sum an integer below 2^24 -- exact in
+    float32 in ANY summation order, and exact in the f16x3 arithmetic too (an integer below 2048 is its own float16 `hi` half, `lo`
+    = 0; the power-of-two weight scale is exact) -- so the layer must equal torch's convolution BIT FOR BIT, twice.  (Tolerance tests
+    of small shapes did not see the store-data hazard of round 6: tests/test_host.py::test_no_unguarded_store_data_hazard.)"""
+    B, H, W, Cin, Cout = shape
+    rng = np.random.RandomState(Cin + Cout + H)
+    x = rng.randint(-3, 4, size=(B, H, W, Cin)).astype(np.float32)
+    w = rng.randint(-2, 3, size=(3, 3, Cin, Cout)).astype(np.float32)
+    b = rng.randint(-5, 6, size=(Cout,)).astype(np.float32)
+    assert 9 * Cin * 3 * 2 + 5 < 2 ** 24
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(3, 2, 0, 1), torch.from_numpy(b),
+                                     padding=1).clamp_(min=0).permute(0, 2, 3, 1).contiguous().numpy()
+    for _ in range(2):
+        got = _conv_gpu(x, w, b, 1, 1, 1, H, W, "relu", precision=precision)
+        wrong = np.argwhere(got != ref)
+        assert len(wrong) == 0, "%d wrong values, first at %s: got %r want %r" % (len(wrong), wrong[0], got[tuple(wrong[0])], ref[tuple(wrong[0])])
+
+
 def test_maxpool_and_depthwise():
     rng = np.random.RandomState(6)
     x = rng.uniform(-1, 1, size=(2, 125, 37, 64)).astype(np.float32)            # odd sizes: 'valid' floors
