@@ -1263,7 +1263,14 @@ __device__ __forceinline__ void w4n_staging_role(const WinoArgs &a, float *ldsA,
             float v[6];
             w4_bt6(T[i], v);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+            for (int j = 0; j < 6; ++j) {
+#ifdef RPN_EXP_WN_F16RATE    /* timing experiment (wrong results): what a transformed value would cost as hi + lo float16 halves */
+                const _Float16 h_ = (_Float16)v[j];
+                const _Float16 l_ = (_Float16)(v[j] - (float)h_);
+                v[j] = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, h_) | ((unsigned)__builtin_bit_cast(unsigned short, l_) << 16));
+#endif
+                vp[(6 * i + j) * (kW4KS * kWnNT)] = v[j];
+            }
         }
     };
     // Pipeline: pair P is requested in iteration P - 4 (register set P & 1), written to raws[P & 1] in iteration P - 3, transformed into
@@ -1432,13 +1439,21 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
         const float *Vn = ldsVR + vcur;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+#ifdef RPN_EXP_WN_F16RATE    /* timing experiment (wrong results): the slice's GEMM at the f16x3 rate -- 24 x 2048 flop = 3 products x 3 MFMAs of 16x16x32 */
+            using f16x8_e = __attribute__((ext_vector_type(8))) _Float16;
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+                acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_e, ureg[j][1]), __builtin_bit_cast(f16x8_e, ureg[j][0]), acc[j][nb], 0, 0, 0);
+            acc[j][3][0] += av[j];
+#else
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb)
                 acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ureg[j][nb >> 2][nb & 3], acc[j][nb], 0, 0, 0);
+#endif
             if (j == 0) { RPN_WN_LOAD_U(nxt, 0); } else if (j == 1) { RPN_WN_LOAD_U(nxt, 1); } else { RPN_WN_LOAD_U(nxt, 2); }
             av[j] = Vn[((3 * wave + j) * kW4KS) * kWnNT + v_lane];
         }
-#ifndef RPN_EXP_WN_NOSCHED
+#if !defined(RPN_EXP_WN_NOSCHED) && !defined(RPN_EXP_WN_F16RATE)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
