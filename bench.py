@@ -874,6 +874,19 @@ def c3_leg(hp, n=30):
     return out
 
 
+def _device_info():
+    """Which device of the pool ran this line (rank 0's): the f16x3 path is power / clock bound and the pool's devices differ by up
+    to ~8 % on it (NOTES.md round 6), the float32 paths by < 1 %."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+                "max_clock_mhz": int(getattr(p, "clock_rate", 0)) // 1000 or None,
+                "note": "devices of the pool measured 2 930-3 170 images/s on this workload with identical code (round 6)"}
+    except Exception as exc:                       # never fail the bench line over a property query
+        return {"error": str(exc)}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1178,6 +1191,7 @@ def main():
                        "nms_overlap": ("decode+NMS of step k on a second HIP stream, overlapping the convs of step k+1"
                                        + ("; all-gather of step k-1 issued behind the convs of step k" if use_dist else ""))
                                       if overlap else "serial on the conv stream"},
+            "device": _device_info(),
             "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "nms_stream_concurrent": side_stream_ok,      # measured (predictor._streams_overlap), rank 0
