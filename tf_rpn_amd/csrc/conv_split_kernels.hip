@@ -2243,7 +2243,9 @@ conv_cin3_kernel(const float *__restrict__ x, const float *__restrict__ w /* (27
 // have their tile offset in the loads' SCALAR offset (no per-lane address arithmetic), ReLU is one integer max.
 // Reference op: Conv2D(64, (3, 3), padding="same", activation="relu") = VGG16 block1_conv1 behind /root/reference/rpn.py:26-33.
 constexpr int kC3Rows = 8;                          // output rows per tile
-constexpr int kC3PatchRow = 200;                    // floats per staged patch row (198 used)
+constexpr int kC3PatchRow = 200;                    // floats per staged patch row (198 used).  (The B-operand reads are 2-way bank-conflicted by
+                                                    // construction -- four K lanes per pixel on a 3-float pixel stride cannot tile 64 banks; rocprofv3: 45 % of
+                                                    // this kernel's LDS cycles, which are < 1 % of its time.  A 201-float row changed nothing.)
 constexpr int kC3Stage = ((kC3Rows + 2) * 198 + 255) / 256;            // staging loads per thread (8)
 constexpr int kC3PatchFloats = (kC3Stage * 256 / 198 + 1) * kC3PatchRow;   // 10 rows + the row that takes the idle threads' writes
 struct C3Tile {

@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void w4n_output_pair(const WinoArgs &a, const float *
     for (int j = 0; j < 6; ++j) {
         float m[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * kWnNT + e_tile) * 64 + e_n];     // xi = 6 i + j
+        for (int i = 0; i < 6; ++i) m[i] = (i < 3 ? MsA : MsB)[((6 * (i % 3) + j) * kWnNT + e_tile) * 64 + (e_n ^ ((e_tile >> 2) * 16))];     // xi = 6 i + j (segment swizzle: see the parking stores)
         const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], ss = m[3] - m[4];
         R[0][j] = m[0] + pp + rr;
         R[1][j] = __builtin_fmaf(2.0f, ss, qq);
@@ -1492,7 +1492,9 @@ conv3x3_wino4n_f32_kernel(WinoArgs a, int tiles_x, int tiles_y, int n_tiles)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) park[(xi * kWnNT + 4 * k4e + r) * 64 + q * 16 + l15e] = acc[j][4 * ph + q][r];
+                for (int r = 0; r < 4; ++r)      // (16-channel segment XOR tile-row group: the four lane groups of a store are four tile rows
+                                                 //  = 256 floats apart, the same banks without it; the reader undoes it with a wave-uniform XOR)
+                    park[(xi * kWnNT + 4 * k4e + r) * 64 + ((q ^ k4e) * 16) + l15e] = acc[j][4 * ph + q][r];
         }
         __syncthreads();
         w4n_output_pair(a, ldsA, ldsVR, tid_e, ph, img, oy0, ox0, n0, w4_out_rsrc(a, img));
