@@ -2420,7 +2420,8 @@ bool conv_cin3_uses_f32_mfma(int B, int H, int W, int OH, int OW, int Cout, int 
     // (laboratory knob 0 = the vector-ALU kernel; same contract)
     static const int f32_mfma = RPN_LAB_KNOB("RPN_CIN3_F32_MFMA", 1);
     return f32_mfma && out_fmt == 0 && Cout == 64 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W &&
-           (act == ACT_RELU || act == ACT_LINEAR) && (long long)H * W * 256 < 0x7fffffffll && B > 0 && B <= 65535 && H > 0 && W > 0;
+           (act == ACT_RELU || act == ACT_LINEAR) && (long long)H * W * 256 < 0x7fffffffll && B > 0 && H > 0 && W > 0 &&
+           (long long)((W + 63) / 64) * ((H + 7) / 8) * B < 0x7fffffffll;            // (the tile count: 32-bit in the kernel)
 }
 
 // w: (27, Cout) float32 = HWIO flattened (BatchNorm scale already folded); out_fmt: 0 float32 NHWC, 1 SPLIT16
